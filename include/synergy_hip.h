@@ -1,0 +1,128 @@
+/*
+ * synergy_hip.h -- C ABI of the MI355X (gfx950) implementation of SynergyNet's
+ * inference hot path:
+ *
+ *   crops [B,3,120,120] -> MobileNetV2 -> 62-d 3DMM params -> 68 landmarks,
+ *   53215-vertex mesh, head pose.
+ *
+ * The reference has no FFI layer for this path; its boundary is the Python
+ * class synergy3DMM.SynergyNet (reference synergy3DMM.py:70-207).  Each entry
+ * point below names the reference method(s) it replaces.  The Python class
+ * synergynet_amd.synergy3DMM.SynergyNet binds these symbols with ctypes and
+ * keeps the reference's method set (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative
+ *     syn_status, and syn_last_error() returns a thread-local message;
+ *   - all tensor arguments of compute calls are DEVICE pointers owned by the
+ *     caller (e.g. torch-ROCm tensor.data_ptr()), fp32, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     are asynchronous on that stream;
+ *   - the library owns only its packed constants and its activation workspace;
+ *   - one handle per device; calls on one handle are not thread-safe, different
+ *     handles are independent.
+ */
+#ifndef SYNERGY_HIP_H
+#define SYNERGY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct syn_handle syn_handle;
+
+typedef enum {
+    SYN_OK = 0,
+    SYN_ERR_INVALID = -1,      /* bad argument (NULL pointer, B <= 0, wrong size ...) */
+    SYN_ERR_HIP = -2,          /* a HIP runtime call failed; see syn_last_error()     */
+    SYN_ERR_NOT_LOADED = -3,   /* compute call before the constants it needs          */
+    SYN_ERR_PARAM_LEN = -4     /* 'length of params mismatch' (synergy3DMM.py:126-129) */
+} syn_status;
+
+#define SYN_PARAM_DIM 62        /* 12 pose + 40 shape + 10 expression (synergy3DMM.py:30-37) */
+#define SYN_POOL_DIM 1280       /* pooled feature (mobilenetv2_backbone.py:179-182)          */
+#define SYN_STD_SIZE 120        /* utils/params.py:34                                        */
+
+const char *syn_last_error(void);
+int syn_abi_version(void);
+
+/* SynergyNet.__init__ (synergy3DMM.py:70-114): one handle per GPU. */
+int syn_create(int device, syn_handle **out);
+int syn_destroy(syn_handle *h);
+
+/* ---- constants ------------------------------------------------------------------- */
+
+/* Number of floats syn_load_backbone expects. */
+size_t syn_backbone_flat_count(void);
+
+/* load_weights (synergy3DMM.py:156-164) for the I2P.backbone.* part of the state_dict.
+ * `flat` is a HOST array: for every conv layer in network order
+ *   conv.weight (PyTorch [Cout,Cin/groups,kh,kw] order), bn.weight, bn.bias,
+ *   bn.running_mean, bn.running_var
+ * then classifier_ori.1.{weight,bias}, classifier_shape.1.{...}, classifier_exp.1.{...}
+ * (mobilenetv2_backbone.py:33-74,107-158).  BatchNorm (eval, eps 1e-5) is turned into a
+ * per-channel scale/shift and the weights are repacked for the kernels. */
+int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats);
+
+/* ParamsPack (utils/params.py:10-35) + the register_buffer block (synergy3DMM.py:95-105).
+ * HOST arrays: w_shp [3*n_vert,40], w_exp [3*n_vert,10], u [3*n_vert] (= u_shp+u_exp),
+ * param_mean/param_std [>=62] (first 62 used), keypoints [3*n_lmk] flat indices into the
+ * 3*n_vert axis ordered [3k,3k+1,3k+2] (utils/io.py:78-81). */
+int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u,
+                   const float *param_mean, const float *param_std,
+                   const int64_t *keypoints, int n_lmk, int n_vert);
+
+/* Multi-GPU: rank 0 loads from host arrays, exports its packed constants into a caller
+ * device buffer, the caller broadcasts that buffer (RCCL, e.g. torch.distributed.broadcast)
+ * and every other rank imports it.  No cross-GPU traffic after that. */
+size_t syn_constants_bytes(syn_handle *h);
+int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream);
+int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void *stream);
+
+/* ---- compute ------------------------------------------------------------------------ */
+
+/* Bytes of activation workspace the library keeps for a batch of B faces. */
+size_t syn_workspace_bytes(syn_handle *h, int B);
+
+/* forward_test (synergy3DMM.py:151-154 -> mobilenetv2_backbone.py:173-189).
+ * img   [B,3,120,120] fp32 NCHW, already (x-127.5)/128 (synergy3DMM.py:189-192)
+ * param [B,62] (ori 0:12, shape 12:52, exp 52:62);  pool [B,1280] or NULL. */
+int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, float *pool,
+                         void *stream);
+
+/* Same, from uint8 crops [B,120,120,3] (HWC, BGR as cv2 delivers them); the
+ * (x-127.5)/128 normalisation and the HWC->CHW permute (synergy3DMM.py:189-192) are fused
+ * into the first convolution. */
+int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img_hwc, int B, float *param,
+                            float *pool, void *stream);
+
+/* reconstruct_vertex_62 (synergy3DMM.py:116-149) fused with the ROI affine of
+ * _predict_vertices (utils/inference.py:127-138).
+ * param [B,param_len] whitened; param_len must be 62 (else SYN_ERR_PARAM_LEN).
+ * dense: 0 -> out [B,3,n_lmk], 1 -> out [B,3,n_vert].
+ * transform: y -> 121 - y (synergy3DMM.py:139,147).
+ * roi [B,5] (sx,sy,ex,ey,score) or NULL for no ROI affine (the batched torch method). */
+int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense,
+                    int transform, const float *roi, float *out, void *stream);
+
+/* predict_pose (utils/inference.py:146-157 -> parse_pose :86-92 -> P2sRt :33-43 ->
+ * matrix2angle_corr :45-62).  angles [B,3] degrees (double, like the reference's python
+ * floats), t3d [B,3] fp32 with the ROI affine on x,y; roi may be NULL. */
+int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles,
+             float *t3d, void *stream);
+
+/* ---- introspection (bench / profiling) --------------------------------------------- */
+
+/* Number of kernel launches one syn_backbone_forward issues, and the algorithmic FLOPs
+ * of its pointwise (MFMA) convolutions per face. */
+int syn_backbone_launch_count(syn_handle *h);
+double syn_backbone_flops_per_face(void);
+double syn_pointwise_flops_per_face(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNERGY_HIP_H */

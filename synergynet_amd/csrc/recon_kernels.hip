@@ -1,0 +1,219 @@
+// gfx950 kernels for the 3DMM parameter -> geometry stage of SynergyNet's inference path:
+//   reconstruct_vertex_62  (reference synergy3DMM.py:116-149, batched torch)
+//   param2vert / _predict_vertices (reference utils/inference.py:64-84,127-138, numpy per face)
+//   predict_pose -> parse_pose -> P2sRt -> matrix2angle_corr (utils/inference.py:33-62,86-92,146-157)
+//
+//   S[b] = u + W_shp a_shp[b] + W_exp a_exp[b]          (3N-vector, xyz interleaved)
+//   V[b] = P[b] * reshape(S[b], (3,N), 'F') + t[b];  V[b][1] = 121 - V[b][1];  ROI affine
+//
+// The contraction is a [B,52] x [52,3N] GEMM (K = 40 shape + 10 expression + the mean u with
+// coefficient 1 + one zero pad) on the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32, with
+// rows = faces and columns = vertices so that a stored row segment is 32 consecutive vertices of
+// one face (128 B).  The output (638,580 B per face) is the compulsory HBM traffic; the basis is
+// read once per wave and kept in registers while the wave walks its share of the faces.
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFaceRec = 64;   // floats per face in the prepared record: alpha[52] | M[9] | T[3]
+
+// -------------------------------------------------------------------------------------
+// Per-face prologue: de-whiten (param*std+mean, synergy3DMM.py:127), split into pose / alpha
+// (parse_param_62, :30-37) and fold the pose matrix with the y flip (:139,:147) and the optional
+// ROI affine (utils/inference.py:129-136) into one affine map  out = Mx * S + T.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void recon_prep_kernel(const float *__restrict__ param, const float *__restrict__ mean,
+                                                        const float *__restrict__ stdv, const float *__restrict__ roi,
+                                                        int transform, float *__restrict__ rec, int B) {
+    const int b = blockIdx.x;
+    const int l = threadIdx.x;
+    __shared__ float p[64];
+    if (l < kParam) p[l] = param[(size_t)b * kParam + l] * stdv[l] + mean[l];
+    __syncthreads();
+    float *r = rec + (size_t)b * kFaceRec;
+    if (l < 50) r[l] = p[12 + l];
+    else if (l == 50) r[l] = 1.0f;       // coefficient of the mean shape u
+    else if (l == 51) r[l] = 0.0f;
+    else if (l < 55) {
+        const int c = l - 52;            // output row: 0 = x, 1 = y, 2 = z
+        float sc = 1.0f, of = 0.0f;
+        if (roi) {
+            const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
+            const float scx = (ex - sx) / 120.0f, scy = (ey - sy) / 120.0f;
+            if (c == 0) { sc = scx; of = sx; }
+            else if (c == 1) { sc = scy; of = sy; }
+            else { sc = (scx + scy) * 0.5f; }
+        }
+        float m0 = p[4 * c + 0], m1 = p[4 * c + 1], m2 = p[4 * c + 2], t = p[4 * c + 3];
+        if (transform && c == 1) { m0 = -m0; m1 = -m1; m2 = -m2; t = (float)(kImg + 1) - t; }
+        r[52 + 3 * c + 0] = m0 * sc;
+        r[52 + 3 * c + 1] = m1 * sc;
+        r[52 + 3 * c + 2] = m2 * sc;
+        r[61 + c] = t * sc + of;
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Main contraction + pose epilogue.
+//
+// v_mfma_f32_32x32x2_f32:  D[i][j] += sum_{k<2} A[i][k] B[k][j];  lane l supplies A[i = l&31][k = l>>5]
+// and B[k = l>>5][j = l&31]; lane l owns D column j = l&31, rows i = (r&3) + 8*(r>>2) + 4*(l>>5), r < 16.
+//   rows i  = 32 faces       (A operand = alpha)
+//   cols j  = 32 vertices    (B operand = one coordinate plane of the basis)
+// K = 52 is walked as 6 chunks of 8 + one chunk of 4: per chunk a lane fetches ONE float4 (float2 for
+// the tail) holding logical k = 8t + 4h + s (h = l>>5) and feeds element s to MFMA step s, identically
+// for both operands.  The basis is pre-packed by the host in exactly that per-lane order
+//   Bp[tile][coord][chunk][lane][4]      (tile = 32 vertices; 6*1 KiB + 512 B per coord)
+// so every basis load of a wave is one fully coalesced 1 KiB (512 B) line set.
+// A wave owns vertex tile T and a contiguous range of 32-face tiles: 3 x 26 basis registers stay
+// resident while alpha fragments stream in from the 256-byte per-face records.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ rec, const float *__restrict__ basis,
+                                                    float *__restrict__ out, int B, int n_vert, int n_tiles,
+                                                    int n_split, int ftiles_per_split, int n_ftiles) {
+    __shared__ __attribute__((aligned(16))) float smt[4][32][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
+    const int T = task / n_split, split = task - T * n_split;
+    if (T >= n_tiles) return;
+    const int j = lane & 31, h = lane >> 5;
+
+    // resident basis fragments for the three coordinate planes of this vertex tile
+    f32x4 bw[3][6];
+    f32x2 bt[3];
+    const float *bp = basis + (size_t)T * 3 * (kBasisK * 32);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *bc = bp + c * (kBasisK * 32);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) bw[c][t] = *(const f32x4 *)(bc + t * 256 + lane * 4);
+        bt[c] = *(const f32x2 *)(bc + 6 * 256 + lane * 2);
+    }
+    const int v = T * 32 + j;
+    const bool v_ok = v < n_vert;
+    const int ft0 = split * ftiles_per_split;
+    int ft1 = ft0 + ftiles_per_split;
+    ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
+    float(*mt)[12] = smt[wave];
+
+    for (int ft = ft0; ft < ft1; ++ft) {
+        const int f0 = ft * 32;
+        int fa = f0 + j;
+        fa = fa < B ? fa : B - 1;
+        const float *ra = rec + (size_t)fa * kFaceRec;
+        f32x4 aw[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) aw[t] = *(const f32x4 *)(ra + 8 * t + 4 * h);
+        const f32x2 at = *(const f32x2 *)(ra + 48 + 2 * h);
+        // stage this face tile's 32 x (M[9],T[3]) into the wave's private LDS slice
+        if (lane < 32) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(f32x4 *)&mt[lane][4 * q] = *(const f32x4 *)(ra + 52 + 4 * q);
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t][s], bw[c][t][s], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s], bt[c][s], acc[c], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int f = f0 + i;
+            const f32x4 q0 = *(const f32x4 *)&mt[i][0];
+            const f32x4 q1 = *(const f32x4 *)&mt[i][4];
+            const f32x4 q2 = *(const f32x4 *)&mt[i][8];
+            const float sx = acc[0][r], sy = acc[1][r], sz = acc[2][r];
+            const float ox = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
+            const float oy = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
+            const float oz = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
+            if (v_ok && f < B) {
+                float *o = out + (size_t)f * 3 * n_vert + v;
+                o[0] = ox;
+                o[n_vert] = oy;
+                o[2 * (size_t)n_vert] = oz;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // LDS slice is rewritten by the next face tile
+    }
+}
+
+// rec: [B,64] scratch for the per-face records (part of the library workspace)
+void launch_reconstruct(const float *param, const float *mean62, const float *std62, const float *basis, int n_vert,
+                        int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec) {
+    recon_prep_kernel<<<B, 64, 0, s>>>(param, mean62, std62, roi, transform, rec, B);
+    const int n_tiles = nvp / 32;
+    const int n_ftiles = (B + 31) / 32;
+    int n_split = (4096 + n_tiles - 1) / n_tiles;            // aim for >= 4096 waves (4 per SIMD)
+    n_split = n_split < 1 ? 1 : n_split;
+    n_split = n_split > n_ftiles ? n_ftiles : n_split;
+    const int per = (n_ftiles + n_split - 1) / n_split;
+    n_split = (n_ftiles + per - 1) / per;
+    const int tasks = n_tiles * n_split;
+    recon_kernel<<<(tasks + 3) / 4, 256, 0, s>>>(rec, basis, out, B, n_vert, n_tiles, n_split, per, n_ftiles);
+}
+
+// -------------------------------------------------------------------------------------
+// predict_pose: one lane per face.  fp32 for the de-whitening / normalisation / cross product
+// (numpy float32 in the reference), double for asin/atan2/cos (python math on the float32 values).
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ param, const float *__restrict__ mean,
+                                                  const float *__restrict__ stdv, const float *__restrict__ roi,
+                                                  double *__restrict__ angles, float *__restrict__ t3d, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = param[(size_t)b * kParam + i] * stdv[i] + mean[i];
+    const float n1 = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);      // P2sRt (:33-43)
+    const float n2 = sqrtf(p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+    const float r1[3] = {p[0] / n1, p[1] / n1, p[2] / n1};
+    const float r2[3] = {p[4] / n2, p[5] / n2, p[6] / n2};
+    const float r3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    // matrix2angle_corr (:45-62): R = [r1; r2; r3]
+    const double PI = 3.14159265358979323846;
+    double x, y, z;
+    if (r3[0] != 1.0f && r3[0] != -1.0f) {
+        x = asin((double)r3[0]);
+        const double cx = cos(x);
+        y = atan2((double)r2[2] / cx, (double)r3[2] / cx);
+        z = atan2((double)r1[1] / cx, (double)r1[0] / cx);
+    } else {                                                                // gimbal lock
+        z = 0.0;
+        if (r3[0] == -1.0f) { x = PI / 2; y = z + atan2((double)r1[1], (double)r1[2]); }
+        else                { x = -PI / 2; y = -z + atan2(-(double)r1[1], -(double)r1[2]); }
+    }
+    angles[(size_t)b * 3 + 0] = x * 180.0 / PI;
+    angles[(size_t)b * 3 + 1] = y * 180.0 / PI;
+    angles[(size_t)b * 3 + 2] = z * 180.0 / PI;
+    float tx = p[3], ty = p[7], tz = p[11];
+    if (roi) {                                                              // predict_pose (:149-154)
+        const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
+        tx = tx * ((ex - sx) / 120.0f) + sx;
+        ty = ty * ((ey - sy) / 120.0f) + sy;
+    }
+    t3d[(size_t)b * 3 + 0] = tx;
+    t3d[(size_t)b * 3 + 1] = ty;
+    t3d[(size_t)b * 3 + 2] = tz;
+}
+
+void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi, double *angles,
+                 float *t3d, int B, hipStream_t s) {
+    pose_kernel<<<(B + 63) / 64, 64, 0, s>>>(param, mean62, std62, roi, angles, t3d, B);
+}
+
+}  // namespace syn

@@ -1,0 +1,50 @@
+// Internal launcher interface between the C-ABI host code (synergy_abi.hip) and the
+// gfx950 kernels (backbone_kernels.hip, recon_kernels.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace syn {
+
+constexpr int kImg = 120;           // utils/params.py:34
+constexpr int kParam = 62;
+constexpr int kPool = 1280;
+constexpr int kBasisK = 52;         // 40 shape + 10 expression + 1 (mean u, alpha = 1) + 1 zero pad
+constexpr int kVertTile = 32;        // vertices per reconstruction tile (one 32x32 MFMA column block)
+
+// ---- backbone ---------------------------------------------------------------------
+// Activations are NHWC fp32: act[b][y][x][c].
+
+// 3x3 stride-2 stem conv + BN scale/shift + ReLU6: NCHW fp32 (or HWC uint8) -> NHWC [B,60,60,32].
+void launch_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w27x32,
+                 const float *scale, const float *shift, float *out, int B, hipStream_t s);
+
+// Pointwise 1x1 conv as an fp32-MFMA GEMM with fused BN scale/shift (+ReLU6) (+residual):
+//   C[m][n] = epi(sum_k A[m][k] * W[n][k]),  A [M,K], W [Npad,Kpad] zero padded, C [M,N].
+void launch_pointwise(const float *A, const float *W, const float *scale, const float *shift,
+                      const float *residual, float *C, int M, int K, int Kpad, int N,
+                      int relu6, hipStream_t s);
+
+// Depthwise 3x3 (pad 1, stride 1|2) + BN scale/shift + ReLU6, NHWC.
+void launch_depthwise(const float *in, const float *w9xC, const float *scale, const float *shift,
+                      float *out, int B, int Hin, int Hout, int C, int stride, hipStream_t s);
+
+// Global average pool over 4x4 + the three linear heads (one [62,1280] GEMV per face).
+void launch_pool_fc(const float *feat /*[B,16,1280]*/, const float *Wfc /*[64,1280]*/,
+                    const float *bias /*[64]*/, float *param /*[B,62]*/, float *pool /*nullable*/,
+                    int B, hipStream_t s);
+
+// ---- reconstruction -----------------------------------------------------------------
+// basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):
+//   Bp[tile][coord x|y|z][chunk][lane][4], K = 52: 0..39 shape, 40..49 expression,
+//   50 = mean u (alpha 1), 51 = 0;  nvp = n_vert rounded up to 32.
+// rec: [B,64] float scratch for the per-face records (alpha[52] | M[9] | T[3]).
+void launch_reconstruct(const float *param, const float *mean62, const float *std62,
+                        const float *basis, int n_vert, int nvp, const float *roi,
+                        int transform, float *out, int B, hipStream_t s, float *rec);
+
+void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
+                 double *angles, float *t3d, int B, hipStream_t s);
+
+}  // namespace syn

@@ -1,0 +1,456 @@
+// Host side of the C ABI declared in include/synergy_hip.h: constant packing (BatchNorm -> per
+// channel scale/shift, weight repack, basis repack into MFMA operand order), workspace, and the
+// launch sequence of the MobileNetV2 forward (reference mobilenetv2_backbone.py:173-189).
+#include "../../include/synergy_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "syn_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(SYN_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {   // torch tracks the current device per thread: never leave it changed
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+enum Kind { STEM = 0, PW = 1, DW = 2 };
+
+struct Layer {
+    Kind kind;
+    int cin, cout, stride, relu6, residual;
+    int hin, hout;       // spatial size in / out
+    int feature;         // index into .features
+    int kpad, npad;      // packed GEMM dims (PW)
+    size_t src_w;        // offsets (floats) into the flat host input
+    size_t dst_w, dst_scale, dst_shift;   // offsets (floats) into the packed device blob
+};
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Network table: reference mobilenetv2_backbone.py:107-117 (t,c,n,s), :129-143 (features), :55 (residual).
+struct Net {
+    std::vector<Layer> layers;
+    size_t flat_count = 0;      // floats in the host flat input (incl. heads)
+    size_t src_fc = 0;
+    size_t packed_count = 0;    // floats in the packed device blob
+    size_t dst_fc_w = 0, dst_fc_b = 0;
+    size_t max_io = 0, max_hidden = 0;   // per-face activation floats (block in/out, expanded)
+    double flops = 0, pw_flops = 0;
+    Net() {
+        static const int cfg[7][4] = {{1, 16, 1, 1}, {6, 24, 2, 2}, {6, 32, 3, 2}, {6, 64, 4, 2},
+                                      {6, 96, 3, 1}, {6, 160, 3, 2}, {6, 320, 1, 1}};
+        auto add = [&](Kind k, int cin, int cout, int stride, int relu6, int residual, int hin, int feature) {
+            Layer L{};
+            L.kind = k; L.cin = cin; L.cout = cout; L.stride = stride; L.relu6 = relu6; L.residual = residual;
+            L.hin = hin; L.hout = (stride == 2) ? (hin + 1) / 2 : hin;   // k=3,p=1,s=2: floor((h-1)/2)+1
+            L.feature = feature;
+            L.kpad = round_up(cin, 16); L.npad = round_up(cout, 64);
+            layers.push_back(L);
+        };
+        add(STEM, 3, 32, 2, 1, 0, 120, 0);
+        int inp = 32, h = 60, f = 1;
+        for (auto &c : cfg) {
+            for (int i = 0; i < c[2]; ++i) {
+                const int stride = i == 0 ? c[3] : 1, hid = inp * c[0];
+                const int res = (stride == 1 && inp == c[1]);
+                if (c[0] != 1) add(PW, inp, hid, 1, 1, 0, h, f);
+                add(DW, hid, hid, stride, 1, 0, h, f);
+                h = layers.back().hout;
+                add(PW, hid, c[1], 1, 0, res, h, f);
+                inp = c[1];
+                ++f;
+            }
+        }
+        add(PW, 320, 1280, 1, 1, 0, h, 18);
+        size_t src = 0, dst = 0;
+        for (auto &L : layers) {
+            size_t wn, wp;
+            if (L.kind == STEM) { wn = 32 * 27; wp = 27 * 32; }
+            else if (L.kind == DW) { wn = (size_t)L.cout * 9; wp = 9 * (size_t)L.cout; }
+            else { wn = (size_t)L.cout * L.cin; wp = (size_t)L.npad * L.kpad; }
+            const int cpad = L.kind == PW ? L.npad : L.cout;
+            L.src_w = src; src += wn + 4 * (size_t)L.cout;
+            L.dst_w = dst; dst += wp;
+            L.dst_scale = dst; dst += cpad;
+            L.dst_shift = dst; dst += cpad;
+            const double pix = (double)L.hout * L.hout;
+            const double f2 = L.kind == STEM ? 2.0 * 27 * 32 * pix : L.kind == DW ? 2.0 * 9 * L.cout * pix
+                                                                                   : 2.0 * L.cin * (double)L.cout * pix;
+            flops += f2;
+            if (L.kind == PW) pw_flops += f2;
+            const size_t out_sz = (size_t)L.cout * L.hout * L.hout;
+            const bool hidden = (L.kind == DW) || (L.kind == PW && L.relu6);   // expand / dw outputs (and features.18)
+            if (hidden) max_hidden = out_sz > max_hidden ? out_sz : max_hidden;
+            else max_io = out_sz > max_io ? out_sz : max_io;
+        }
+        src_fc = src; src += 62 * 1280 + 62;
+        flat_count = src;
+        dst_fc_w = dst; dst += 64 * 1280;
+        dst_fc_b = dst; dst += 64;
+        packed_count = dst;
+        flops += 2.0 * 1280 * 62;
+    }
+};
+
+const Net &net() {
+    static const Net n;
+    return n;
+}
+
+struct ConstHeader {   // first 256 bytes of an exported constants buffer
+    uint64_t magic;
+    uint32_t version, has_backbone, has_basis, n_vert, n_lmk, nvp, nlp, pad0;
+    uint64_t backbone_floats, basis_floats, total_bytes;
+    uint8_t reserved[256 - 8 - 8 * 4 - 3 * 8];
+};
+static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
+constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
+
+}  // namespace
+
+struct syn_handle {
+    int device = 0;
+    float *d_backbone = nullptr;   // packed_count floats
+    float *d_basis = nullptr;      // dense tiles | landmark tiles | mean[64] | std[64]
+    size_t basis_floats = 0;
+    int n_vert = 0, n_lmk = 0, nvp = 0, nlp = 0;
+    float *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+size_t basis_float_count(int nvp, int nlp) { return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 128; }
+const float *basis_dense(const syn_handle *h) { return h->d_basis; }
+const float *basis_lmk(const syn_handle *h) { return h->d_basis + (size_t)h->nvp * 3 * syn::kBasisK; }
+const float *basis_mean(const syn_handle *h) { return h->d_basis + (size_t)(h->nvp + h->nlp) * 3 * syn::kBasisK; }
+const float *basis_std(const syn_handle *h) { return basis_mean(h) + 64; }
+
+size_t ws_floats_per_face() { return 2 * net().max_io + 2 * net().max_hidden + 64; }
+
+int ensure_ws(syn_handle *h, int B) {
+    const size_t need = ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
+    if (need <= h->ws_bytes) return SYN_OK;
+    if (h->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
+    HIP_TRY(hipMalloc((void **)&h->ws, need));
+    h->ws_bytes = need;
+    return SYN_OK;
+}
+
+// Pack one 32-vertex tile plane set in MFMA-operand lane order (see recon_kernels.hip):
+// dst[(tile*3 + c) * 1664 + chunk*256 + lane*4 + s] = Wfull[c][32*tile + (lane&31)][8*chunk + 4*(lane>>5) + s]
+void pack_basis_tiles(float *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
+                      const int64_t *rows /* nullable: row index triplets for landmarks */) {
+    auto wfull = [&](int v, int c, int k) -> float {
+        if (v >= n_rows_valid) return 0.f;
+        const size_t row = rows ? (size_t)rows[3 * v + c] : (size_t)3 * v + c;   // flat[3j+i] = coord i of vertex j
+        if (k < 40) return w_shp[row * 40 + k];
+        if (k < 50) return w_exp[row * 10 + (k - 40)];
+        if (k == 50) return u[row];
+        return 0.f;
+    };
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < 3; ++c) {
+            float *d = dst + ((size_t)t * 3 + c) * (syn::kBasisK * 32);
+            for (int chunk = 0; chunk < 6; ++chunk)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s)
+                        d[chunk * 256 + lane * 4 + s] = wfull(32 * t + (lane & 31), c, 8 * chunk + 4 * (lane >> 5) + s);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 2; ++s)
+                    d[6 * 256 + lane * 2 + s] = wfull(32 * t + (lane & 31), c, 48 + 2 * (lane >> 5) + s);
+        }
+}
+
+int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, float *param, float *pool, hipStream_t s,
+                 int stop_feature = -1, float *feature_out = nullptr) {
+    const Net &n = net();
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    float *X = h->ws;
+    float *Y = X + (size_t)B * n.max_io;
+    float *H1 = Y + (size_t)B * n.max_io;
+    float *H2 = H1 + (size_t)B * n.max_hidden;
+    const float *P = h->d_backbone;
+    const size_t nl = n.layers.size();
+    for (size_t li = 0; li < nl; ++li) {
+        const Layer &L = n.layers[li];
+        const float *w = P + L.dst_w, *sc = P + L.dst_scale, *sh = P + L.dst_shift;
+        if (L.kind == STEM) {
+            syn::launch_stem(img, img8, w, sc, sh, X, B, s);
+        } else if (L.kind == DW) {
+            // input: expanded H1, or the block input X for the t=1 block (no expand conv, :58-60)
+            const bool has_expand = li > 0 && n.layers[li - 1].kind == PW && n.layers[li - 1].feature == L.feature;
+            syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
+        } else if (L.feature == 18) {
+            syn::launch_pointwise(X, w, sc, sh, nullptr, H1, B * L.hout * L.hout, L.cin, L.kpad, L.cout, 1, s);
+        } else if (L.relu6) {   // expand
+            syn::launch_pointwise(X, w, sc, sh, nullptr, H1, B * L.hout * L.hout, L.cin, L.kpad, L.cout, 1, s);
+        } else {                // linear project (+ residual), then the block output becomes the next input
+            syn::launch_pointwise(H2, w, sc, sh, L.residual ? X : nullptr, Y, B * L.hout * L.hout, L.cin, L.kpad, L.cout, 0, s);
+            float *t = X; X = Y; Y = t;
+        }
+        // test hook (syn_debug_feature): hand back the NHWC output of .features[stop_feature]
+        if (stop_feature >= 0 && L.feature == stop_feature && (li + 1 == nl || n.layers[li + 1].feature != L.feature)) {
+            const float *src = L.feature == 18 ? H1 : X;
+            HIP_TRY(hipMemcpyAsync(feature_out, src, (size_t)B * L.cout * L.hout * L.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+            return SYN_OK;
+        }
+    }
+    syn::launch_pool_fc(H1, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, s);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *syn_last_error(void) { return g_err.c_str(); }
+int syn_abi_version(void) { return 1; }
+
+int syn_create(int device, syn_handle **out) {
+    if (!out) return fail(SYN_ERR_INVALID, "syn_create: out is NULL");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(SYN_ERR_INVALID, "syn_create: device %d of %d", device, count);
+    syn_handle *h = new syn_handle();
+    h->device = device;
+    *out = h;
+    return SYN_OK;
+}
+
+int syn_destroy(syn_handle *h) {
+    if (!h) return SYN_OK;
+    DeviceGuard g(h->device);
+    if (h->d_backbone) (void)hipFree(h->d_backbone);
+    if (h->d_basis) (void)hipFree(h->d_basis);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+    return SYN_OK;
+}
+
+size_t syn_backbone_flat_count(void) { return net().flat_count; }
+double syn_backbone_flops_per_face(void) { return net().flops; }
+double syn_pointwise_flops_per_face(void) { return net().pw_flops; }
+int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 1; }
+
+int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
+    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone: NULL argument");
+    const Net &n = net();
+    if (n_floats != n.flat_count)
+        return fail(SYN_ERR_INVALID, "syn_load_backbone: got %zu floats, the MobileNetV2 backbone has %zu", n_floats, n.flat_count);
+    std::vector<float> pk(n.packed_count, 0.f);
+    for (const Layer &L : n.layers) {
+        const float *w = flat + L.src_w;
+        size_t wn = L.kind == STEM ? 32 * 27 : L.kind == DW ? (size_t)L.cout * 9 : (size_t)L.cout * L.cin;
+        const float *gamma = w + wn, *beta = gamma + L.cout, *mean = beta + L.cout, *var = mean + L.cout;
+        float *dw = pk.data() + L.dst_w;
+        if (L.kind == STEM) {            // [32][3][3][3] -> [ci*9+ky*3+kx][32]
+            for (int co = 0; co < 32; ++co)
+                for (int t = 0; t < 27; ++t) dw[t * 32 + co] = w[co * 27 + t];
+        } else if (L.kind == DW) {       // [C][1][3][3] -> [tap][C]
+            for (int c = 0; c < L.cout; ++c)
+                for (int t = 0; t < 9; ++t) dw[(size_t)t * L.cout + c] = w[(size_t)c * 9 + t];
+        } else {                         // [N][K] -> zero padded [Npad][Kpad]
+            for (int nn = 0; nn < L.cout; ++nn)
+                memcpy(dw + (size_t)nn * L.kpad, w + (size_t)nn * L.cin, sizeof(float) * L.cin);
+        }
+        // eval-mode BatchNorm (eps 1e-5) as y = x*scale + shift, the form torch's CPU kernel uses
+        for (int c = 0; c < L.cout; ++c) {
+            const float inv = 1.0f / sqrtf(var[c] + 1e-5f);
+            const float a = gamma[c] * inv;
+            pk[L.dst_scale + c] = a;
+            pk[L.dst_shift + c] = beta[c] - mean[c] * a;
+        }
+    }
+    // heads: ori[12] | shape[40] | exp[10] concatenated in that order (mobilenetv2_backbone.py:184-188)
+    {
+        const float *src = flat + n.src_fc;
+        static const int hn[3] = {12, 40, 10};
+        int row = 0;
+        for (int k = 0; k < 3; ++k) {
+            memcpy(pk.data() + n.dst_fc_w + (size_t)row * 1280, src, sizeof(float) * hn[k] * 1280);
+            src += (size_t)hn[k] * 1280;
+            memcpy(pk.data() + n.dst_fc_b + row, src, sizeof(float) * hn[k]);
+            src += hn[k];
+            row += hn[k];
+        }
+    }
+    DeviceGuard g(h->device);
+    if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
+    return SYN_OK;
+}
+
+int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u, const float *param_mean,
+                   const float *param_std, const int64_t *keypoints, int n_lmk, int n_vert) {
+    if (!h || !w_shp || !w_exp || !u || !param_mean || !param_std || !keypoints)
+        return fail(SYN_ERR_INVALID, "syn_load_basis: NULL argument");
+    if (n_vert <= 0 || n_lmk <= 0) return fail(SYN_ERR_INVALID, "syn_load_basis: n_vert=%d n_lmk=%d", n_vert, n_lmk);
+    for (int i = 0; i < 3 * n_lmk; ++i)
+        if (keypoints[i] < 0 || keypoints[i] >= (int64_t)3 * n_vert)
+            return fail(SYN_ERR_INVALID, "syn_load_basis: keypoints[%d]=%lld out of range", i, (long long)keypoints[i]);
+    const int nvp = round_up(n_vert, 32), nlp = round_up(n_lmk, 32);
+    const size_t total = basis_float_count(nvp, nlp);
+    std::vector<float> pk(total, 0.f);
+    pack_basis_tiles(pk.data(), n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
+    // landmark sub-basis: w_*_base = w_*[keypoints], u_base = u[keypoints] (utils/params.py:31-33)
+    pack_basis_tiles(pk.data() + (size_t)nvp * 3 * syn::kBasisK, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
+    float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
+    memcpy(ms, param_mean, sizeof(float) * 62);
+    memcpy(ms + 64, param_std, sizeof(float) * 62);
+    DeviceGuard g(h->device);
+    if (h->d_basis && h->basis_floats != total) { HIP_TRY(hipFree(h->d_basis)); h->d_basis = nullptr; }
+    if (!h->d_basis) HIP_TRY(hipMalloc((void **)&h->d_basis, total * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_basis, pk.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    h->basis_floats = total; h->n_vert = n_vert; h->n_lmk = n_lmk; h->nvp = nvp; h->nlp = nlp;
+    return SYN_OK;
+}
+
+size_t syn_constants_bytes(syn_handle *h) {
+    if (!h) return 0;
+    return sizeof(ConstHeader) + ((h->d_backbone ? net().packed_count : 0) + (h->d_basis ? h->basis_floats : 0)) * sizeof(float);
+}
+
+int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream) {
+    if (!h || !dev_dst) return fail(SYN_ERR_INVALID, "syn_export_constants: NULL argument");
+    const size_t need = syn_constants_bytes(h);
+    if (bytes < need) return fail(SYN_ERR_INVALID, "syn_export_constants: buffer %zu < %zu bytes", bytes, need);
+    ConstHeader hd{};
+    hd.magic = kMagic; hd.version = 1;
+    hd.has_backbone = h->d_backbone ? 1 : 0; hd.has_basis = h->d_basis ? 1 : 0;
+    hd.n_vert = h->n_vert; hd.n_lmk = h->n_lmk; hd.nvp = h->nvp; hd.nlp = h->nlp;
+    hd.backbone_floats = hd.has_backbone ? net().packed_count : 0;
+    hd.basis_floats = hd.has_basis ? h->basis_floats : 0;
+    hd.total_bytes = need;
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    char *d = (char *)dev_dst;
+    HIP_TRY(hipMemcpyAsync(d, &hd, sizeof hd, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // hd is a stack object
+    d += sizeof hd;
+    if (hd.has_backbone) {
+        HIP_TRY(hipMemcpyAsync(d, h->d_backbone, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        d += hd.backbone_floats * sizeof(float);
+    }
+    if (hd.has_basis) HIP_TRY(hipMemcpyAsync(d, h->d_basis, hd.basis_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SYN_OK;
+}
+
+int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void *stream) {
+    if (!h || !dev_src) return fail(SYN_ERR_INVALID, "syn_import_constants: NULL argument");
+    if (bytes < sizeof(ConstHeader)) return fail(SYN_ERR_INVALID, "syn_import_constants: %zu bytes is smaller than the header", bytes);
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    ConstHeader hd{};
+    HIP_TRY(hipMemcpyAsync(&hd, dev_src, sizeof hd, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (hd.magic != kMagic || hd.version != 1) return fail(SYN_ERR_INVALID, "syn_import_constants: bad magic/version");
+    if (hd.total_bytes > bytes) return fail(SYN_ERR_INVALID, "syn_import_constants: header says %llu bytes, buffer has %zu",
+                                            (unsigned long long)hd.total_bytes, bytes);
+    if (hd.has_backbone && hd.backbone_floats != net().packed_count)
+        return fail(SYN_ERR_INVALID, "syn_import_constants: backbone size mismatch");
+    if (hd.has_basis && hd.basis_floats != basis_float_count(hd.nvp, hd.nlp))
+        return fail(SYN_ERR_INVALID, "syn_import_constants: basis size mismatch");
+    const char *d = (const char *)dev_src + sizeof hd;
+    if (hd.has_backbone) {
+        if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, hd.backbone_floats * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(h->d_backbone, d, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        d += hd.backbone_floats * sizeof(float);
+    }
+    if (hd.has_basis) {
+        if (h->d_basis && h->basis_floats != hd.basis_floats) { HIP_TRY(hipFree(h->d_basis)); h->d_basis = nullptr; }
+        if (!h->d_basis) HIP_TRY(hipMalloc((void **)&h->d_basis, hd.basis_floats * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(h->d_basis, d, hd.basis_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        h->basis_floats = hd.basis_floats; h->n_vert = hd.n_vert; h->n_lmk = hd.n_lmk; h->nvp = hd.nvp; h->nlp = hd.nlp;
+    }
+    return SYN_OK;
+}
+
+size_t syn_workspace_bytes(syn_handle *, int B) {
+    if (B <= 0) return 0;
+    return ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
+}
+
+int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, float *pool, void *stream) {
+    if (!h || !img || !param) return fail(SYN_ERR_INVALID, "syn_backbone_forward: NULL argument");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_backbone_forward: B=%d", B);
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward: backbone weights not loaded");
+    DeviceGuard g(h->device);
+    return run_backbone(h, img, nullptr, B, param, pool, (hipStream_t)stream);
+}
+
+int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img, int B, float *param, float *pool, void *stream) {
+    if (!h || !img || !param) return fail(SYN_ERR_INVALID, "syn_backbone_forward_u8: NULL argument");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_backbone_forward_u8: B=%d", B);
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward_u8: backbone weights not loaded");
+    DeviceGuard g(h->device);
+    return run_backbone(h, nullptr, img, B, param, pool, (hipStream_t)stream);
+}
+
+// Test hook, not part of include/synergy_hip.h: output of .features[feature] as NHWC [B,H,W,C].
+int syn_debug_feature(syn_handle *h, const float *img, int B, int feature, float *out, void *stream) {
+    if (!h || !img || !out || B <= 0 || feature < 0 || feature > 18) return fail(SYN_ERR_INVALID, "syn_debug_feature: bad argument");
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_debug_feature: backbone weights not loaded");
+    DeviceGuard g(h->device);
+    return run_backbone(h, img, nullptr, B, nullptr, nullptr, (hipStream_t)stream, feature, out);
+}
+
+int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
+                    float *out, void *stream) {
+    if (!h || !param || !out) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
+    if (param_len != SYN_PARAM_DIM) return fail(SYN_ERR_PARAM_LEN, "length of params mismatch");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_reconstruct: B=%d", B);
+    if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_reconstruct: 3DMM basis not loaded");
+    DeviceGuard g(h->device);
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    float *rec = h->ws + (size_t)B * (2 * net().max_io + 2 * net().max_hidden);
+    if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
+    else       syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles, float *t3d, void *stream) {
+    if (!h || !param || !angles || !t3d) return fail(SYN_ERR_INVALID, "syn_pose: NULL argument");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_pose: B=%d", B);
+    if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_pose: whitening statistics not loaded");
+    DeviceGuard g(h->device);
+    syn::launch_pose(param, basis_mean(h), basis_std(h), roi, angles, t3d, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,372 @@
+"""MI355X drop-in for the reference's inference class `synergy3DMM.SynergyNet`.
+
+Same method set and return types as reference synergy3DMM.py:70-207
+(`get_all_outputs`, `forward_test`, `reconstruct_vertex_62`, `load_weights`, attributes
+`triangles`, `keypoints`, `data_param`, buffers `param_mean ... w_exp_base`), but every
+piece of arithmetic runs in hand-written gfx950 kernels behind the C ABI of
+include/synergy_hip.h (ctypes, see abi.py).  There is no CPU fallback.
+
+Additions that the reference does not have (all optional):
+  * batched entry points (`forward_crops_u8`, `reconstruct`, `predict_pose_batch`) - the
+    reference loops over faces in Python (synergy3DMM.py:177-205);
+  * `rects=` on `get_all_outputs`: the FaceBoxes detector is out of scope, so
+    detections are passed in or produced by a pluggable `face_detector` callable;
+  * constants can come from an in-memory pack / state_dict (synthetic assets) and can be
+    broadcast from rank 0 over RCCL instead of being loaded on every rank.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import abi
+from .params import ParamsPack
+from .synth import HEADS, mbv2_layers
+
+BACKBONE_PREFIX = 'I2P.backbone.'
+_BASIS_BUFFERS = ('param_mean', 'param_std', 'w_shp', 'u', 'w_exp', 'u_base', 'w_shp_base', 'w_exp_base')
+
+
+def parse_param_62(param):
+    """reference synergy3DMM.py:30-37 (tensor views only; kept for callers that import it)."""
+    p_ = param[:, :12].reshape(-1, 3, 4)
+    p = p_[:, :, :3]
+    offset = p_[:, :, -1].reshape(-1, 3, 1)
+    alpha_shp = param[:, 12:52].reshape(-1, 40, 1)
+    alpha_exp = param[:, 52:62].reshape(-1, 10, 1)
+    return p, offset, alpha_shp, alpha_exp
+
+
+def backbone_keys():
+    """(state_dict key, shape) of every backbone tensor, in the order syn_load_backbone expects."""
+    out = []
+    for L in mbv2_layers():
+        if L['kind'] == 'dw':
+            shape = (L['cout'], 1, 3, 3)
+        elif L['kind'] == 'stem':
+            shape = (L['cout'], L['cin'], 3, 3)
+        else:
+            shape = (L['cout'], L['cin'], 1, 1)
+        out.append((L['key'] + '.weight', shape))
+        for s in ('weight', 'bias', 'running_mean', 'running_var'):
+            out.append((L['bn'] + '.' + s, (L['cout'],)))
+    for name, n in HEADS:
+        out.append((name + '.weight', (n, 1280)))
+        out.append((name + '.bias', (n,)))
+    return out
+
+
+def flatten_backbone(sd: dict, prefix: str = '') -> np.ndarray:
+    """state_dict -> the flat fp32 host array of syn_load_backbone (include/synergy_hip.h)."""
+    parts = []
+    for k, shape in backbone_keys():
+        v = sd[prefix + k]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if tuple(v.shape) != tuple(shape):
+            raise RuntimeError(f'backbone tensor {k}: shape {tuple(v.shape)} != {tuple(shape)}')
+        parts.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
+class _Container(nn.Module):
+    """Empty node of the state_dict key tree (so state_dict() keys equal the reference's)."""
+
+
+def _register_by_key(root: nn.Module, key: str, tensor: torch.Tensor):
+    node = root
+    parts = key.split('.')
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Container())
+        node = node._modules[p]
+    node.register_buffer(parts[-1], tensor)
+
+
+class SynergyNet(nn.Module):
+    """Drop-in for reference synergy3DMM.SynergyNet (inference only), backed by HIP kernels."""
+
+    def __init__(self, device=None, checkpoint_fp=None, data_dir=None, pack=None, backbone_state=None,
+                 face_detector=None, load_constants=True):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError('synergynet_amd.SynergyNet needs a ROCm GPU (MI355X); there is no CPU path')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        self._lib = abi.lib()
+        h = C.c_void_p()
+        abi.check(self._lib.syn_create(self.device.index, C.byref(h)))
+        self._h = h
+        self.face_detector = face_detector
+        self.triangles = None
+        self.keypoints = None
+        self.data_param = None
+        self._n_vert = self._n_lmk = 0
+        self._have_backbone = self._have_basis = False
+        if not load_constants:          # constants arrive later through receive_constants()
+            self.eval()
+            return
+
+        # --- 3DMM constants (reference synergy3DMM.py:8-9,73-74,95-107) ---
+        pp = ParamsPack(data_dir=data_dir, pack=pack)            # raises RuntimeError('Missing data')
+        self.param_pack = pp
+        if pp.tri is not None:
+            self.triangles = torch.Tensor((np.asarray(pp.tri) - 1).astype(np.int64)).long()
+        self.register_buffer('param_mean', torch.Tensor(np.asarray(pp.param_mean, dtype=np.float32)))
+        self.register_buffer('param_std', torch.Tensor(np.asarray(pp.param_std, dtype=np.float32)))
+        self.register_buffer('w_shp', torch.Tensor(np.asarray(pp.w_shp, dtype=np.float32)))
+        self.register_buffer('u', torch.Tensor(np.asarray(pp.u, dtype=np.float32)))
+        self.register_buffer('w_exp', torch.Tensor(np.asarray(pp.w_exp, dtype=np.float32)))
+        self.register_buffer('u_base', torch.Tensor(np.asarray(pp.u_base, dtype=np.float32)))
+        self.register_buffer('w_shp_base', torch.Tensor(np.asarray(pp.w_shp_base, dtype=np.float32)))
+        self.register_buffer('w_exp_base', torch.Tensor(np.asarray(pp.w_exp_base, dtype=np.float32)))
+        self.keypoints = torch.Tensor(np.asarray(pp.keypoints)).long()
+        self.data_param = [self.param_mean, self.param_std, self.w_shp_base, self.u_base, self.w_exp_base]
+        self._upload_basis()
+
+        # --- backbone weights: key tree identical to the reference's I2P.backbone.* ---
+        for k, shape in backbone_keys():
+            _register_by_key(self, BACKBONE_PREFIX + k, torch.zeros(shape, dtype=torch.float32))
+        if backbone_state is not None:
+            sd = {BACKBONE_PREFIX + k: torch.as_tensor(np.asarray(v)) for k, v in backbone_state.items()
+                  if not k.endswith('num_batches_tracked')}
+            self.load_state_dict(sd, strict=False)
+            self._upload_backbone()
+        else:
+            fp = checkpoint_fp or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                               'pretrained', 'best.pth.tar')
+            try:
+                self.load_weights(fp)
+            except Exception as e:      # the reference swallows this silently (synergy3DMM.py:109-113)
+                warnings.warn(f'SynergyNet: could not load weights from {fp} ({e}); backbone weights are zero')
+                self._upload_backbone()
+        self.eval()
+        from . import inference
+        inference.set_default_model(self)
+
+    # nn.Module device moves must not drag the host-side constant copies around
+    def _apply(self, fn, *a, **k):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and self._h.value:
+                self._lib.syn_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ constants
+    def _upload_basis(self):
+        f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
+        w_shp, w_exp, u = f32(self.w_shp), f32(self.w_exp), f32(self.u).reshape(-1)
+        mean, std = f32(self.param_mean).reshape(-1), f32(self.param_std).reshape(-1)
+        if mean.size < 62 or std.size < 62:
+            raise RuntimeError('param_mean/param_std shorter than 62')
+        kp = np.ascontiguousarray(self.keypoints.numpy(), dtype=np.int64)
+        n_vert = w_shp.shape[0] // 3
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        abi.check(self._lib.syn_load_basis(self._h, ptr(w_shp), ptr(w_exp), ptr(u), ptr(mean), ptr(std), ptr(kp),
+                                           kp.size // 3, n_vert))
+        self._n_vert, self._n_lmk = n_vert, kp.size // 3
+        self._have_basis = True
+
+    def _upload_backbone(self):
+        flat = flatten_backbone(self.state_dict(), BACKBONE_PREFIX)
+        assert flat.size == self._lib.syn_backbone_flat_count()
+        abi.check(self._lib.syn_load_backbone(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
+        self._have_backbone = True
+
+    def load_weights(self, path):
+        """reference synergy3DMM.py:156-164: torch checkpoint {'state_dict': ...} with DataParallel
+        'module.' prefixes; keys this class does not have (MLP_for/MLP_rev, training-only) are ignored.
+        A checkpoint that carries the 3DMM buffers overrides the .npy values, as in the reference."""
+        model_dict = self.state_dict()
+        checkpoint = torch.load(path, map_location=lambda storage, loc: storage)['state_dict']
+        basis_touched = False
+        for k in checkpoint.keys():
+            kk = k.replace('module.', '')
+            if kk in model_dict:
+                model_dict[kk] = checkpoint[k]
+                basis_touched |= kk in _BASIS_BUFFERS
+        self.load_state_dict(model_dict, strict=False)
+        self._upload_backbone()
+        if basis_touched:
+            self._upload_basis()
+
+    # --- multi-GPU: rank `src` loads, everybody else receives ---
+    def constants_nbytes(self) -> int:
+        return int(self._lib.syn_constants_bytes(self._h))
+
+    def export_constants(self) -> torch.Tensor:
+        """Packed constants (header | folded backbone | MFMA-ordered basis) as a uint8 device tensor."""
+        n = self.constants_nbytes()
+        buf = torch.empty(n, dtype=torch.uint8, device=self.device)
+        abi.check(self._lib.syn_export_constants(self._h, buf.data_ptr(), n, self._stream()))
+        return buf
+
+    def import_constants(self, buf: torch.Tensor):
+        assert buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()
+        abi.check(self._lib.syn_import_constants(self._h, buf.data_ptr(), buf.numel(), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._have_backbone = self._have_basis = True
+        hdr = buf[:256].cpu().numpy()
+        self._n_vert, self._n_lmk = int(hdr[20:24].view(np.uint32)[0]), int(hdr[24:28].view(np.uint32)[0])
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_f32(self, t):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ reference API
+    def forward_test(self, input, return_pool=False):
+        """reference synergy3DMM.py:151-154: [B,3,120,120] fp32 (already (x-127.5)/128) -> [B,62]."""
+        was_cpu = isinstance(input, torch.Tensor) and not input.is_cuda
+        x = self._dev_f32(input)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 120, 120):
+            raise RuntimeError(f'forward_test expects [B,3,120,120], got {tuple(x.shape)}')
+        B = x.shape[0]
+        with torch.cuda.device(self.device):
+            param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
+            pool = torch.empty((B, 1280), dtype=torch.float32, device=self.device) if return_pool else None
+            abi.check(self._lib.syn_backbone_forward(self._h, x.data_ptr(), B, param.data_ptr(),
+                                                     pool.data_ptr() if return_pool else None, self._stream()))
+        if was_cpu:
+            param = param.cpu()
+            pool = pool.cpu() if return_pool else None
+        return (param, pool) if return_pool else param
+
+    def forward_crops_u8(self, crops, return_pool=False):
+        """uint8 crops [B,120,120,3] (HWC BGR, the output of cv2.resize at synergy3DMM.py:188) -> [B,62];
+        the HWC->CHW permute and (x-127.5)/128 of :189-192 are fused into the first convolution."""
+        if not isinstance(crops, torch.Tensor):
+            crops = torch.as_tensor(np.asarray(crops))
+        if crops.dtype != torch.uint8 or crops.dim() != 4 or tuple(crops.shape[1:]) != (120, 120, 3):
+            raise RuntimeError('forward_crops_u8 expects uint8 [B,120,120,3]')
+        x = crops.to(self.device).contiguous()
+        B = x.shape[0]
+        with torch.cuda.device(self.device):
+            param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
+            pool = torch.empty((B, 1280), dtype=torch.float32, device=self.device) if return_pool else None
+            abi.check(self._lib.syn_backbone_forward_u8(self._h, x.data_ptr(), B, param.data_ptr(),
+                                                        pool.data_ptr() if return_pool else None, self._stream()))
+        return (param, pool) if return_pool else param
+
+    def reconstruct(self, param, roi=None, dense=False, transform=True, out=None):
+        """Batched reconstruct_vertex_62 (+ optional ROI affine of utils/inference.py:127-138) on device."""
+        p = self._dev_f32(param)
+        if p.dim() != 2:
+            raise RuntimeError('param must be [B,62]')
+        B = p.shape[0]
+        n = self._n_vert if dense else self._n_lmk
+        r = None
+        if roi is not None:
+            r = self._dev_f32(roi)
+            if tuple(r.shape) != (B, 5):
+                raise RuntimeError('roi must be [B,5] (sx,sy,ex,ey,score)')
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((B, 3, n), dtype=torch.float32, device=self.device)
+            try:
+                abi.check(self._lib.syn_reconstruct(self._h, p.data_ptr(), B, p.shape[1], int(dense), int(transform),
+                                                    r.data_ptr() if r is not None else None, out.data_ptr(),
+                                                    self._stream()))
+            except abi.SynergyHipError as e:
+                if e.code == abi.SYN_ERR_PARAM_LEN:
+                    raise RuntimeError('length of params mismatch') from None
+                raise
+        return out
+
+    def reconstruct_vertex_62(self, param, whitening=True, dense=False, transform=True, lmk_pts=68):
+        """reference synergy3DMM.py:116-149.  [B,62] whitened -> [B,3,68] or [B,3,53215] in 120x120 crop
+        coordinates (no ROI affine), on the device of `param`."""
+        if not whitening:
+            # the reference leaves `param_` unbound on this branch (synergy3DMM.py:125-131)
+            raise UnboundLocalError("local variable 'param_' referenced before assignment")
+        if not dense and lmk_pts != self._n_lmk:
+            raise RuntimeError(f'lmk_pts={lmk_pts} but the landmark basis has {self._n_lmk} points')
+        was_cpu = isinstance(param, torch.Tensor) and not param.is_cuda
+        out = self.reconstruct(param, roi=None, dense=dense, transform=transform)
+        return out.cpu() if was_cpu else out
+
+    def predict_pose_batch(self, param, roi=None):
+        """Batched predict_pose (utils/inference.py:146-157): angles [B,3] float64 degrees, t3d [B,3] fp32."""
+        p = self._dev_f32(param)
+        B = p.shape[0]
+        r = self._dev_f32(roi) if roi is not None else None
+        with torch.cuda.device(self.device):
+            ang = torch.empty((B, 3), dtype=torch.float64, device=self.device)
+            t3d = torch.empty((B, 3), dtype=torch.float32, device=self.device)
+            abi.check(self._lib.syn_pose(self._h, p.data_ptr(), B, r.data_ptr() if r is not None else None,
+                                         ang.data_ptr(), t3d.data_ptr(), self._stream()))
+        return ang, t3d
+
+    # numpy single-face helpers with the reference's names and return types (utils/inference.py:140-157)
+    def predict_sparseVert(self, param, roi_box, transform=False):
+        return self._predict_vertices(param, roi_box, False, transform)
+
+    def predict_denseVert(self, param, roi_box, transform=False):
+        return self._predict_vertices(param, roi_box, True, transform)
+
+    def _predict_vertices(self, param, roi_box, dense, transform):
+        p = np.asarray(param, dtype=np.float32).reshape(1, -1)
+        if p.shape[1] != 62:
+            raise RuntimeError('length of params mismatch')
+        roi = np.asarray(roi_box, dtype=np.float32).reshape(1, 5)
+        return self.reconstruct(p, roi=roi, dense=dense, transform=transform)[0].cpu().numpy()
+
+    def predict_pose(self, param, roi_bbox):
+        p = np.asarray(param, dtype=np.float32).reshape(1, -1)
+        roi = np.asarray(roi_bbox, dtype=np.float32).reshape(1, 5)
+        ang, t3d = self.predict_pose_batch(p, roi)
+        return [float(v) for v in ang[0].cpu().numpy()], t3d[0].cpu().numpy()
+
+    def get_all_outputs(self, input, rects=None):
+        """reference synergy3DMM.py:167-207: BGR uint8 image [H,W,3] -> (list of (3,68) landmarks,
+        list of (3,53215) meshes, list of [angles_deg, translation]) with one entry per face.
+
+        All faces of the image go through ONE batched launch chain instead of the reference's
+        per-face loop.  `rects` = detections [[xmin,ymin,xmax,ymax,score], ...]; when omitted the
+        pluggable `face_detector(image)` is called (the reference constructs FaceBoxes here,
+        :170-171; that detector is outside this repo's scope)."""
+        from .inference import crop_img, resize_lanczos4
+        if rects is None:
+            if self.face_detector is None:
+                raise RuntimeError('no face detector: pass rects=[[xmin,ymin,xmax,ymax,score],...] or set '
+                                   'model.face_detector (FaceBoxes is outside the scope of this hot-path library)')
+            rects = self.face_detector(input)
+        pts_res, vertices_lst, poses = [], [], []
+        if len(rects) == 0:
+            return pts_res, vertices_lst, poses
+        crops, rois = [], []
+        for rect in rects:
+            roi_box = rect                      # aliases and mutates the caller's list like the reference (:178,185)
+            HCenter = (rect[1] + rect[3]) / 2
+            WCenter = (rect[0] + rect[2]) / 2
+            side_len = roi_box[3] - roi_box[1]
+            margin = side_len * 1.2 // 2
+            roi_box[0], roi_box[1], roi_box[2], roi_box[3] = WCenter - margin, HCenter - margin, WCenter + margin, HCenter + margin
+            img = crop_img(input, roi_box)
+            crops.append(resize_lanczos4(img, 120, 120))
+            rois.append([float(v) for v in roi_box[:5]])
+        crops = np.stack(crops)
+        rois = np.asarray(rois, dtype=np.float32)
+        param = self.forward_crops_u8(crops)
+        lmk = self.reconstruct(param, roi=rois, dense=False, transform=True).cpu().numpy()
+        mesh = self.reconstruct(param, roi=rois, dense=True, transform=True).cpu().numpy()
+        ang, t3d = self.predict_pose_batch(param, rois)
+        ang, t3d = ang.cpu().numpy(), t3d.cpu().numpy()
+        for i in range(len(rects)):
+            pts_res.append(lmk[i])
+            vertices_lst.append(mesh[i])
+            poses.append([[float(v) for v in ang[i]], t3d[i]])
+        return pts_res, vertices_lst, poses

@@ -1,0 +1,212 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI
+(ctypes -> libsynergy_hip.so), against
+  (1) tests/golden/reference_outputs.npz -- outputs of the REAL reference code, and
+  (2) the oracle (oracle/*.py, pinned to the reference by tests/test_oracle_golden.py)
+on identical seeded inputs.  Tolerance: 1e-4 relative (BASELINE.json north_star), fp32.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def model(pack, backbone_sd):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from synergynet_amd.synergy3DMM import SynergyNet
+    return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+
+
+@pytest.fixture(scope='module')
+def basis(pack):
+    from oracle import recon_numpy
+    return recon_numpy.Basis(pack)
+
+
+def test_native_library_is_loaded_in_tree(model):
+    from synergynet_amd import abi
+    from synergynet_amd.build import LIB
+    assert os.path.isfile(LIB)
+    maps = open('/proc/self/maps').read()
+    assert 'synergynet_amd/libsynergy_hip.so' in maps
+    assert abi.lib().syn_abi_version() == 1
+    n_hip = sum(1 for l in set(x.split()[-1] for x in maps.splitlines() if 'libamdhip64' in x))
+    assert n_hip == 1, 'two HIP runtimes in one process'
+
+
+def test_backbone_every_feature_matches_oracle(model, backbone_sd):
+    """Output of each of the 19 .features modules (NHWC on device) vs the torch-CPU oracle."""
+    import ctypes as C
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import abi, synth
+    x = synth.normalize_crops(synth.make_crops(3, seed=21))
+    _, _, feats = backbone_torch.mobilenet_v2_forward(backbone_sd, x, return_features=True)
+    last = {}
+    for L in synth.mbv2_layers():
+        last[L['feature']] = L['key']
+    xd = torch.from_numpy(x).cuda()
+    worst = 0.0
+    for f in range(19):
+        want = feats[last[f]].numpy()                       # NCHW
+        got = torch.empty((3, want.shape[2], want.shape[3], want.shape[1]), dtype=torch.float32, device='cuda')
+        abi.check(abi.lib().syn_debug_feature(model._h, xd.data_ptr(), 3, f, got.data_ptr(), None))
+        torch.cuda.synchronize()
+        e = rel_max(got.permute(0, 3, 1, 2).cpu().numpy(), want)
+        worst = max(worst, e)
+        assert e < TOL, f'features.{f}: rel err {e:.3e}'
+    print('worst per-feature rel err', worst)
+
+
+def test_forward_test_matches_reference_golden(model, golden):
+    import torch
+    from synergynet_amd import synth
+    x = torch.from_numpy(synth.normalize_crops(golden['crops_u8'])).cuda()
+    param, pool = model.forward_test(x, return_pool=True)
+    assert param.shape == (x.shape[0], 62) and param.is_cuda
+    assert rel_max(param.cpu().numpy(), golden['param_net']) < TOL
+    assert rel_l2(param.cpu().numpy(), golden['param_net']) < TOL
+    assert rel_max(pool.cpu().numpy(), golden['pool_net']) < TOL
+    # CPU tensor in -> CPU tensor out, like the reference's device-agnostic method
+    p2 = model.forward_test(x.cpu())
+    assert not p2.is_cuda and np.array_equal(p2.numpy(), param.cpu().numpy())
+
+
+def test_u8_ingest_equals_fp32_ingest(model, golden):
+    import torch
+    from synergynet_amd import synth
+    p8 = model.forward_crops_u8(golden['crops_u8'])
+    pf = model.forward_test(torch.from_numpy(synth.normalize_crops(golden['crops_u8'])).cuda())
+    assert np.array_equal(p8.cpu().numpy(), pf.cpu().numpy())     # same arithmetic, bit-identical
+
+
+@pytest.mark.parametrize('B', [1, 5, 33, 70])
+def test_backbone_ragged_batches_match_oracle(model, backbone_sd, B):
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    x = synth.normalize_crops(synth.make_crops(B, seed=100 + B, smooth=(B % 2 == 0)))
+    want, want_pool = backbone_torch.mobilenet_v2_forward(backbone_sd, x)
+    got, got_pool = model.forward_test(torch.from_numpy(x).cuda(), return_pool=True)
+    assert rel_max(got.cpu().numpy(), want.numpy()) < TOL
+    assert rel_max(got_pool.cpu().numpy(), want_pool.numpy()) < TOL
+
+
+def test_reconstruct_matches_reference_golden(model, golden):
+    import torch
+    s = int(golden['vert_stride'])
+    p = torch.from_numpy(golden['params']).cuda()
+    lmk = model.reconstruct_vertex_62(p, dense=False)
+    assert tuple(lmk.shape) == (p.shape[0], 3, 68)
+    assert rel_max(lmk.cpu().numpy(), golden['lmk_batched']) < TOL
+    lmk_nt = model.reconstruct_vertex_62(p, dense=False, transform=False)
+    assert rel_max(lmk_nt.cpu().numpy(), golden['lmk_batched_notransform']) < TOL
+    mesh = model.reconstruct_vertex_62(p, dense=True).cpu().numpy()
+    assert mesh.shape == (p.shape[0], 3, 53215)
+    assert rel_max(mesh[:, :, ::s], golden['mesh_batched_sub']) < TOL
+    assert rel_l2(mesh.astype(np.float64).sum(axis=2), golden['mesh_batched_rowsum']) < TOL
+
+
+def test_roi_vertices_and_pose_match_reference_golden(model, golden):
+    s = int(golden['vert_stride'])
+    lmk = model.reconstruct(golden['params'], roi=golden['rois'], dense=False).cpu().numpy()
+    mesh = model.reconstruct(golden['params'], roi=golden['rois'], dense=True).cpu().numpy()
+    assert rel_max(lmk, golden['lmk_roi']) < TOL
+    assert rel_max(mesh[:, :, ::s], golden['mesh_roi_sub']) < TOL
+    assert rel_l2(mesh.astype(np.float64).sum(axis=2), golden['mesh_roi_rowsum']) < TOL
+    ang, t3d = model.predict_pose_batch(golden['params'], golden['rois'])
+    assert np.allclose(ang.cpu().numpy(), golden['angles'], rtol=0, atol=1e-3)
+    assert rel_max(t3d.cpu().numpy(), golden['t3d']) < TOL
+    # single-face numpy helpers with the reference's names / return types
+    v = model.predict_sparseVert(golden['params'][1], list(golden['rois'][1]), transform=True)
+    assert isinstance(v, np.ndarray) and v.shape == (3, 68) and v.dtype == np.float32
+    assert rel_max(v, golden['lmk_roi'][1]) < TOL
+    a, t = model.predict_pose(golden['params'][2], list(golden['rois'][2]))
+    assert isinstance(a, list) and isinstance(a[0], float) and t.shape == (3,)
+    assert np.allclose(a, golden['angles'][2], atol=1e-3)
+
+
+@pytest.mark.parametrize('B', [1, 31, 32, 33, 100])
+def test_dense_reconstruction_ragged_batches_match_oracle(model, basis, B):
+    from oracle import recon_numpy
+    from synergynet_amd import synth
+    params = synth.make_params(B, seed=300 + B, scale=1.3)
+    want = recon_numpy.reconstruct_vertex_62(basis, params, dense=True)
+    got = model.reconstruct(params, dense=True).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_max(got, want) < TOL
+    per_face = np.abs(got - want).reshape(B, -1).max(axis=1) / np.abs(want).reshape(B, -1).max(axis=1)
+    assert per_face.max() < TOL
+
+
+def test_full_size_properties_b1024(model, golden):
+    """BASELINE config sizes (B=1024, dense mesh) through size-independent properties:
+    batch-position independence (bitwise) and landmarks == the keypoint columns of the mesh."""
+    import torch
+    from synergynet_amd import synth
+    B = 1024
+    crops = torch.from_numpy(synth.make_crops(4, seed=77)).cuda()
+    big = crops.repeat(B // 4, 1, 1, 1)
+    p_big = model.forward_crops_u8(big)
+    p4 = model.forward_crops_u8(crops)
+    assert torch.equal(p_big, p4.repeat(B // 4, 1))
+    params = torch.from_numpy(synth.make_params(8, seed=5)).cuda().repeat(B // 8, 1)
+    mesh = model.reconstruct(params, dense=True)
+    assert torch.equal(mesh[:8].repeat(B // 8, 1, 1), mesh)
+    lmk = model.reconstruct(params, dense=False)
+    kp_vert = (model.keypoints[::3] // 3).cuda()
+    assert rel_max(mesh[:, :, kp_vert].cpu().numpy(), lmk.cpu().numpy()) < 1e-6
+    assert torch.isfinite(mesh).all()
+
+
+def test_error_behaviour_mirrors_reference(model):
+    import torch
+    with pytest.raises(RuntimeError, match='length of params mismatch'):     # synergy3DMM.py:126-129
+        model.reconstruct_vertex_62(torch.zeros(2, 61).cuda())
+    with pytest.raises(UnboundLocalError):                                     # synergy3DMM.py:125-131
+        model.reconstruct_vertex_62(torch.zeros(2, 62).cuda(), whitening=False)
+    with pytest.raises(RuntimeError):
+        model.forward_test(torch.zeros(2, 3, 64, 64).cuda())
+    from synergynet_amd.synergy3DMM import SynergyNet
+    with pytest.raises(RuntimeError, match='Missing data'):                    # utils/params.py:36-37
+        SynergyNet(device='cuda:0', data_dir='/nonexistent')
+    empty = SynergyNet(device='cuda:0', load_constants=False)
+    from synergynet_amd import abi
+    with pytest.raises(abi.SynergyHipError, match='not loaded'):
+        empty.forward_test(torch.zeros(1, 3, 120, 120).cuda())
+
+
+def test_constants_export_import_roundtrip(model, golden):
+    """The multi-GPU constant hand-off (rank 0 exports, others import) on one device."""
+    import torch
+    from synergynet_amd.synergy3DMM import SynergyNet
+    buf = model.export_constants()
+    other = SynergyNet(device='cuda:0', load_constants=False)
+    other.import_constants(buf)
+    p = torch.from_numpy(golden['params']).cuda()
+    assert torch.equal(other.reconstruct(p, dense=True), model.reconstruct(p, dense=True))
+    crops = golden['crops_u8']
+    assert torch.equal(other.forward_crops_u8(crops), model.forward_crops_u8(crops))
+
+
+def test_get_all_outputs_shapes_and_consistency(model):
+    """get_all_outputs with supplied detections: types/shapes of reference synergy3DMM.py:167-207 and
+    agreement with the batched calls on the same crops."""
+    from synergynet_amd import synth
+    from synergynet_amd.inference import crop_img, resize_lanczos4
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    rects = [[100.0, 80.0, 260.0, 270.0, 0.99], [400.0, 200.0, 560.0, 420.0, 0.95]]   # second one overhangs the border
+    lm, mesh, pose = model.get_all_outputs(img, rects=[list(r) for r in rects])
+    assert len(lm) == len(mesh) == len(pose) == 2
+    assert lm[0].shape == (3, 68) and mesh[0].shape == (3, 53215) and lm[0].dtype == np.float32
+    assert isinstance(pose[0][0], list) and len(pose[0][0]) == 3 and pose[0][1].shape == (3,)
+    assert model.get_all_outputs(img, rects=[]) == ([], [], [])
+    with pytest.raises(RuntimeError, match='face detector'):
+        model.get_all_outputs(img)
