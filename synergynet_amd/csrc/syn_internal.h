@@ -35,6 +35,18 @@ void launch_pool_fc(const float *feat /*[B,16,1280]*/, const float *Wfc /*[64,12
                     const float *bias /*[64]*/, float *param /*[B,62]*/, float *pool /*nullable*/,
                     int B, hipStream_t s);
 
+// Fused inverted-residual block (expand 1x1 -> dw 3x3 -> project 1x1 [+ residual]) for
+// .features[2..17]; weights in MFMA lane order (see fused_block.hip).  Returns false if `feature`
+// has no fused configuration.
+struct FusedBlockArgs {
+    const float *X;                                   // block input  NHWC
+    const float *We, *e_scale, *e_shift;              // expand: Wpk[HID/16][CINP/16][64][4], [HID], [HID]
+    const float *Wd, *d_scale, *d_shift;              // depthwise: [9][HID], [HID], [HID]
+    const float *Wp, *p_scale, *p_shift;              // project: Wpk[COUTP/16][HID/16][64][4], [COUTP], [COUTP]
+    float *Y;                                         // block output NHWC
+};
+bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):
 //   Bp[tile][coord x|y|z][chunk][lane][4], K = 52: 0..39 shape, 40..49 expression,

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ struct Layer {
     int kpad, npad;      // packed GEMM dims (PW)
     size_t src_w;        // offsets (floats) into the flat host input
     size_t dst_w, dst_scale, dst_shift;   // offsets (floats) into the packed device blob
+    size_t dst_wpk;      // PW layers of fused blocks: weights in MFMA lane order (fused_block.hip)
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -103,6 +105,11 @@ struct Net {
             L.dst_w = dst; dst += wp;
             L.dst_scale = dst; dst += cpad;
             L.dst_shift = dst; dst += cpad;
+            L.dst_wpk = 0;
+            if (L.kind == PW && L.feature >= 2 && L.feature <= 17) {
+                L.dst_wpk = dst;
+                dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
+            }
             const double pix = (double)L.hout * L.hout;
             const double f2 = L.kind == STEM ? 2.0 * 27 * 32 * pix : L.kind == DW ? 2.0 * 9 * L.cout * pix
                                                                                    : 2.0 * L.cin * (double)L.cout * pix;
@@ -146,6 +153,7 @@ struct syn_handle {
     int n_vert = 0, n_lmk = 0, nvp = 0, nlp = 0;
     float *ws = nullptr;
     size_t ws_bytes = 0;
+    int fusion = 1;                // 1: fused inverted-residual blocks, 0: one kernel per layer (SYNERGY_HIP_FUSION)
 };
 
 namespace {
@@ -206,6 +214,22 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     for (size_t li = 0; li < nl; ++li) {
         const Layer &L = n.layers[li];
         const float *w = P + L.dst_w, *sc = P + L.dst_scale, *sh = P + L.dst_shift;
+        // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
+        if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
+            const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
+            syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
+                                  P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
+            if (syn::launch_fused_block(L.feature, a, B, s)) {
+                float *t = X; X = Y; Y = t;
+                li += 2;
+                const Layer &Lp = n.layers[li];
+                if (stop_feature >= 0 && Lp.feature == stop_feature) {
+                    HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    return SYN_OK;
+                }
+                continue;
+            }
+        }
         if (L.kind == STEM) {
             syn::launch_stem(img, img8, w, sc, sh, X, B, s);
         } else if (L.kind == DW) {
@@ -246,6 +270,7 @@ int syn_create(int device, syn_handle **out) {
     if (device < 0 || device >= count) return fail(SYN_ERR_INVALID, "syn_create: device %d of %d", device, count);
     syn_handle *h = new syn_handle();
     h->device = device;
+    if (const char *e = getenv("SYNERGY_HIP_FUSION")) h->fusion = atoi(e);
     *out = h;
     return SYN_OK;
 }
@@ -285,6 +310,18 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
         } else {                         // [N][K] -> zero padded [Npad][Kpad]
             for (int nn = 0; nn < L.cout; ++nn)
                 memcpy(dw + (size_t)nn * L.kpad, w + (size_t)nn * L.cin, sizeof(float) * L.cin);
+        }
+        if (L.dst_wpk) {                 // [N][K] -> Wpk[n_tile][k_chunk][lane][4] (MFMA operand lane order)
+            float *dp = pk.data() + L.dst_wpk;
+            const int ntl = round_up(L.cout, 16) / 16, kch = round_up(L.cin, 16) / 16;
+            for (int nt = 0; nt < ntl; ++nt)
+                for (int kc = 0; kc < kch; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q) {
+                            const int nn = nt * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + q;
+                            dp[(((size_t)nt * kch + kc) * 64 + lane) * 4 + q] =
+                                (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] : 0.f;
+                        }
         }
         // eval-mode BatchNorm (eps 1e-5) as y = x*scale + shift, the form torch's CPU kernel uses
         for (int c = 0; c < L.cout; ++c) {

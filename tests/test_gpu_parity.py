@@ -15,12 +15,18 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope='module')
-def model(pack, backbone_sd):
+@pytest.fixture(scope='module', params=['fused-blocks', 'per-layer'])
+def model(request, pack, backbone_sd):
+    """Both backbone schedules of the library: fused inverted-residual blocks (default) and one
+    kernel per layer (SYNERGY_HIP_FUSION=0, read at syn_create)."""
     import torch
     assert torch.cuda.is_available(), 'GPU tests need an MI355X'
     from synergynet_amd.synergy3DMM import SynergyNet
-    return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    os.environ['SYNERGY_HIP_FUSION'] = '1' if request.param == 'fused-blocks' else '0'
+    try:
+        return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    finally:
+        os.environ.pop('SYNERGY_HIP_FUSION', None)
 
 
 @pytest.fixture(scope='module')
