@@ -48,7 +48,8 @@ _SIGS = {
 
 EXPORTED_SYMBOLS = tuple(_SIGS)          # exactly the symbols include/synergy_hip.h declares
 # test hook exported by the library but deliberately not part of the public header
-_SIGS = dict(_SIGS, syn_debug_feature=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]))
+_SIGS = dict(_SIGS, syn_debug_feature=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+             syn_debug_profile_block=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]))
 
 
 def lib():

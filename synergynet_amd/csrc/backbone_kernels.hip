@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const float *__restrict_
     const int nt_idx = q % n_tiles;
     const int mt_idx = (q / n_tiles) * 8 + xcd;
     if (mt_idx >= m_tiles) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int m0 = (mt_idx * 4 + wave) * (MT * 16);
     const int n0 = nt_idx * (NT * 16);

@@ -17,7 +17,15 @@
 // MFMA "B" cols = 16 pixels (activations from LDS); a lane owns 4 consecutive channels of one pixel.
 // Weights are pre-packed by the host in lane order  Wpk[n_tile][k_chunk][lane][4]  with
 //   value = W[n = 16*n_tile + (lane&15)][k = 16*k_chunk + 4*(lane>>4) + s]
-// so each weight fetch of a wave is one fully coalesced 1 KiB load.
+// so each weight fetch of a wave is one fully coalesced 1 KiB load (global) / conflict-free b128 (LDS).
+//
+// Latency plan (measured: the naive version spent 55-90 % of every MFMA stage waiting for weights):
+//   WLDS = false (late blocks, weights 0.2-1.2 MB): the weights of the NEXT MFMA stage are fetched into
+//       registers one stage ahead (project weights while the depthwise stage runs, the next chunk's expand
+//       weights while the project stage runs), so no global load sits on an MFMA critical path.
+//   WLDS = true  (early blocks, weights <= 42 KB): all weights live in LDS for the lifetime of a
+//       PERSISTENT workgroup that loops over tiles, and the next tile's input is prefetched into registers
+//       while the current tile computes (no other VMEM op is in flight, so it stays in flight).
 #include "syn_internal.h"
 
 namespace syn {
@@ -36,11 +44,12 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
 
 template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int TH_, int TW_, int NF_, int HC_, int NW_,
-          int EPB_, int WN_, int WP_>
+          int EPB_, int WN_, int WP_, bool WLDS_>
 struct BlockCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, TH = TH_, TW = TW_, NF = NF_,
                          HC = HC_, NW = NW_, EPB = EPB_, WN = WN_, WP = WP_;
-    static constexpr bool RES = RES_;
+    static constexpr bool RES = RES_, WLDS = WLDS_;
+    static constexpr int NT = NW * 64;
     static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
     static constexpr int TILES_Y = cdiv(HOUT, TH), TILES_X = cdiv(HOUT, TW);
     // a tile that covers the whole image needs no halo ring: everything outside is zero padding
@@ -49,203 +58,369 @@ struct BlockCfg {
     static constexpr int PIN = NF * IH * IW, PINP = rup(PIN, 16);
     static constexpr int POUT = NF * TH * TW, POUTP = rup(POUT, 16);
     static constexpr int CINP = rup(CIN, 16), COUTP = rup(COUT, 16);
-    static constexpr int KCH = CINP / 16;                                        // expand k-chunks
+    static constexpr int KCH = CINP / 16, KC3 = HC / 16;                         // k-chunks of expand / project
     static constexpr int XS = CINP + 4, ES = HC + 4;                             // LDS row strides (floats)
     static constexpr int NT_E = HC / 16, PT_IN = PINP / 16, PG = cdiv(PT_IN, EPB), JOBS = NT_E * PG;
+    static constexpr int JPW = cdiv(JOBS, NW);                                   // expand jobs per wave
     static constexpr int NT_O = COUTP / 16, PT_O = POUTP / 16;
     static constexpr int AN = cdiv(NT_O, WN), AP = cdiv(PT_O, WP);
+    static constexpr int X_ITEMS = PINP * (CINP / 4), X_IPT = cdiv(X_ITEMS, NT); // input-tile float4 per thread
+    // depthwise stage mapping: thread = (channel quad, output column of a face, row segment)
+    static constexpr int C4N = HC / 4, COLS = NF * TW;
+    static constexpr int RS_ = NT / (C4N * COLS);
+    static constexpr int RS = RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_);
+    static constexpr int RPS = cdiv(TH, RS), DW_THREADS = C4N * COLS * cdiv(TH, RPS);
+    // LDS carve (floats)
     static constexpr int XS_FLOATS = PINP * XS, ES_FLOATS = PINP * ES, DS_FLOATS = POUTP * ES;
-    static constexpr int LDS_FLOATS = XS_FLOATS + ES_FLOATS + DS_FLOATS;
+    static constexpr int WE_FLOATS = (HID / 16) * KCH * 256, WP_FLOATS = NT_O * (HID / 16) * 256;
+    static constexpr int WD_FLOATS = WLDS ? 11 * HID : 11 * HC;                  // 9 taps | scale | shift
+    static constexpr int LDS_FLOATS = XS_FLOATS + ES_FLOATS + DS_FLOATS + WD_FLOATS + (WLDS ? WE_FLOATS + WP_FLOATS + 2 * HID : 0);
+    static constexpr int WDR_THREADS = 11 * HC / 4;
     static_assert(HID % HC == 0 && HC % 16 == 0, "hidden chunking");
     static_assert(WN * WP == NW, "wave grid");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(WLDS || WDR_THREADS <= NT, "one depthwise-weight float4 per thread");
 };
 
-template <class C>
+// PROF: wave 0 accumulates s_memtime deltas (shader cycles) per stage into prof[0..7] (debug hook
+// syn_debug_profile_block): 0 stage0, 1 expand, 2 barrier-after-expand, 3 depthwise, 4 barrier-after-dw,
+// 5 project, 6 epilogue, 7 #tiles
+#define SYN_TICK() (PROF ? __builtin_amdgcn_s_memtime() : 0ull)
+#define SYN_LAP(i) do { if (PROF) { tn = SYN_TICK(); pt_[i] += tn - tk; tk = tn; } } while (0)
+
+template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
     const float *__restrict__ X, const float *__restrict__ We, const float *__restrict__ e_scale,
     const float *__restrict__ e_shift, const float *__restrict__ Wd, const float *__restrict__ d_scale,
     const float *__restrict__ d_shift, const float *__restrict__ Wp, const float *__restrict__ p_scale,
-    const float *__restrict__ p_shift, float *__restrict__ Y, int B) {
+    const float *__restrict__ p_shift, float *__restrict__ Y, int B, int total_tiles,
+    unsigned long long *prof = nullptr) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
-    float *Xs = smem, *Es = smem + C::XS_FLOATS, *Ds = Es + C::ES_FLOATS;
-    constexpr int NT = C::NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *Xs = smem, *Es = Xs + C::XS_FLOATS, *Ds = Es + C::ES_FLOATS, *Wds = Ds + C::DS_FLOATS;
+    float *Wle = Wds + C::WD_FLOATS, *Wlp = Wle + C::WE_FLOATS, *Ebn = Wlp + C::WP_FLOATS;   // only carved when WLDS
+    constexpr int NT = C::NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef SYN_NO_RFL
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
+#endif
     const int r16 = lane & 15, g = lane >> 4;
+    const int wn = wave % C::WN, wp = wave / C::WN;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk = SYN_TICK(), tn;
+    unsigned long long ntiles_done = 0;
 
-    int bid = blockIdx.x;
-    const int tx = bid % C::TILES_X;
-    bid /= C::TILES_X;
-    const int ty = bid % C::TILES_Y;
-    const int f0 = (bid / C::TILES_Y) * C::NF;
-    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-    const int iy0 = C::WHOLE ? 0 : oy0 * C::S - 1, ix0 = C::WHOLE ? 0 : ox0 * C::S - 1;   // image coords of tile pixel (0,0)
-
-    // ---- stage 0: input tile (halo included, zero outside the image / past CIN) -> LDS ----
-    for (int it = tid; it < C::PINP * (C::CINP / 4); it += NT) {
-        const int c4 = it % (C::CINP / 4), p = it / (C::CINP / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p < C::PIN && 4 * c4 < C::CIN) {
-            const int i = p / (C::IH * C::IW), r = p % (C::IH * C::IW);
-            const int iy = iy0 + r / C::IW, ix = ix0 + r % C::IW;
-            const int f = f0 + i;
-            if (f < B && iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::HIN)
-                v = *(const f32x4 *)&X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 4 * c4];
+    // input tile `tile` -> registers (halo included, zero outside the image / past CIN)
+    f32x4 xr[C::X_IPT];
+    auto load_x = [&](int tile) {
+        const int tx = tile % C::TILES_X, ty = (tile / C::TILES_X) % C::TILES_Y;
+        const int f0 = (tile / (C::TILES_X * C::TILES_Y)) * C::NF;
+        const int iy0 = C::WHOLE ? 0 : ty * C::TH * C::S - 1, ix0 = C::WHOLE ? 0 : tx * C::TW * C::S - 1;
+#pragma unroll
+        for (int ii = 0; ii < C::X_IPT; ++ii) {
+            const int it = tid + ii * NT;
+            const int c4 = it % (C::CINP / 4), p = it / (C::CINP / 4);
+            f32x4 v = z4;
+            if (it < C::X_ITEMS && p < C::PIN && 4 * c4 < C::CIN) {
+                const int i = p / (C::IH * C::IW), r = p % (C::IH * C::IW);
+                const int iy = iy0 + r / C::IW, ix = ix0 + r % C::IW;
+                const int f = f0 + i;
+                if (f < B && iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::HIN)
+                    v = *(const f32x4 *)&X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 4 * c4];
+            }
+            xr[ii] = v;
         }
-        *(f32x4 *)&Xs[p * C::XS + 4 * c4] = v;
+    };
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) load_x(tile);
+    if (C::WLDS) {   // all weights of the block -> LDS, once per (persistent) workgroup
+        for (int i = tid; i < C::WE_FLOATS / 4; i += NT) *(f32x4 *)&Wle[4 * i] = *(const f32x4 *)&We[4 * i];
+        for (int i = tid; i < C::WP_FLOATS / 4; i += NT) *(f32x4 *)&Wlp[4 * i] = *(const f32x4 *)&Wp[4 * i];
+        for (int i = tid; i < 11 * C::HID / 4; i += NT) {
+            const int row = i / (C::HID / 4), c4 = i % (C::HID / 4);
+            const float *src = row < 9 ? Wd + row * C::HID : (row == 9 ? d_scale : d_shift);
+            *(f32x4 *)&Wds[row * C::HID + 4 * c4] = *(const f32x4 *)&src[4 * c4];
+        }
+        for (int i = tid; i < C::HID / 4; i += NT) {
+            *(f32x4 *)&Ebn[4 * i] = *(const f32x4 *)&e_scale[4 * i];
+            *(f32x4 *)&Ebn[C::HID + 4 * i] = *(const f32x4 *)&e_shift[4 * i];
+        }
+    }
+    // project BN of the channels this lane owns: constant for the whole kernel
+    f32x4 psc[C::AN], psh[C::AN];
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i) {
+        const int n = (wn + i * C::WN) * 16 + 4 * g;
+        psc[i] = n < C::COUTP ? *(const f32x4 *)&p_scale[n] : z4;
+        psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
     }
     if (C::POUTP > C::POUT)
         for (int it = tid; it < (C::POUTP - C::POUT) * C::ES; it += NT) Ds[C::POUT * C::ES + it] = 0.f;
 
-    f32x4 acc[C::AN][C::AP];
+    // register-prefetched weights (WLDS = false)
+    f32x4 a1[C::JPW][C::KCH];      // expand weights of the coming chunk, per job of this wave
+    f32x4 e1s[C::JPW], e1h[C::JPW]; // ... and the expand BN scale / shift of the job's 4 channels
+    f32x4 a3[C::AN][C::KC3];       // project weights of the current chunk
+    f32x4 wdr = z4;                // this thread's float4 of the coming chunk's depthwise filter / BN
+    auto fetch_a1 = [&](int hc0) {
 #pragma unroll
-    for (int i = 0; i < C::AN; ++i)
+        for (int jj = 0; jj < C::JPW; ++jj) {
+            const int job = wave + jj * C::NW;
+            if (job < C::JOBS) {
+                const float *wa = We + ((size_t)(hc0 / 16 + job % C::NT_E) * C::KCH) * 256 + lane * 4;
 #pragma unroll
-        for (int j = 0; j < C::AP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int wn = wave % C::WN, wp = wave / C::WN;
-    __syncthreads();
+                for (int kc = 0; kc < C::KCH; ++kc) a1[jj][kc] = *(const f32x4 *)(wa + kc * 256);
+                const int ch = hc0 + (job % C::NT_E) * 16 + 4 * g;
+                e1s[jj] = *(const f32x4 *)&e_scale[ch];
+                e1h[jj] = *(const f32x4 *)&e_shift[ch];
+            }
+        }
+        if (tid < C::WDR_THREADS) {
+            const int row = tid / (C::HC / 4), c4 = tid % (C::HC / 4);
+            const float *src = row < 9 ? Wd + row * C::HID : (row == 9 ? d_scale : d_shift);
+            wdr = *(const f32x4 *)&src[hc0 + 4 * c4];
+        }
+    };
+    auto fetch_a3 = [&](int hc0) {
+#pragma unroll
+        for (int i = 0; i < C::AN; ++i) {
+            int nt = wn + i * C::WN;
+            nt = nt < C::NT_O ? nt : 0;
+#pragma unroll
+            for (int kc = 0; kc < C::KC3; ++kc)
+                a3[i][kc] = *(const f32x4 *)(Wp + ((size_t)nt * (C::HID / 16) + hc0 / 16 + kc) * 256 + lane * 4);
+        }
+    };
+    if (!C::WLDS) fetch_a1(0);
 
-    for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
-        // ---- stage 1: expand 1x1 + BN + ReLU6 for every pixel of the input tile ----
-        for (int job = wave; job < C::JOBS; job += C::NW) {
-            const int nt = job % C::NT_E, pg = job / C::NT_E;
-            f32x4 ea[C::EPB];
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int tx = tile % C::TILES_X, ty = (tile / C::TILES_X) % C::TILES_Y;
+        const int f0 = (tile / (C::TILES_X * C::TILES_Y)) * C::NF;
+        const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+        const int iy0 = C::WHOLE ? 0 : oy0 * C::S - 1, ix0 = C::WHOLE ? 0 : ox0 * C::S - 1;   // image coords of tile pixel (0,0)
+
+        // ---- stage 0: input tile registers -> LDS; start fetching the next tile ----
 #pragma unroll
-            for (int q = 0; q < C::EPB; ++q) ea[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float *wa = We + ((size_t)(hc0 / 16 + nt) * C::KCH) * 256 + lane * 4;
+        for (int ii = 0; ii < C::X_IPT; ++ii) {
+            const int it = tid + ii * NT;
+            if (it < C::X_ITEMS) *(f32x4 *)&Xs[(it / (C::CINP / 4)) * C::XS + 4 * (it % (C::CINP / 4))] = xr[ii];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) load_x(tile + gridDim.x);
+        SYN_LAP(0);
+
+        f32x4 acc[C::AN][C::AP];
 #pragma unroll
-            for (int kc = 0; kc < C::KCH; ++kc) {
-                const f32x4 a = *(const f32x4 *)(wa + kc * 256);
+        for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+            for (int j = 0; j < C::AP; ++j) acc[i][j] = z4;
+
+        for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
+            const float *wdc = C::WLDS ? Wds + hc0 : Wds;                 // depthwise filter of this chunk
+            constexpr int WDS = C::WLDS ? C::HID : C::HC;                 // its row stride
+            if (!C::WLDS && tid < C::WDR_THREADS) *(f32x4 *)&Wds[4 * tid] = wdr;   // rows are HC wide: [row][c4] == tid
+            // ---- stage 1: expand 1x1 + BN + ReLU6 for every pixel of the input tile ----
+#pragma unroll
+            for (int jj = 0; jj < C::JPW; ++jj) {
+                const int job = wave + jj * C::NW;
+                if (job >= C::JOBS) break;
+                const int nt = job % C::NT_E, pg = job / C::NT_E;
+                f32x4 ea[C::EPB];
+#pragma unroll
+                for (int q = 0; q < C::EPB; ++q) ea[q] = z4;
+#pragma unroll
+                for (int kc = 0; kc < C::KCH; ++kc) {
+                    f32x4 a;
+                    if (C::WLDS) a = *(const f32x4 *)&Wle[((hc0 / 16 + nt) * C::KCH + kc) * 256 + lane * 4];
+                    else a = a1[jj][kc];
+                    f32x4 b[C::EPB];
+#pragma unroll
+                    for (int q = 0; q < C::EPB; ++q) {
+                        const int pt = pg * C::EPB + q;
+                        b[q] = *(const f32x4 *)&Xs[((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XS + kc * 16 + 4 * g];
+                    }
+                    // unconditional: a ragged last group multiplies a clamped (duplicate) pixel tile, never stored
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int q = 0; q < C::EPB; ++q)
+                            ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[q][s], ea[q], 0, 0, 0);
+                }
+                const int ch = hc0 + nt * 16 + 4 * g;
+                const f32x4 sc = C::WLDS ? *(const f32x4 *)&Ebn[ch] : e1s[jj];
+                const f32x4 sh = C::WLDS ? *(const f32x4 *)&Ebn[C::HID + ch] : e1h[jj];
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) {
                     const int pt = pg * C::EPB + q;
-                    if (pt < C::PT_IN) {
-                        const f32x4 b = *(const f32x4 *)&Xs[(pt * 16 + r16) * C::XS + kc * 16 + 4 * g];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], ea[q], 0, 0, 0);
-                    }
+                    if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6_(ea[q] * sc + sh);
                 }
             }
-            const int ch = hc0 + nt * 16 + 4 * g;
-            const f32x4 sc = *(const f32x4 *)&e_scale[ch];
-            const f32x4 sh = *(const f32x4 *)&e_shift[ch];
+            if (!C::WLDS) fetch_a3(hc0);          // in flight during the depthwise stage
+            SYN_LAP(1);
+            __syncthreads();
+            SYN_LAP(2);
+            // ---- stage 2: depthwise 3x3 + BN + ReLU6, LDS -> LDS ----
+            // thread = (channel quad, output column, row segment): walks down its column with a 3-row sliding
+            // window (3 LDS reads per output at S=1).  Zero padding: column taps outside the image are folded
+            // into the thread's filter copy (weight := 0, address clamped), rows outside the image load as zeros.
+            for (int t = tid; t < C::DW_THREADS; t += NT) {
+                const int c4 = t % C::C4N, q = t / C::C4N;
+                const int col = q % C::COLS, seg = q / C::COLS;
+                const int fi = col / C::TW, oxl = col % C::TW;
+                const int ixb = (ox0 + oxl) * C::S - 1;                       // image x of tap kx = 0
+                f32x4 w[9];
 #pragma unroll
-            for (int q = 0; q < C::EPB; ++q) {
-                const int pt = pg * C::EPB + q;
-                if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6_(ea[q] * sc + sh);
-            }
-        }
-        __syncthreads();
-        // ---- stage 2: depthwise 3x3 + BN + ReLU6 (zero padding = skip taps outside the image) ----
-        for (int it = tid; it < C::POUT * (C::HC / 4); it += NT) {
-            const int c4 = it % (C::HC / 4), po = it / (C::HC / 4);
-            const int i = po / (C::TH * C::TW), r = po % (C::TH * C::TW);
-            const int oyl = r / C::TW, oxl = r % C::TW;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&wdc[k * WDS + 4 * c4];
+                if (ixb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
+                if (ixb + 2 >= C::HIN) { w[2] = z4; w[5] = z4; w[8] = z4; }
+                const int lx1 = ixb + 1 - ix0;
+                const int lx0 = lx1 > 0 ? lx1 - 1 : 0, lx2 = lx1 + 1 < C::IW ? lx1 + 1 : C::IW - 1;
+                const f32x4 sc = *(const f32x4 *)&wdc[9 * WDS + 4 * c4];
+                const f32x4 sh = *(const f32x4 *)&wdc[10 * WDS + 4 * c4];
+                const float *ebase = Es + (size_t)fi * C::IH * C::IW * C::ES + 4 * c4;
+                f32x4 rb[3][3];
+                auto load_row = [&](int iy, f32x4(&dst)[3]) {
+                    const bool ok = (unsigned)iy < (unsigned)C::HIN;
+                    int ly = iy - iy0;
+                    ly = ly < 0 ? 0 : (ly > C::IH - 1 ? C::IH - 1 : ly);
+                    const float *er = ebase + ly * C::IW * C::ES;
+                    dst[0] = *(const f32x4 *)(er + lx0 * C::ES);
+                    dst[1] = *(const f32x4 *)(er + lx1 * C::ES);
+                    dst[2] = *(const f32x4 *)(er + lx2 * C::ES);
+                    if (!ok) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
+                };
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = (oy0 + oyl) * C::S - 1 + ky, ly = iy - iy0;
+                for (int r = 0; r < C::RPS; ++r) {
+                    const int oyl = seg * C::RPS + r;
+                    if (oyl >= C::TH) break;
+                    const int iyb = (oy0 + oyl) * C::S - 1;
+                    if (r == 0) {
+                        load_row(iyb, rb[0]); load_row(iyb + 1, rb[1]); load_row(iyb + 2, rb[2]);
+                    } else if (C::S == 1) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = (ox0 + oxl) * C::S - 1 + kx, lx = ix - ix0;
-                    if (iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::HIN) {
-                        const f32x4 e = *(const f32x4 *)&Es[((i * C::IH + ly) * C::IW + lx) * C::ES + 4 * c4];
-                        const f32x4 w = *(const f32x4 *)&Wd[(ky * 3 + kx) * C::HID + hc0 + 4 * c4];
-                        a += e * w;
+                        for (int k = 0; k < 3; ++k) { rb[0][k] = rb[1][k]; rb[1][k] = rb[2][k]; }
+                        load_row(iyb + 2, rb[2]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) rb[0][k] = rb[2][k];
+                        load_row(iyb + 1, rb[1]); load_row(iyb + 2, rb[2]);
                     }
+                    f32x4 a = rb[0][0] * w[0];
+                    a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                    a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
+                    a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
+                    const int po = (fi * C::TH + oyl) * C::TW + oxl;
+                    *(f32x4 *)&Ds[po * C::ES + 4 * c4] = relu6_(a * sc + sh);
                 }
             }
-            const f32x4 sc = *(const f32x4 *)&d_scale[hc0 + 4 * c4];
-            const f32x4 sh = *(const f32x4 *)&d_shift[hc0 + 4 * c4];
-            *(f32x4 *)&Ds[po * C::ES + 4 * c4] = relu6_(a * sc + sh);
-        }
-        __syncthreads();
-        // ---- stage 3: project 1x1, K = this hidden chunk, accumulators stay in registers ----
+            if (!C::WLDS) fetch_a1(hc0 + C::HC < C::HID ? hc0 + C::HC : 0);   // next chunk (or next tile's chunk 0)
+            SYN_LAP(3);
+            __syncthreads();
+            SYN_LAP(4);
+            // ---- stage 3: project 1x1, K = this hidden chunk, accumulators stay in registers ----
 #pragma unroll
-        for (int kc = 0; kc < C::HC / 16; ++kc) {
-            f32x4 a[C::AN], b[C::AP];
+            for (int kc = 0; kc < C::KC3; ++kc) {
+                f32x4 a[C::AN], b[C::AP];
 #pragma unroll
-            for (int i = 0; i < C::AN; ++i) {
-                const int nt = wn + i * C::WN;
-                if (nt < C::NT_O) a[i] = *(const f32x4 *)(Wp + ((size_t)nt * (C::HID / 16) + hc0 / 16 + kc) * 256 + lane * 4);
+                for (int i = 0; i < C::AN; ++i) {
+                    const int nt = wn + i * C::WN;
+                    if (C::WLDS) a[i] = *(const f32x4 *)&Wlp[(((nt < C::NT_O ? nt : 0) * (C::HID / 16)) + hc0 / 16 + kc) * 256 + lane * 4];
+                    else a[i] = a3[i][kc];
+                }
+#pragma unroll
+                for (int j = 0; j < C::AP; ++j) {
+                    const int pt = wp + j * C::WP;
+                    b[j] = *(const f32x4 *)&Ds[((pt < C::PT_O ? pt : 0) * 16 + r16) * C::ES + kc * 16 + 4 * g];
+                }
+                // unconditional straight-line MFMAs: tiles past NT_O / PT_O use clamped operands and are never stored
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::AP; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
             }
+            SYN_LAP(5);
+            // no barrier here: the next stage 1 only writes Es / Wds (their readers finished before the barrier
+            // above), and Ds is rewritten only after the next barrier, which every wave reaches after stage 3.
+        }
+
+        // ---- epilogue: BN (+ residual from the LDS input tile) and NHWC store ----
+#pragma unroll
+        for (int i = 0; i < C::AN; ++i) {
+            const int nt = wn + i * C::WN;
+            const int n = nt * 16 + 4 * g;
+            if (nt >= C::NT_O || n >= C::COUT) continue;
+            const f32x4 sc = psc[i], sh = psh[i];
 #pragma unroll
             for (int j = 0; j < C::AP; ++j) {
                 const int pt = wp + j * C::WP;
-                if (pt < C::PT_O) b[j] = *(const f32x4 *)&Ds[(pt * 16 + r16) * C::ES + kc * 16 + 4 * g];
+                const int po = pt * 16 + r16;
+                if (pt >= C::PT_O || po >= C::POUT) continue;
+                const int fi = po / (C::TH * C::TW), r = po % (C::TH * C::TW);
+                const int oyl = r / C::TW, oxl = r % C::TW;
+                const int f = f0 + fi, oy = oy0 + oyl, ox = ox0 + oxl;
+                if (f >= B || oy >= C::HOUT || ox >= C::HOUT) continue;
+                f32x4 v = acc[i][j] * sc + sh;
+                if (C::RES) v += *(const f32x4 *)&Xs[((fi * C::IH + (oy - iy0)) * C::IW + (ox - ix0)) * C::XS + n];   // x + conv(x)
+                *(f32x4 *)&Y[((size_t)(f * C::HOUT + oy) * C::HOUT + ox) * C::COUT + n] = v;
             }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < C::AN; ++i)
-#pragma unroll
-                    for (int j = 0; j < C::AP; ++j)
-                        if (wn + i * C::WN < C::NT_O && wp + j * C::WP < C::PT_O)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-        // no barrier here: the next stage 1 only writes Es (its readers finished before the barrier above),
-        // and Ds is rewritten only after the next barrier, which every wave reaches after its stage 3.
+        ++ntiles_done;
+        if (tile + (int)gridDim.x < total_tiles) __syncthreads();   // Xs (residual) is rewritten by the next tile
+        SYN_LAP(6);
     }
-
-    // ---- epilogue: BN (+ residual from the LDS input tile) and NHWC store ----
-#pragma unroll
-    for (int i = 0; i < C::AN; ++i) {
-        const int nt = wn + i * C::WN;
-        const int n = nt * 16 + 4 * g;
-        if (nt >= C::NT_O || n >= C::COUT) continue;
-        const f32x4 sc = *(const f32x4 *)&p_scale[n];
-        const f32x4 sh = *(const f32x4 *)&p_shift[n];
-#pragma unroll
-        for (int j = 0; j < C::AP; ++j) {
-            const int pt = wp + j * C::WP;
-            const int po = pt * 16 + r16;
-            if (pt >= C::PT_O || po >= C::POUT) continue;
-            const int fi = po / (C::TH * C::TW), r = po % (C::TH * C::TW);
-            const int oyl = r / C::TW, oxl = r % C::TW;
-            const int f = f0 + fi, oy = oy0 + oyl, ox = ox0 + oxl;
-            if (f >= B || oy >= C::HOUT || ox >= C::HOUT) continue;
-            f32x4 v = acc[i][j] * sc + sh;
-            if (C::RES) v += *(const f32x4 *)&Xs[((fi * C::IH + (oy - iy0)) * C::IW + (ox - ix0)) * C::XS + n];   // x + conv(x)
-            *(f32x4 *)&Y[((size_t)(f * C::HOUT + oy) * C::HOUT + ox) * C::COUT + n] = v;
-        }
+    if (PROF && tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], ntiles_done);
     }
 }
 
 template <class C>
-static void launch_cfg(const FusedBlockArgs &a, int B, hipStream_t s) {
+static void launch_cfg(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
     const int groups = (B + C::NF - 1) / C::NF;
-    const int grid = groups * C::TILES_Y * C::TILES_X;
-    fused_block_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We, a.e_scale, a.e_shift, a.Wd, a.d_scale, a.d_shift, a.Wp,
-                                                       a.p_scale, a.p_shift, a.Y, B);
+    const int total = groups * C::TILES_Y * C::TILES_X;
+    int grid = total;
+    if (C::WLDS && grid > 256 * wgs_per_cu) grid = 256 * wgs_per_cu;     // persistent: one resident wave of workgroups
+    if (a.prof)
+        fused_block_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We, a.e_scale, a.e_shift, a.Wd, a.d_scale, a.d_shift,
+                                                                 a.Wp, a.p_scale, a.p_shift, a.Y, B, total, a.prof);
+    else
+        fused_block_kernel<C, false><<<grid, C::NW * 64, 0, s>>>(a.X, a.We, a.e_scale, a.e_shift, a.Wd, a.d_scale, a.d_shift,
+                                                                  a.Wp, a.p_scale, a.p_shift, a.Y, B, total);
 }
 
-//                      CIN  HID COUT HIN S  RES    TH  TW NF  HC NW EPB WN WP
-using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false,  6,  6, 1, 32, 4, 3, 2, 2>;   // features.2   60 -> 30
-using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 4, 3, 2, 2>;   // features.3   30
-using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 48, 4, 2, 2, 2>;   // features.4   30 -> 15
-using Cfg5 = BlockCfg<  32, 192,  32, 15, 1, true,  15, 15, 1, 32, 8, 4, 2, 4>;   // features.5,6 15
-using Cfg7 = BlockCfg<  32, 192,  64, 15, 2, false,  8,  8, 1, 32, 4, 4, 4, 1>;   // features.7   15 -> 8
-using Cfg8 = BlockCfg<  64, 384,  64,  8, 1, true,   8,  8, 1, 64, 4, 4, 4, 1>;   // features.8-10
-using Cfg11 = BlockCfg< 64, 384,  96,  8, 1, false,  8,  8, 1, 64, 4, 4, 2, 2>;   // features.11
-using Cfg12 = BlockCfg< 96, 576,  96,  8, 1, true,   8,  8, 1, 64, 4, 4, 2, 2>;   // features.12,13
-using Cfg14 = BlockCfg< 96, 576, 160,  8, 2, false,  4,  4, 2, 64, 4, 4, 4, 1>;   // features.14  8 -> 4
-using Cfg15 = BlockCfg<160, 960, 160,  4, 1, true,   4,  4, 4, 64, 4, 4, 2, 2>;   // features.15,16
-using Cfg17 = BlockCfg<160, 960, 320,  4, 1, false,  4,  4, 4, 64, 4, 4, 4, 1>;   // features.17
+//                      CIN  HID COUT HIN S  RES    TH  TW NF  HC NW EPB WN WP  WLDS
+using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false,  6,  6, 1, 32, 4, 3, 2, 2, true>;    // features.2   60 -> 30
+using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 8, 2, 2, 4, true>;    // features.3   30
+using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 16, 4, 2, 2, 2, true>;    // features.4   30 -> 15
+using Cfg5 = BlockCfg<  32, 192,  32, 15, 1, true,  15, 15, 1, 32, 8, 4, 2, 4, false>;   // features.5,6 15
+using Cfg7 = BlockCfg<  32, 192,  64, 15, 2, false,  8,  8, 1, 32, 4, 4, 4, 1, false>;   // features.7   15 -> 8
+using Cfg8 = BlockCfg<  64, 384,  64,  8, 1, true,   8,  8, 1, 64, 4, 4, 4, 1, false>;   // features.8-10
+using Cfg11 = BlockCfg< 64, 384,  96,  8, 1, false,  8,  8, 1, 64, 4, 4, 2, 2, false>;   // features.11
+using Cfg12 = BlockCfg< 96, 576,  96,  8, 1, true,   8,  8, 1, 64, 4, 4, 2, 2, false>;   // features.12,13
+using Cfg14 = BlockCfg< 96, 576, 160,  8, 2, false,  4,  4, 2, 64, 4, 4, 4, 1, false>;   // features.14  8 -> 4
+using Cfg15 = BlockCfg<160, 960, 160,  4, 1, true,   4,  4, 4, 64, 4, 4, 2, 2, false>;   // features.15,16
+using Cfg17 = BlockCfg<160, 960, 320,  4, 1, false,  4,  4, 4, 64, 4, 4, 4, 1, false>;   // features.17
 
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     switch (feature) {
-        case 2: launch_cfg<Cfg2>(a, B, s); return true;
-        case 3: launch_cfg<Cfg3>(a, B, s); return true;
-        case 4: launch_cfg<Cfg4>(a, B, s); return true;
-        case 5: case 6: launch_cfg<Cfg5>(a, B, s); return true;
-        case 7: launch_cfg<Cfg7>(a, B, s); return true;
-        case 8: case 9: case 10: launch_cfg<Cfg8>(a, B, s); return true;
-        case 11: launch_cfg<Cfg11>(a, B, s); return true;
-        case 12: case 13: launch_cfg<Cfg12>(a, B, s); return true;
-        case 14: launch_cfg<Cfg14>(a, B, s); return true;
-        case 15: case 16: launch_cfg<Cfg15>(a, B, s); return true;
-        case 17: launch_cfg<Cfg17>(a, B, s); return true;
+        case 2: launch_cfg<Cfg2>(a, B, s, 2); return true;
+        case 3: launch_cfg<Cfg3>(a, B, s, 1); return true;
+        case 4: launch_cfg<Cfg4>(a, B, s, 2); return true;
+        case 5: case 6: launch_cfg<Cfg5>(a, B, s, 1); return true;
+        case 7: launch_cfg<Cfg7>(a, B, s, 1); return true;
+        case 8: case 9: case 10: launch_cfg<Cfg8>(a, B, s, 1); return true;
+        case 11: launch_cfg<Cfg11>(a, B, s, 1); return true;
+        case 12: case 13: launch_cfg<Cfg12>(a, B, s, 1); return true;
+        case 14: launch_cfg<Cfg14>(a, B, s, 1); return true;
+        case 15: case 16: launch_cfg<Cfg15>(a, B, s, 1); return true;
+        case 17: launch_cfg<Cfg17>(a, B, s, 1); return true;
         default: return false;
     }
 }

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
                                                     float *__restrict__ out, int B, int n_vert, int n_tiles,
                                                     int n_split, int ftiles_per_split, int n_ftiles) {
     __shared__ __attribute__((aligned(16))) float smt[4][32][12];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int task = blockIdx.x * 4 + wave;
     const int T = task / n_split, split = task - T * n_split;
     if (T >= n_tiles) return;

@@ -44,8 +44,14 @@ struct FusedBlockArgs {
     const float *Wd, *d_scale, *d_shift;              // depthwise: [9][HID], [HID], [HID]
     const float *Wp, *p_scale, *p_shift;              // project: Wpk[COUTP/16][HID/16][64][4], [COUTP], [COUTP]
     float *Y;                                         // block output NHWC
+    unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+
+// features.0 + features.1 fused (stem_block1.hip): image -> NHWC [B,60,60,16].
+void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w0, const float *s0,
+                        const float *b0, const float *wd, const float *sd, const float *bd, const float *wp_pk,
+                        const float *sp, const float *bp, float *Y, int B, hipStream_t s);
 
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):

@@ -106,7 +106,7 @@ struct Net {
             L.dst_scale = dst; dst += cpad;
             L.dst_shift = dst; dst += cpad;
             L.dst_wpk = 0;
-            if (L.kind == PW && L.feature >= 2 && L.feature <= 17) {
+            if (L.kind == PW && L.feature >= 1 && L.feature <= 17) {
                 L.dst_wpk = dst;
                 dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
             }
@@ -201,7 +201,8 @@ void pack_basis_tiles(float *dst, int n_rows_valid, int n_tiles, const float *w_
 }
 
 int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, float *param, float *pool, hipStream_t s,
-                 int stop_feature = -1, float *feature_out = nullptr) {
+                 int stop_feature = -1, float *feature_out = nullptr, int prof_feature = -1,
+                 unsigned long long *prof = nullptr) {
     const Net &n = net();
     int rc = ensure_ws(h, B);
     if (rc) return rc;
@@ -214,11 +215,24 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     for (size_t li = 0; li < nl; ++li) {
         const Layer &L = n.layers[li];
         const float *w = P + L.dst_w, *sc = P + L.dst_scale, *sh = P + L.dst_shift;
+        // fused network head: stem conv + features.1 (dw + linear project) in one launch
+        if (h->fusion && L.kind == STEM && stop_feature != 0) {
+            const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
+            syn::launch_stem_block1(img, img8, w, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
+                                    P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, X, B, s);
+            li += 2;
+            if (stop_feature == 1) {
+                HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Pj.cout * Pj.hout * Pj.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                return SYN_OK;
+            }
+            continue;
+        }
         // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
         if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
             syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
                                   P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
+            if (prof_feature == L.feature) a.prof = prof;
             if (syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
@@ -454,6 +468,28 @@ int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img, int B, float *par
     if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward_u8: backbone weights not loaded");
     DeviceGuard g(h->device);
     return run_backbone(h, nullptr, img, B, param, pool, (hipStream_t)stream);
+}
+
+// Profiling hook, not part of include/synergy_hip.h: runs the backbone with the fused block of
+// .features[feature] instrumented; out8 (host) = summed s_memtime ticks of wave 0 per stage
+// {stage0, expand, barrier, depthwise, barrier, project, epilogue} and the workgroup count.
+int syn_debug_profile_block(syn_handle *h, const float *img, int B, int feature, unsigned long long *out8) {
+    if (!h || !img || !out8 || B <= 0) return fail(SYN_ERR_INVALID, "syn_debug_profile_block: bad argument");
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_debug_profile_block: backbone weights not loaded");
+    DeviceGuard g(h->device);
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
+    float *param = nullptr;
+    HIP_TRY(hipMalloc((void **)&param, (size_t)B * 62 * sizeof(float)));
+    int rc = run_backbone(h, img, nullptr, B, param, nullptr, nullptr, -1, nullptr, feature, d);
+    if (rc == SYN_OK) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d);
+    (void)hipFree(param);
+    return rc;
 }
 
 // Test hook, not part of include/synergy_hip.h: output of .features[feature] as NHWC [B,H,W,C].

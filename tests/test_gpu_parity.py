@@ -24,7 +24,9 @@ def model(request, pack, backbone_sd):
     from synergynet_amd.synergy3DMM import SynergyNet
     os.environ['SYNERGY_HIP_FUSION'] = '1' if request.param == 'fused-blocks' else '0'
     try:
-        return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+        m = SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+        m._test_fusion = os.environ['SYNERGY_HIP_FUSION']
+        return m
     finally:
         os.environ.pop('SYNERGY_HIP_FUSION', None)
 
@@ -193,7 +195,11 @@ def test_constants_export_import_roundtrip(model, golden):
     import torch
     from synergynet_amd.synergy3DMM import SynergyNet
     buf = model.export_constants()
-    other = SynergyNet(device='cuda:0', load_constants=False)
+    os.environ['SYNERGY_HIP_FUSION'] = model._test_fusion      # same schedule -> bit-identical results
+    try:
+        other = SynergyNet(device='cuda:0', load_constants=False)
+    finally:
+        os.environ.pop('SYNERGY_HIP_FUSION', None)
     other.import_constants(buf)
     p = torch.from_numpy(golden['params']).cuda()
     assert torch.equal(other.reconstruct(p, dense=True), model.reconstruct(p, dense=True))
