@@ -116,9 +116,18 @@ int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double 
 
 /* ---- introspection (bench / profiling) --------------------------------------------- */
 
-/* Number of kernel launches one syn_backbone_forward issues, and the algorithmic FLOPs
- * of its pointwise (MFMA) convolutions per face. */
+/* Number of kernel launches one per-layer syn_backbone_forward issues. */
 int syn_backbone_launch_count(syn_handle *h);
+
+/* Runs one forward with a HIP event recorded on the library's stream after every kernel launch.
+ * Returns the number of launches n (<= max_launches) or a negative syn_status; for launch i:
+ * feature_of_launch[i] = index into .features the launch completes (1 = fused stem + features.1,
+ * 19 = pool + heads), ms_of_launch[i] = event-to-event time, flops_of_launch[i] = algorithmic FLOPs
+ * of the layers it covers for the whole batch (no halo / padding work counted).  Synchronises. */
+int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_launches,
+                         int *feature_of_launch, float *ms_of_launch, double *flops_of_launch);
+
+/* Algorithmic FLOPs per face of the whole backbone / of its pointwise (MFMA) convolutions. */
 double syn_backbone_flops_per_face(void);
 double syn_pointwise_flops_per_face(void);
 

@@ -396,9 +396,9 @@ static void launch_cfg(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_pe
 }
 
 //                      CIN  HID COUT HIN S  RES    TH  TW NF  HC NW EPB WN WP  WLDS
-using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false,  6,  6, 1, 32, 4, 3, 2, 2, true>;    // features.2   60 -> 30
+using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false,  6,  6, 1, 96, 8, 3, 2, 4, true>;    // features.2   60 -> 30
 using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 8, 2, 2, 4, true>;    // features.3   30
-using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 16, 4, 2, 2, 2, true>;    // features.4   30 -> 15
+using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 144, 8, 2, 2, 4, true>;   // features.4   30 -> 15
 using Cfg5 = BlockCfg<  32, 192,  32, 15, 1, true,  15, 15, 1, 32, 8, 4, 2, 4, false>;   // features.5,6 15
 using Cfg7 = BlockCfg<  32, 192,  64, 15, 2, false,  8,  8, 1, 32, 4, 4, 4, 1, false>;   // features.7   15 -> 8
 using Cfg8 = BlockCfg<  64, 384,  64,  8, 1, true,   8,  8, 1, 64, 4, 4, 4, 1, false>;   // features.8-10
@@ -410,9 +410,9 @@ using Cfg17 = BlockCfg<160, 960, 320,  4, 1, false,  4,  4, 4, 64, 4, 4, 4, 1, f
 
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     switch (feature) {
-        case 2: launch_cfg<Cfg2>(a, B, s, 2); return true;
+        case 2: launch_cfg<Cfg2>(a, B, s, 1); return true;
         case 3: launch_cfg<Cfg3>(a, B, s, 1); return true;
-        case 4: launch_cfg<Cfg4>(a, B, s, 2); return true;
+        case 4: launch_cfg<Cfg4>(a, B, s, 1); return true;
         case 5: case 6: launch_cfg<Cfg5>(a, B, s, 1); return true;
         case 7: launch_cfg<Cfg7>(a, B, s, 1); return true;
         case 8: case 9: case 10: launch_cfg<Cfg8>(a, B, s, 1); return true;

@@ -2,10 +2,17 @@
 // (depthwise 3x3 + BN + ReLU6, then linear 1x1 32->16 + BN; t = 1 block without expand conv) in ONE
 // kernel (reference mobilenetv2_backbone.py:129, :58-66).  The 60x60x32 stem output -- the largest
 // activation of the network, 460 KB per face -- never leaves the CU: a workgroup reads the 25x25x3
-// image patch behind a 10x10 output tile, builds the 12x12x32 stem tile in LDS, runs the depthwise
-// stage LDS->LDS and the 32->16 projection on the fp32 MFMA, and stores 10x10x16 (NHWC).
-// HBM traffic per face: 43 KB of uint8 crop in (+halo re-reads from L2), 230 KB out.
-// The uint8 variant also folds the HWC->CHW permute and (x-127.5)/128 (synergy3DMM.py:189-192).
+// image patch behind a 10x10 output tile, builds the 12x12x32 stem tile in LDS with an im2col GEMM on
+// the fp32 MFMA, runs the depthwise stage LDS->LDS (sliding 3-row window) and the 32->16 projection on
+// the MFMA, and stores 10x10x16 (NHWC).  HBM traffic per face: 43 KB of uint8 crop in (+halo re-reads
+// from L2), 230 KB out.  The uint8 variant also folds the HWC->CHW permute and (x-127.5)/128
+// (synergy3DMM.py:189-192).
+//
+// Workgroups are PERSISTENT (filters / BN vectors are loaded into LDS and registers once) and the next
+// tile's image patch is prefetched into registers while the current tile computes: uint8 rows as aligned
+// dwords (25 px * 3 B = 75 B -> 20 dwords per patch row), fp32 NCHW planes as scalars.
+#include <cstdlib>
+
 #include "syn_internal.h"
 
 namespace syn {
@@ -18,10 +25,19 @@ constexpr int FT = T + 2;             // stem-output tile edge incl. the depthwi
 constexpr int IT = 2 * FT + 1;        // image tile edge (stride-2 3x3 receptive field) = 25
 constexpr int ITS = IT + 1;           // padded image row
 constexpr int ES = 36;                // LDS row stride of the 32-channel tiles
-constexpr int PIN = FT * FT;          // 144 stem pixels
+constexpr int PIN = FT * FT;          // 144 stem pixels = 9 MFMA pixel tiles
 constexpr int POUT = T * T, POUTP = 112;
 constexpr int NTH = 256;
+constexpr int ROWDW = 20;             // dwords per uint8 patch row (covers 3 lead bytes + 75 + tail)
+constexpr int U8_IPT = (IT * ROWDW + NTH - 1) / NTH;      // 2 dword loads per thread per tile
+constexpr int F32_IPT = (3 * IT * IT + NTH - 1) / NTH;    // 8 scalar loads per thread per tile
 __device__ __forceinline__ float r6(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ f32x4 r6(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = r6(v[i]);
+    return r;
+}
 }  // namespace
 
 template <bool U8>
@@ -29,121 +45,218 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     const float *__restrict__ img, const uint8_t *__restrict__ img8, const float *__restrict__ w0 /*[27][32]*/,
     const float *__restrict__ s0, const float *__restrict__ b0, const float *__restrict__ wd /*[9][32]*/,
     const float *__restrict__ sd, const float *__restrict__ bd, const float *__restrict__ wp /*Wpk[1][2][64][4]*/,
-    const float *__restrict__ sp, const float *__restrict__ bp, float *__restrict__ Y, int B) {
+    const float *__restrict__ sp, const float *__restrict__ bp, float *__restrict__ Y, int total_tiles, int ablate) {
     __shared__ __attribute__((aligned(16))) float im[3 * IT * ITS];
     __shared__ __attribute__((aligned(16))) float Es[PIN * ES];
     __shared__ __attribute__((aligned(16))) float Ds[POUTP * ES];
-    __shared__ __attribute__((aligned(16))) float W0[27 * 32 + 64];     // stem filter | scale | shift
-    __shared__ __attribute__((aligned(16))) float WD[9 * 32 + 64];      // depthwise filter | scale | shift
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int tx = bid % 6;
-    bid /= 6;
-    const int ty = bid % 6;
-    const int f = bid / 6;
-    const int oy0 = ty * T, ox0 = tx * T;            // first output pixel (60x60 grid)
-    const int fy0 = oy0 - 1, fx0 = ox0 - 1;          // stem-output coords of Es pixel (0,0)
-    const int iy0 = 2 * fy0 - 1, ix0 = 2 * fx0 - 1;  // image coords of im pixel (0,0)
-
-    for (int i = tid; i < 27 * 32 / 4; i += NTH) *(f32x4 *)&W0[4 * i] = *(const f32x4 *)&w0[4 * i];
-    if (tid < 8) { *(f32x4 *)&W0[864 + 4 * tid] = *(const f32x4 *)&s0[4 * tid]; *(f32x4 *)&W0[896 + 4 * tid] = *(const f32x4 *)&b0[4 * tid]; }
-    for (int i = tid; i < 9 * 32 / 4; i += NTH) *(f32x4 *)&WD[4 * i] = *(const f32x4 *)&wd[4 * i];
-    if (tid >= 64 && tid < 72) { const int t = tid - 64; *(f32x4 *)&WD[288 + 4 * t] = *(const f32x4 *)&sd[4 * t]; *(f32x4 *)&WD[320 + 4 * t] = *(const f32x4 *)&bd[4 * t]; }
-    // image patch -> LDS as normalised fp32 planes; zero outside the image (conv padding = 1)
-    for (int i = tid; i < IT * IT; i += NTH) {
-        const int ly = i / IT, lx = i % IT;
-        const int iy = iy0 + ly, ix = ix0 + lx;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (iy >= 0 && iy < kImg && ix >= 0 && ix < kImg) {
-            if (U8) {
-                const uint8_t *p = img8 + ((size_t)(f * kImg + iy) * kImg + ix) * 3;
-                v0 = ((float)p[0] - 127.5f) * 0.0078125f;
-                v1 = ((float)p[1] - 127.5f) * 0.0078125f;
-                v2 = ((float)p[2] - 127.5f) * 0.0078125f;
-            } else {
-                const float *p = img + ((size_t)f * 3 * kImg + iy) * kImg + ix;
-                v0 = p[0]; v1 = p[kImg * kImg]; v2 = p[2 * kImg * kImg];
-            }
-        }
-        im[ly * ITS + lx] = v0;
-        im[IT * ITS + ly * ITS + lx] = v1;
-        im[2 * IT * ITS + ly * ITS + lx] = v2;
-    }
-    for (int i = tid; i < (POUTP - POUT) * ES; i += NTH) Ds[POUT * ES + i] = 0.f;
-    __syncthreads();
-
-    // ---- stem conv: thread = (stem pixel, 4 channels) ----
-    for (int it = tid; it < PIN * 8; it += NTH) {
-        const int c4 = it & 7, p = it >> 3;
-        const int ly = p / FT, lx = p % FT;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = im[ci * IT * ITS + (2 * ly + ky) * ITS + 2 * lx + kx];
-                    a += v * *(const f32x4 *)&W0[(ci * 9 + ky * 3 + kx) * 32 + 4 * c4];
-                }
-        const f32x4 sc = *(const f32x4 *)&W0[864 + 4 * c4], sh = *(const f32x4 *)&W0[896 + 4 * c4];
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = r6(a[j] * sc[j] + sh[j]);
-        *(f32x4 *)&Es[p * ES + 4 * c4] = o;
-    }
-    __syncthreads();
-    // ---- depthwise 3x3 s1 on the stem tile (zero padding = taps outside the 60x60 map contribute 0) ----
-    for (int it = tid; it < POUT * 8; it += NTH) {
-        const int c4 = it & 7, po = it >> 3;
-        const int oyl = po / T, oxl = po % T;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int fy = fy0 + oyl + ky;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int fx = fx0 + oxl + kx;
-                const bool ok = fy >= 0 && fy < 60 && fx >= 0 && fx < 60;
-                f32x4 e = *(const f32x4 *)&Es[((oyl + ky) * FT + oxl + kx) * ES + 4 * c4];
-                const f32x4 w = *(const f32x4 *)&WD[(ky * 3 + kx) * 32 + 4 * c4];
-                if (!ok) e = (f32x4){0.f, 0.f, 0.f, 0.f};
-                a += e * w;
-            }
-        }
-        const f32x4 sc = *(const f32x4 *)&WD[288 + 4 * c4], sh = *(const f32x4 *)&WD[320 + 4 * c4];
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = r6(a[j] * sc[j] + sh[j]);
-        *(f32x4 *)&Ds[po * ES + 4 * c4] = o;
-    }
-    __syncthreads();
-    // ---- linear 1x1 32 -> 16 on the MFMA: 7 pixel tiles over 4 waves ----
+    __shared__ __attribute__((aligned(16))) float WD[11 * 32];          // depthwise filter [9][32] | scale | shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const f32x4 a0 = *(const f32x4 *)(wp + lane * 4), a1 = *(const f32x4 *)(wp + 256 + lane * 4);
-    const f32x4 sc = *(const f32x4 *)&sp[4 * g], sh = *(const f32x4 *)&bp[4 * g];
-    for (int pt = wave; pt < POUTP / 16; pt += 4) {
-        const f32x4 b0v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 4 * g];
-        const f32x4 b1v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 16 + 4 * g];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-workgroup constants: depthwise filter in LDS; stem / project fragments + BN in registers ----
+    for (int i = tid; i < 9 * 32 / 4; i += NTH) *(f32x4 *)&WD[4 * i] = *(const f32x4 *)&wd[4 * i];
+    if (tid < 8) { *(f32x4 *)&WD[288 + 4 * tid] = *(const f32x4 *)&sd[4 * tid]; *(f32x4 *)&WD[320 + 4 * tid] = *(const f32x4 *)&bd[4 * tid]; }
+    for (int i = tid; i < (POUTP - POUT) * ES; i += NTH) Ds[POUT * ES + i] = 0.f;
+    // stem filter as MFMA "A" fragments: lane (channel r16 of tile nt, k-slot g): k = 16*kc + 4*g + q < 27
+    f32x4 wa[2][2];
+    int koff[2][4];                     // LDS offset of patch element k inside the image planes (-1: zero pad)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0v[s], acc, 0, 0, 0);
+    for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1v[s], acc, 0, 0, 0);
-        const int po = pt * 16 + r16;
-        if (po < POUT) {
-            const int oy = oy0 + po / T, ox = ox0 + po % T;
-            *(f32x4 *)&Y[((size_t)(f * 60 + oy) * 60 + ox) * 16 + 4 * g] = acc * sc + sh;
+        for (int q = 0; q < 4; ++q) {
+            const int k = 16 * kc + 4 * g + q;
+            const int ci = k / 9, rr = k % 9;
+            koff[kc][q] = k < 27 ? ci * IT * ITS + (rr / 3) * ITS + rr % 3 : -1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wa[nt][kc][q] = k < 27 ? w0[k * 32 + nt * 16 + r16] : 0.f;
         }
+    const f32x4 sc0 = *(const f32x4 *)&s0[4 * g], sh0 = *(const f32x4 *)&b0[4 * g];
+    const f32x4 sc1 = *(const f32x4 *)&s0[16 + 4 * g], sh1 = *(const f32x4 *)&b0[16 + 4 * g];
+    const f32x4 pa0 = *(const f32x4 *)(wp + lane * 4), pa1 = *(const f32x4 *)(wp + 256 + lane * 4);
+    const f32x4 psc = *(const f32x4 *)&sp[4 * g], psh = *(const f32x4 *)&bp[4 * g];
+
+    // ---- image patch prefetch (registers) ----
+    unsigned xr8[U8_IPT];
+    float xrf[U8 ? 1 : F32_IPT];
+    auto tile_origin = [&](int tile, int &f, int &oy0, int &ox0) {
+        ox0 = (tile % 6) * T;
+        oy0 = ((tile / 6) % 6) * T;
+        f = tile / 36;
+    };
+    auto load_patch = [&](int tile) {
+        int f, oy0, ox0;
+        tile_origin(tile, f, oy0, ox0);
+        const int iy0 = 2 * (oy0 - 1) - 1, ix0 = 2 * (ox0 - 1) - 1;     // image coords of patch pixel (0,0)
+        if (U8) {
+            // patch row ly = bytes [ (iy*120 + ix0)*3 , +75 ); ix0*3 == 3 (mod 4) for every tile column, so the
+            // aligned window starts 3 bytes earlier and is 20 dwords long; image rows are 360 B (a dword multiple),
+            // so an aligned dword is either entirely inside its row or entirely outside (then it is masked later)
+#pragma unroll
+            for (int ii = 0; ii < U8_IPT; ++ii) {
+                const int it = tid + ii * NTH;
+                const int ly = it / ROWDW, d = it % ROWDW;
+                const int iy = iy0 + ly;
+                const int byte0 = ix0 * 3 - 3 + 4 * d;                   // byte offset inside the image row
+                unsigned v = 0x80808080u;                                 // never used un-masked
+                if (it < IT * ROWDW && iy >= 0 && iy < kImg && byte0 >= 0 && byte0 + 3 < kImg * 3)
+                    v = *(const unsigned *)(img8 + ((size_t)(f * kImg + iy) * kImg) * 3 + byte0);
+                xr8[ii] = v;
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < F32_IPT; ++ii) {
+                const int it = tid + ii * NTH;
+                const int ci = it / (IT * IT), r = it % (IT * IT);
+                const int iy = iy0 + r / IT, ix = ix0 + r % IT;
+                float v = 0.f;
+                if (it < 3 * IT * IT && iy >= 0 && iy < kImg && ix >= 0 && ix < kImg)
+                    v = img[((size_t)(f * 3 + ci) * kImg + iy) * kImg + ix];
+                xrf[ii] = v;
+            }
+        }
+    };
+    auto store_patch = [&](int tile) {      // registers -> normalised fp32 planes in LDS, zero outside the image
+        int f, oy0, ox0;
+        tile_origin(tile, f, oy0, ox0);
+        const int iy0 = 2 * (oy0 - 1) - 1, ix0 = 2 * (ox0 - 1) - 1;
+        if (U8) {
+#pragma unroll
+            for (int ii = 0; ii < U8_IPT; ++ii) {
+                const int it = tid + ii * NTH;
+                if (it >= IT * ROWDW) continue;
+                const int ly = it / ROWDW, d = it % ROWDW;
+                const bool row_ok = (unsigned)(iy0 + ly) < (unsigned)kImg;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int pb = 4 * d + b - 3;                        // byte index inside the 75-byte patch row
+                    if (pb < 0 || pb >= IT * 3) continue;
+                    const int lx = pb / 3, ci = pb % 3;
+                    const bool ok = row_ok && (unsigned)(ix0 + lx) < (unsigned)kImg;
+                    const float v = ((float)((xr8[ii] >> (8 * b)) & 0xffu) - 127.5f) * 0.0078125f;
+                    im[ci * IT * ITS + ly * ITS + lx] = ok ? v : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < F32_IPT; ++ii) {
+                const int it = tid + ii * NTH;
+                if (it >= 3 * IT * IT) continue;
+                const int ci = it / (IT * IT), r = it % (IT * IT);
+                im[ci * IT * ITS + (r / IT) * ITS + r % IT] = xrf[ii];
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < total_tiles) load_patch(tile);
+    // de-phase the co-resident persistent workgroups of a CU (they start together and would otherwise hit the
+    // same MFMA / VALU / LDS stage at the same time): workgroup "layer" k waits k * ~1/3 tile time once
+    if (ablate & 16)
+        for (int i = 0; i < (int)(blockIdx.x >> 8) * 3; ++i) __builtin_amdgcn_s_sleep(32);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        int f, oy0, ox0;
+        tile_origin(tile, f, oy0, ox0);
+        const int fy0 = oy0 - 1, fx0 = ox0 - 1;      // stem-output coords of Es pixel (0,0)
+        if (!(ablate & 1)) store_patch(tile);
+        __syncthreads();
+        if (!(ablate & 1) && tile + (int)gridDim.x < total_tiles) load_patch(tile + gridDim.x);     // in flight during the whole tile
+
+        // ---- stem conv on the MFMA: im2col GEMM  E[144 px][32] = patch[px][27(+5 zero)] . W0^T ----
+        // MFMA "B" = patches gathered straight from the LDS image planes: lane (pixel r16, k-slot g) reads
+        // element k at the fixed per-lane offset koff[kc][q] plus the pixel's base 2*ly*ITS + 2*lx.
+        if (!(ablate & 2))
+        for (int pt = wave; pt < PIN / 16; pt += 4) {
+            const int p = pt * 16 + r16;
+            const int base = 2 * (p / FT) * ITS + 2 * (p % FT);
+            f32x4 bv[2];
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = im[base + (koff[kc][q] >= 0 ? koff[kc][q] : 0)];
+                    bv[kc][q] = koff[kc][q] >= 0 ? v : 0.f;
+                }
+            f32x4 e0 = z4, e1 = z4;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][kc][q], bv[kc][q], e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kc][q], bv[kc][q], e1, 0, 0, 0);
+                }
+            // lane owns pixel p, channels 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
+            *(f32x4 *)&Es[p * ES + 4 * g] = r6(e0 * sc0 + sh0);
+            *(f32x4 *)&Es[p * ES + 16 + 4 * g] = r6(e1 * sc1 + sh1);
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 s1 on the stem tile: thread = (channel quad, output column, row half) ----
+        // column taps outside the 60x60 map are folded into the thread's filter copy, rows outside load as 0
+        if (!(ablate & 4) && tid < 8 * T * 2) {
+            const int c4 = tid & 7, q2 = tid >> 3;
+            const int oxl = q2 % T, seg = q2 / T;
+            const int fxb = fx0 + oxl;                                   // stem x of tap kx = 0
+            f32x4 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&WD[k * 32 + 4 * c4];
+            if (fxb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
+            if (fxb + 2 >= 60) { w[2] = z4; w[5] = z4; w[8] = z4; }
+            const f32x4 sc = *(const f32x4 *)&WD[288 + 4 * c4], sh = *(const f32x4 *)&WD[320 + 4 * c4];
+            f32x4 rb[3][3];
+            auto load_row = [&](int ly, f32x4(&dst)[3]) {               // ly = tile row (always inside the 12x12 tile)
+                const bool ok = (unsigned)(fy0 + ly) < 60u;
+                const float *er = Es + (ly * FT + oxl) * ES + 4 * c4;
+                dst[0] = *(const f32x4 *)(er);
+                dst[1] = *(const f32x4 *)(er + ES);
+                dst[2] = *(const f32x4 *)(er + 2 * ES);
+                if (!ok) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
+            };
+#pragma unroll
+            for (int r = 0; r < T / 2; ++r) {
+                const int oyl = seg * (T / 2) + r;
+                if (r == 0) { load_row(oyl, rb[0]); load_row(oyl + 1, rb[1]); load_row(oyl + 2, rb[2]); }
+                else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { rb[0][k] = rb[1][k]; rb[1][k] = rb[2][k]; }
+                    load_row(oyl + 2, rb[2]);
+                }
+                f32x4 a = rb[0][0] * w[0];
+                a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
+                a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
+                *(f32x4 *)&Ds[(oyl * T + oxl) * ES + 4 * c4] = r6(a * sc + sh);
+            }
+        }
+        __syncthreads();
+        // ---- linear 1x1 32 -> 16 on the MFMA: 7 pixel tiles over 4 waves ----
+        if (!(ablate & 8))
+        for (int pt = wave; pt < POUTP / 16; pt += 4) {
+            const f32x4 b0v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 4 * g];
+            const f32x4 b1v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 16 + 4 * g];
+            f32x4 acc = z4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[s], b0v[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa1[s], b1v[s], acc, 0, 0, 0);
+            const int po = pt * 16 + r16;
+            if (po < POUT) {
+                const int oy = oy0 + po / T, ox = ox0 + po % T;
+                *(f32x4 *)&Y[((size_t)(f * 60 + oy) * 60 + ox) * 16 + 4 * g] = acc * psc + psh;
+            }
+        }
+        // the next iteration rewrites `im` (read in the stem stage, two barriers ago) and then barriers before
+        // Es is rewritten; Ds is rewritten only after two more barriers -> no extra barrier needed here
     }
 }
 
 void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, const float *s0, const float *b0,
                         const float *wd, const float *sd, const float *bd, const float *wp, const float *sp,
                         const float *bp, float *Y, int B, hipStream_t s) {
-    const int grid = B * 36;
-    if (img8) stem_block1_kernel<true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, B);
-    else      stem_block1_kernel<false><<<grid, NTH, 0, s>>>(img, nullptr, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, B);
+    const int total = B * 36;
+    const int grid = total < 256 * 3 ? total : 256 * 3;          // persistent: 3 workgroups (50 KB LDS each) per CU
+    static const int ablate = getenv("SYN_ABLATE_STEM") ? atoi(getenv("SYN_ABLATE_STEM")) : 0;   // profiling only: skip stages
+    if (img8) stem_block1_kernel<true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    else      stem_block1_kernel<false><<<grid, NTH, 0, s>>>(img, nullptr, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
 }
 
 }  // namespace syn

@@ -202,7 +202,8 @@ void pack_basis_tiles(float *dst, int n_rows_valid, int n_tiles, const float *w_
 
 int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, float *param, float *pool, hipStream_t s,
                  int stop_feature = -1, float *feature_out = nullptr, int prof_feature = -1,
-                 unsigned long long *prof = nullptr) {
+                 unsigned long long *prof = nullptr, std::vector<hipEvent_t> *marks = nullptr,
+                 std::vector<int> *mark_feature = nullptr) {
     const Net &n = net();
     int rc = ensure_ws(h, B);
     if (rc) return rc;
@@ -212,6 +213,15 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     float *H2 = H1 + (size_t)B * n.max_hidden;
     const float *P = h->d_backbone;
     const size_t nl = n.layers.size();
+    auto mark = [&](int feature) {          // profiling hook: one event after every launch
+        if (!marks) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, s);
+        marks->push_back(e);
+        mark_feature->push_back(feature);
+    };
+    mark(-1);
     for (size_t li = 0; li < nl; ++li) {
         const Layer &L = n.layers[li];
         const float *w = P + L.dst_w, *sc = P + L.dst_scale, *sh = P + L.dst_shift;
@@ -221,6 +231,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::launch_stem_block1(img, img8, w, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
                                     P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, X, B, s);
             li += 2;
+            mark(1);
             if (stop_feature == 1) {
                 HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Pj.cout * Pj.hout * Pj.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
                 return SYN_OK;
@@ -236,6 +247,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             if (syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
+                mark(L.feature);
                 const Layer &Lp = n.layers[li];
                 if (stop_feature >= 0 && Lp.feature == stop_feature) {
                     HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -258,6 +270,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::launch_pointwise(H2, w, sc, sh, L.residual ? X : nullptr, Y, B * L.hout * L.hout, L.cin, L.kpad, L.cout, 0, s);
             float *t = X; X = Y; Y = t;
         }
+        mark(L.feature);
         // test hook (syn_debug_feature): hand back the NHWC output of .features[stop_feature]
         if (stop_feature >= 0 && L.feature == stop_feature && (li + 1 == nl || n.layers[li + 1].feature != L.feature)) {
             const float *src = L.feature == 18 ? H1 : X;
@@ -266,6 +279,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         }
     }
     syn::launch_pool_fc(H1, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, s);
+    mark(19);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
 }
@@ -468,6 +482,51 @@ int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img, int B, float *par
     if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward_u8: backbone weights not loaded");
     DeviceGuard g(h->device);
     return run_backbone(h, nullptr, img, B, param, pool, (hipStream_t)stream);
+}
+
+int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_launches, int *feature_of_launch,
+                         float *ms_of_launch, double *flops_of_launch) {
+    if (!h || !img_hwc || B <= 0 || !feature_of_launch || !ms_of_launch || !flops_of_launch)
+        return fail(SYN_ERR_INVALID, "syn_backbone_profile: bad argument");
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_profile: backbone weights not loaded");
+    DeviceGuard g(h->device);
+    float *param = nullptr;
+    HIP_TRY(hipMalloc((void **)&param, (size_t)B * 62 * sizeof(float)));
+    std::vector<hipEvent_t> marks;
+    std::vector<int> feats;
+    int rc = run_backbone(h, nullptr, img_hwc, B, param, nullptr, nullptr, -1, nullptr, -1, nullptr, &marks, &feats);
+    int count = 0;
+    if (rc == SYN_OK) {
+        HIP_TRY(hipDeviceSynchronize());
+        const Net &n = net();
+        for (size_t i = 1; i < marks.size() && count < max_launches; ++i, ++count) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, marks[i - 1], marks[i]);
+            feature_of_launch[count] = feats[i];
+            ms_of_launch[count] = ms;
+            double fl = 0;       // algorithmic FLOPs of the layers this launch covers (no halo / padding work)
+            if (feats[i] == 19) fl = 2.0 * 1280 * 62 + 16.0 * 1280;
+            else if (i == 1 && feats[i] == 1) { for (const Layer &L : n.layers) if (L.feature <= 1) fl += 2.0 * (L.kind == STEM ? 27.0 * 32 : L.kind == DW ? 9.0 * L.cout : (double)L.cin * L.cout) * L.hout * L.hout; }
+            else {
+                // a launch after a fused block covers the whole feature; per-layer launches cover one layer each
+                int same = 0;
+                for (size_t j = 1; j < feats.size(); ++j) same += feats[j] == feats[i];
+                int seen = 0;
+                for (size_t j = 1; j <= i; ++j) seen += feats[j] == feats[i];
+                int idx = 0;
+                for (const Layer &L : n.layers) {
+                    if (L.feature != feats[i]) continue;
+                    ++idx;
+                    if (same > 1 && idx != seen) continue;
+                    fl += 2.0 * (L.kind == STEM ? 27.0 * 32 : L.kind == DW ? 9.0 * L.cout : (double)L.cin * L.cout) * L.hout * L.hout;
+                }
+            }
+            flops_of_launch[count] = fl * B;
+        }
+    }
+    for (hipEvent_t e : marks) (void)hipEventDestroy(e);
+    (void)hipFree(param);
+    return rc == SYN_OK ? count : rc;
 }
 
 // Profiling hook, not part of include/synergy_hip.h: runs the backbone with the fused block of
