@@ -1,0 +1,146 @@
+// Fused network tail for gfx950: features.18 (1x1 conv 320->1280 + BN + ReLU6), adaptive_avg_pool2d(4x4 -> 1)
+// and the three linear heads (12 + 40 + 10 outputs) in ONE kernel
+// (reference mobilenetv2_backbone.py:140,177-188).  The 1280x4x4 activation (82 KB per face) never leaves the CU.
+//
+// A workgroup owns 4 faces = 64 pixels (4 MFMA pixel tiles) held in LDS; each of its 4 waves walks 20 of the 80
+// output-channel tiles: per tile 20 k-chunks x 4 pixel tiles x 4 = 320 x v_mfma_f32_16x16x4_f32 with the weight
+// fragments of the NEXT channel tile prefetched into registers meanwhile (weights in MFMA lane order, 1 KiB per
+// fetch).  A lane owns 4 channels of one pixel, so the pool is a 16-lane butterfly (the 16 pixels of a face are
+// the 16 lanes of a DPP row) and the pooled 1280-vector of each face lands in LDS for the 62 dot products.
+#include <cstdlib>
+
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NF = 4, PX = NF * 16, K = 320, KCH = K / 16, N = 1280, NTL = N / 16, XS = K + 4;
+__device__ __forceinline__ float r6h(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+// sum over the 16 lanes of a DPP row, result in every lane of the row: 4 VALU adds, no LDS traffic
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+__device__ __forceinline__ float wave64_sum(float v) {          // uniform result (via 4 v_readlane)
+    const int b = __builtin_bit_cast(int, row16_sum(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /*[B,16,320]*/, const float *__restrict__ Wpk,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   const float *__restrict__ Wfc /*[64,1280]*/, const float *__restrict__ bfc,
+                                                   float *__restrict__ param, float *__restrict__ pool, int B, int ablate) {
+    __shared__ __attribute__((aligned(16))) float Xs[PX * XS];
+    __shared__ __attribute__((aligned(16))) float Ps[NF * N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int f0 = blockIdx.x * NF;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 an[KCH], sn, hn;                         // prefetched: next channel tile's weights + BN
+    auto fetch = [&](int nt) {
+        const float *w = Wpk + (size_t)nt * KCH * 256 + lane * 4;
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) an[kc] = *(const f32x4 *)(w + kc * 256);
+        sn = *(const f32x4 *)&scale[nt * 16 + 4 * g];
+        hn = *(const f32x4 *)&shift[nt * 16 + 4 * g];
+    };
+    fetch(wave);
+    for (int it = tid; it < PX * (K / 4); it += 256) {
+        const int c4 = it % (K / 4), p = it / (K / 4);
+        const int f = f0 + (p >> 4);
+        f32x4 v = z4;
+        if (f < B) v = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
+        *(f32x4 *)&Xs[p * XS + 4 * c4] = v;
+    }
+    __syncthreads();
+
+    for (int nt = wave; nt < NTL; nt += 4) {
+        f32x4 a[KCH];
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) a[kc] = an[kc];
+        const f32x4 sc = sn, sh = hn;
+        if (!(ablate & 1) && nt + 4 < NTL) fetch(nt + 4);
+        f32x4 acc[NF] = {z4, z4, z4, z4};
+        // LDS operand reads run exactly one k-chunk ahead of the MFMAs; the scheduling barriers stop the compiler
+        // from hoisting all 80 reads to the top (that spilled the weight fragments to scratch)
+        f32x4 bc[NF], bn[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bc[j] = *(const f32x4 *)&Xs[(j * 16 + r16) * XS + 4 * g];
+        if (!(ablate & 2))
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            if (kc + 1 < KCH) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bn[j] = *(const f32x4 *)&Xs[(j * 16 + r16) * XS + (kc + 1) * 16 + 4 * g];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc][s], bc[j][s], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bc[j] = bn[j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // BN + ReLU6, then mean over the 16 pixels of each face = butterfly over the 16 lanes sharing g
+        if (!(ablate & 4))
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = r6h(acc[j][t] * sc[t] + sh[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = row16_sum(v[t]);
+            if (r16 == 0) *(f32x4 *)&Ps[j * N + nt * 16 + 4 * g] = v * 0.0625f;
+        }
+    }
+    __syncthreads();
+    // pooled feature out (optional), then the heads: wave w computes outputs w, w+4, ... for all NF faces, so
+    // every row of Wfc is fetched once per workgroup; 64-lane dot products reduced with DPP + readlane
+    if (pool) {
+        for (int it = tid; it < NF * (N / 4); it += 256) {
+            const int j = it / (N / 4), c4 = it % (N / 4);
+            if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
+        }
+    }
+    if (!(ablate & 8)) {
+        f32x4 xv[NF][N / 256];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
+#pragma unroll 2
+        for (int o = wave; o < kParam; o += 4) {
+            const float *wr = Wfc + (size_t)o * N;
+            f32x4 wv[N / 256];
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i) wv[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
+            const float bo = bfc[o];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < N / 256; ++i)
+                    a += wv[i][0] * xv[j][i][0] + wv[i][1] * xv[j][i][1] + wv[i][2] * xv[j][i][2] + wv[i][3] * xv[j][i][3];
+                const float tot = wave64_sum(a);
+                if (lane == 0 && f0 + j < B) param[(size_t)(f0 + j) * kParam + o] = tot + bo;
+            }
+        }
+    }
+}
+
+void launch_head(const float *X, const float *Wpk, const float *scale, const float *shift, const float *Wfc,
+                 const float *bfc, float *param, float *pool, int B, hipStream_t s) {
+    static const int ablate = getenv("SYN_ABLATE_HEAD") ? atoi(getenv("SYN_ABLATE_HEAD")) : 0;   // profiling only
+    head_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wpk, scale, shift, Wfc, bfc, param, pool, B, ablate);
+}
+
+}  // namespace syn

@@ -53,6 +53,11 @@ void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const 
                         const float *b0, const float *wd, const float *sd, const float *bd, const float *wp_pk,
                         const float *sp, const float *bp, float *Y, int B, hipStream_t s);
 
+// features.18 + global average pool + the three heads fused (head_kernel.hip): NHWC [B,4,4,320] -> param [B,62].
+void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const float *scale, const float *shift,
+                 const float *Wfc /*[64,1280]*/, const float *bfc, float *param, float *pool /*nullable*/, int B,
+                 hipStream_t s);
+
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):
 //   Bp[tile][coord x|y|z][chunk][lane][4], K = 52: 0..39 shape, 40..49 expression,

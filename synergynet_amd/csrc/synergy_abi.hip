@@ -106,7 +106,7 @@ struct Net {
             L.dst_scale = dst; dst += cpad;
             L.dst_shift = dst; dst += cpad;
             L.dst_wpk = 0;
-            if (L.kind == PW && L.feature >= 1 && L.feature <= 17) {
+            if (L.kind == PW && L.feature >= 1 && L.feature <= 18) {
                 L.dst_wpk = dst;
                 dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
             }
@@ -262,6 +262,11 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             // input: expanded H1, or the block input X for the t=1 block (no expand conv, :58-60)
             const bool has_expand = li > 0 && n.layers[li - 1].kind == PW && n.layers[li - 1].feature == L.feature;
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
+        } else if (L.feature == 18 && h->fusion && stop_feature != 18) {
+            syn::launch_head(X, P + L.dst_wpk, sc, sh, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, s);
+            mark(19);
+            HIP_TRY(hipGetLastError());
+            return SYN_OK;
         } else if (L.feature == 18) {
             syn::launch_pointwise(X, w, sc, sh, nullptr, H1, B * L.hout * L.hout, L.cin, L.kpad, L.cout, 1, s);
         } else if (L.relu6) {   // expand
@@ -505,7 +510,12 @@ int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_l
             feature_of_launch[count] = feats[i];
             ms_of_launch[count] = ms;
             double fl = 0;       // algorithmic FLOPs of the layers this launch covers (no halo / padding work)
-            if (feats[i] == 19) fl = 2.0 * 1280 * 62 + 16.0 * 1280;
+            if (feats[i] == 19) {
+                fl = 2.0 * 1280 * 62 + 16.0 * 1280;
+                bool has18 = false;
+                for (size_t j = 1; j < feats.size(); ++j) has18 |= feats[j] == 18;
+                if (!has18) fl += 2.0 * 320 * 1280 * 16;          // fused head: features.18 rides in this launch
+            }
             else if (i == 1 && feats[i] == 1) { for (const Layer &L : n.layers) if (L.feature <= 1) fl += 2.0 * (L.kind == STEM ? 27.0 * 32 : L.kind == DW ? 9.0 * L.cout : (double)L.cin * L.cout) * L.hout * L.hout; }
             else {
                 // a launch after a fused block covers the whole feature; per-layer launches cover one layer each
