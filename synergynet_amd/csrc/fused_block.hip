@@ -6,6 +6,9 @@
 // a workgroup owns a spatial tile of output pixels (of NF faces), keeps the input tile (with its 3x3
 // halo) in LDS and walks the hidden channels HC at a time:
 //
+//   (BN scales are folded into the packed weights by the host; accumulators start at the BN shift, so each
+//    BN+ReLU6 epilogue is a single clamp per element -- fp32 MFMA and VALU share the vector pipe on gfx950,
+//    every VALU instruction saved is MFMA time gained)
 //   stage 1  expand   E[pix_in ][HC] = ReLU6(BN(Xs[pix_in][CIN] . We^T))    fp32 MFMA 16x16x4 -> LDS
 //   stage 2  dw 3x3   D[pix_out][HC] = ReLU6(BN(dw(E)))                       VALU, LDS -> LDS
 //   stage 3  project  acc[pix_out][COUT] += D . Wp[:, chunk]^T                fp32 MFMA, accumulators in VGPRs
@@ -74,7 +77,7 @@ struct BlockCfg {
     static constexpr int XS_FLOATS = PINP * XS, ES_FLOATS = PINP * ES, DS_FLOATS = POUTP * ES;
     static constexpr int WE_FLOATS = (HID / 16) * KCH * 256, WP_FLOATS = NT_O * (HID / 16) * 256;
     static constexpr int WD_FLOATS = WLDS ? 11 * HID : 11 * HC;                  // 9 taps | scale | shift
-    static constexpr int LDS_FLOATS = XS_FLOATS + ES_FLOATS + DS_FLOATS + WD_FLOATS + (WLDS ? WE_FLOATS + WP_FLOATS + 2 * HID : 0);
+    static constexpr int LDS_FLOATS = XS_FLOATS + ES_FLOATS + DS_FLOATS + WD_FLOATS + (WLDS ? WE_FLOATS + WP_FLOATS + HID : 0);
     static constexpr int WDR_THREADS = 11 * HC / 4;
     static_assert(HID % HC == 0 && HC % 16 == 0, "hidden chunking");
     static_assert(WN * WP == NW, "wave grid");
@@ -146,16 +149,14 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
             *(f32x4 *)&Wds[row * C::HID + 4 * c4] = *(const f32x4 *)&src[4 * c4];
         }
         for (int i = tid; i < C::HID / 4; i += NT) {
-            *(f32x4 *)&Ebn[4 * i] = *(const f32x4 *)&e_scale[4 * i];
-            *(f32x4 *)&Ebn[C::HID + 4 * i] = *(const f32x4 *)&e_shift[4 * i];
+            *(f32x4 *)&Ebn[4 * i] = *(const f32x4 *)&e_shift[4 * i];
         }
     }
     // project BN of the channels this lane owns: constant for the whole kernel
-    f32x4 psc[C::AN], psh[C::AN];
+    f32x4 psh[C::AN];
 #pragma unroll
     for (int i = 0; i < C::AN; ++i) {
         const int n = (wn + i * C::WN) * 16 + 4 * g;
-        psc[i] = n < C::COUTP ? *(const f32x4 *)&p_scale[n] : z4;
         psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
     }
     if (C::POUTP > C::POUT)
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
 
     // register-prefetched weights (WLDS = false)
     f32x4 a1[C::JPW][C::KCH];      // expand weights of the coming chunk, per job of this wave
-    f32x4 e1s[C::JPW], e1h[C::JPW]; // ... and the expand BN scale / shift of the job's 4 channels
+    f32x4 e1h[C::JPW];             // ... and the expand BN shift of the job's 4 channels
     f32x4 a3[C::AN][C::KC3];       // project weights of the current chunk
     f32x4 wdr = z4;                // this thread's float4 of the coming chunk's depthwise filter / BN
     auto fetch_a1 = [&](int hc0) {
@@ -175,7 +176,6 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
 #pragma unroll
                 for (int kc = 0; kc < C::KCH; ++kc) a1[jj][kc] = *(const f32x4 *)(wa + kc * 256);
                 const int ch = hc0 + (job % C::NT_E) * 16 + 4 * g;
-                e1s[jj] = *(const f32x4 *)&e_scale[ch];
                 e1h[jj] = *(const f32x4 *)&e_shift[ch];
             }
         }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
 #pragma unroll
         for (int i = 0; i < C::AN; ++i)
 #pragma unroll
-            for (int j = 0; j < C::AP; ++j) acc[i][j] = z4;
+            for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];        // BN shift = accumulator start
 
         for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
             const float *wdc = C::WLDS ? Wds + hc0 : Wds;                 // depthwise filter of this chunk
@@ -229,9 +229,11 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                 const int job = wave + jj * C::NW;
                 if (job >= C::JOBS) break;
                 const int nt = job % C::NT_E, pg = job / C::NT_E;
+                const int ch = hc0 + nt * 16 + 4 * g;
+                const f32x4 sh = C::WLDS ? *(const f32x4 *)&Ebn[ch] : e1h[jj];       // BN shift = accumulator start
                 f32x4 ea[C::EPB];
 #pragma unroll
-                for (int q = 0; q < C::EPB; ++q) ea[q] = z4;
+                for (int q = 0; q < C::EPB; ++q) ea[q] = sh;
 #pragma unroll
                 for (int kc = 0; kc < C::KCH; ++kc) {
                     f32x4 a;
@@ -250,13 +252,10 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                         for (int q = 0; q < C::EPB; ++q)
                             ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[q][s], ea[q], 0, 0, 0);
                 }
-                const int ch = hc0 + nt * 16 + 4 * g;
-                const f32x4 sc = C::WLDS ? *(const f32x4 *)&Ebn[ch] : e1s[jj];
-                const f32x4 sh = C::WLDS ? *(const f32x4 *)&Ebn[C::HID + ch] : e1h[jj];
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) {
                     const int pt = pg * C::EPB + q;
-                    if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6_(ea[q] * sc + sh);
+                    if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6_(ea[q]);
                 }
             }
             if (!C::WLDS) fetch_a3(hc0);          // in flight during the depthwise stage
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                 if (ixb + 2 >= C::HIN) { w[2] = z4; w[5] = z4; w[8] = z4; }
                 const int lx1 = ixb + 1 - ix0;
                 const int lx0 = lx1 > 0 ? lx1 - 1 : 0, lx2 = lx1 + 1 < C::IW ? lx1 + 1 : C::IW - 1;
-                const f32x4 sc = *(const f32x4 *)&wdc[9 * WDS + 4 * c4];
                 const f32x4 sh = *(const f32x4 *)&wdc[10 * WDS + 4 * c4];
                 const float *ebase = Es + (size_t)fi * C::IH * C::IW * C::ES + 4 * c4;
                 f32x4 rb[3][3];
@@ -309,12 +307,12 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                         for (int k = 0; k < 3; ++k) rb[0][k] = rb[2][k];
                         load_row(iyb + 1, rb[1]); load_row(iyb + 2, rb[2]);
                     }
-                    f32x4 a = rb[0][0] * w[0];
-                    a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                    f32x4 a = sh;
+                    a += rb[0][0] * w[0]; a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
                     a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
                     a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
                     const int po = (fi * C::TH + oyl) * C::TW + oxl;
-                    *(f32x4 *)&Ds[po * C::ES + 4 * c4] = relu6_(a * sc + sh);
+                    *(f32x4 *)&Ds[po * C::ES + 4 * c4] = relu6_(a);
                 }
             }
             if (!C::WLDS) fetch_a1(hc0 + C::HC < C::HID ? hc0 + C::HC : 0);   // next chunk (or next tile's chunk 0)
@@ -356,7 +354,6 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
             const int nt = wn + i * C::WN;
             const int n = nt * 16 + 4 * g;
             if (nt >= C::NT_O || n >= C::COUT) continue;
-            const f32x4 sc = psc[i], sh = psh[i];
 #pragma unroll
             for (int j = 0; j < C::AP; ++j) {
                 const int pt = wp + j * C::WP;
@@ -366,7 +363,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                 const int oyl = r / C::TW, oxl = r % C::TW;
                 const int f = f0 + fi, oy = oy0 + oyl, ox = ox0 + oxl;
                 if (f >= B || oy >= C::HOUT || ox >= C::HOUT) continue;
-                f32x4 v = acc[i][j] * sc + sh;
+                f32x4 v = acc[i][j];
                 if (C::RES) v += *(const f32x4 *)&Xs[((fi * C::IH + (oy - iy0)) * C::IW + (ox - ix0)) * C::XS + n];   // x + conv(x)
                 *(f32x4 *)&Y[((size_t)(f * C::HOUT + oy) * C::HOUT + ox) * C::COUT + n] = v;
             }

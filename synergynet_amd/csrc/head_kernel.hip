@@ -45,12 +45,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
     const int f0 = blockIdx.x * NF;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 an[KCH], sn, hn;                         // prefetched: next channel tile's weights + BN
+    f32x4 an[KCH], hn;                             // prefetched: next channel tile's weights + BN shift (scale is folded in)
     auto fetch = [&](int nt) {
         const float *w = Wpk + (size_t)nt * KCH * 256 + lane * 4;
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) an[kc] = *(const f32x4 *)(w + kc * 256);
-        sn = *(const f32x4 *)&scale[nt * 16 + 4 * g];
         hn = *(const f32x4 *)&shift[nt * 16 + 4 * g];
     };
     fetch(wave);
@@ -67,9 +66,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
         f32x4 a[KCH];
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) a[kc] = an[kc];
-        const f32x4 sc = sn, sh = hn;
+        const f32x4 sh = hn;
         if (!(ablate & 1) && nt + 4 < NTL) fetch(nt + 4);
-        f32x4 acc[NF] = {z4, z4, z4, z4};
+        f32x4 acc[NF] = {sh, sh, sh, sh};             // BN shift = accumulator start
         // LDS operand reads run exactly one k-chunk ahead of the MFMAs; the scheduling barriers stop the compiler
         // from hoisting all 80 reads to the top (that spilled the weight fragments to scratch)
         f32x4 bc[NF], bn[NF];
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
         for (int j = 0; j < NF; ++j) {
             f32x4 v;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = r6h(acc[j][t] * sc[t] + sh[t]);
+            for (int t = 0; t < 4; ++t) v[t] = r6h(acc[j][t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = row16_sum(v[t]);
             if (r16 == 0) *(f32x4 *)&Ps[j * N + nt * 16 + 4 * g] = v * 0.0625f;

@@ -11,6 +11,8 @@
 // rows = faces and columns = vertices so that a stored row segment is 32 consecutive vertices of
 // one face (128 B).  The output (638,580 B per face) is the compulsory HBM traffic; the basis is
 // read once per wave and kept in registers while the wave walks its share of the faces.
+#include <cstdlib>
+
 #include "syn_internal.h"
 
 namespace syn {
@@ -20,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kFaceRec = 64;   // floats per face in the prepared record: alpha[52] | M[9] | T[3]
+constexpr int kStageStride = 132;  // floats per row of the store-transpose stage: 4 tiles x 32 vertices + pad (16-byte aligned rows)
 
 // -------------------------------------------------------------------------------------
 // Per-face prologue: de-whiten (param*std+mean, synergy3DMM.py:127), split into pose / alpha
@@ -74,12 +77,20 @@ __global__ __launch_bounds__(64) void recon_prep_kernel(const float *__restrict_
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ rec, const float *__restrict__ basis,
                                                     float *__restrict__ out, int B, int n_vert, int n_tiles,
-                                                    int n_split, int ftiles_per_split, int n_ftiles) {
+                                                    int n_split, int ftiles_per_split, int n_ftiles, int n_units,
+                                                    int ablate) {
     __shared__ __attribute__((aligned(16))) float smt[4][32][12];
+    __shared__ __attribute__((aligned(16))) float stage[96 * kStageStride];   // [face*3 + coord][4 tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int task = blockIdx.x * 4 + wave;
-    const int T = task / n_split, split = task - T * n_split;
-    if (T >= n_tiles) return;
+    // XCD-aware unit order: block b runs on XCD b % 8; give each XCD a contiguous range of (tile group, split) units so
+    // that the row segments of neighbouring tile groups meet in the same L2 and leave it as full lines
+    const int per_xcd = (n_units + 7) / 8;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
+    const int tg = unit / n_split, split = unit - tg * n_split;
+    int T = tg * 4 + wave;                        // the 4 waves of a workgroup own 4 consecutive vertex tiles
+    const bool t_ok = T < n_tiles;
+    T = t_ok ? T : n_tiles - 1;
     const int j = lane & 31, h = lane >> 5;
 
     // resident basis fragments for the three coordinate planes of this vertex tile
@@ -93,12 +104,14 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         for (int t = 0; t < 6; ++t) bw[c][t] = *(const f32x4 *)(bc + t * 256 + lane * 4);
         bt[c] = *(const f32x2 *)(bc + 6 * 256 + lane * 2);
     }
-    const int v = T * 32 + j;
-    const bool v_ok = v < n_vert;
     const int ft0 = split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
     ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
     float(*mt)[12] = smt[wave];
+    const int v_base = tg * 128;                  // first vertex of the workgroup's 128-vertex run
+    // the two co-resident workgroups of a CU start together; delaying every second one by about half an
+    // iteration lets one's MFMA phase run in the shadow of the other's epilogue / store phase
+    if (!(ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(56);
 
     for (int ft = ft0; ft < ft1; ++ft) {
         const int f0 = ft * 32;
@@ -119,6 +132,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+            if (ablate & 1) continue;
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -130,25 +144,41 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
+        if (!(ablate & 8))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int f = f0 + i;
             const f32x4 q0 = *(const f32x4 *)&mt[i][0];
             const f32x4 q1 = *(const f32x4 *)&mt[i][4];
             const f32x4 q2 = *(const f32x4 *)&mt[i][8];
             const float sx = acc[0][r], sy = acc[1][r], sz = acc[2][r];
-            const float ox = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
-            const float oy = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
-            const float oz = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
-            if (v_ok && f < B) {
-                float *o = out + (size_t)f * 3 * n_vert + v;
-                o[0] = ox;
-                o[n_vert] = oy;
-                o[2 * (size_t)n_vert] = oz;
+            float *st = stage + (i * 3) * kStageStride + wave * 32 + j;
+            st[0] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
+            st[kStageStride] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
+            st[2 * kStageStride] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
+        }
+        __syncthreads();
+        // cooperative store: 32 lanes x float4 = one 512-byte run of one (face, coord) row; 2 rows per instruction
+        if (!(ablate & 2)) {
+            const int seg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+            const int vq = v_base + 4 * seg;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int row = k * 8 + rsub;                 // = face_in_tile * 3 + coord
+                const int f = f0 + row / 3, c = row % 3;
+                const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
+                if (f < B) {
+                    float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
+                    if (vq + 3 < n_vert) *(f32x4 *)o = vv;       // 4-byte aligned 16-byte store (rows are n_vert floats)
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (vq + t < n_vert) o[t] = vv[t];
+                    }
+                }
             }
         }
-        __builtin_amdgcn_wave_barrier();   // LDS slice is rewritten by the next face tile
+        __syncthreads();   // stage and the M/T slices are rewritten by the next face tile
     }
 }
 
@@ -157,14 +187,18 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
                         int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec) {
     recon_prep_kernel<<<B, 64, 0, s>>>(param, mean62, std62, roi, transform, rec, B);
     const int n_tiles = nvp / 32;
+    const int n_groups = (n_tiles + 3) / 4;                   // a workgroup = 4 consecutive vertex tiles
     const int n_ftiles = (B + 31) / 32;
-    int n_split = (4096 + n_tiles - 1) / n_tiles;            // aim for >= 4096 waves (4 per SIMD)
+    int n_split = (3072 + n_groups - 1) / n_groups;           // aim for >= 3072 workgroups: 6+ rounds of 512 resident ones,
+                                                              // so the partially filled last round costs < 10 %
     n_split = n_split < 1 ? 1 : n_split;
     n_split = n_split > n_ftiles ? n_ftiles : n_split;
     const int per = (n_ftiles + n_split - 1) / n_split;
     n_split = (n_ftiles + per - 1) / per;
-    const int tasks = n_tiles * n_split;
-    recon_kernel<<<(tasks + 3) / 4, 256, 0, s>>>(rec, basis, out, B, n_vert, n_tiles, n_split, per, n_ftiles);
+    const int n_units = n_groups * n_split;
+    const int grid = ((n_units + 7) / 8) * 8;
+    static const int ablate = getenv("SYN_ABLATE_RECON") ? atoi(getenv("SYN_ABLATE_RECON")) : 0;   // profiling only
+    recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units, ablate);
 }
 
 // -------------------------------------------------------------------------------------

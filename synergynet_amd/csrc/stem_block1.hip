@@ -71,10 +71,10 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) wa[nt][kc][q] = k < 27 ? w0[k * 32 + nt * 16 + r16] : 0.f;
         }
-    const f32x4 sc0 = *(const f32x4 *)&s0[4 * g], sh0 = *(const f32x4 *)&b0[4 * g];
-    const f32x4 sc1 = *(const f32x4 *)&s0[16 + 4 * g], sh1 = *(const f32x4 *)&b0[16 + 4 * g];
+    // BN scales are folded into the filters by the host; accumulators start at the BN shift
+    const f32x4 sh0 = *(const f32x4 *)&b0[4 * g], sh1 = *(const f32x4 *)&b0[16 + 4 * g];
     const f32x4 pa0 = *(const f32x4 *)(wp + lane * 4), pa1 = *(const f32x4 *)(wp + 256 + lane * 4);
-    const f32x4 psc = *(const f32x4 *)&sp[4 * g], psh = *(const f32x4 *)&bp[4 * g];
+    const f32x4 psh = *(const f32x4 *)&bp[4 * g];
 
     // ---- image patch prefetch (registers) ----
     unsigned xr8[U8_IPT];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                     const float v = im[base + (koff[kc][q] >= 0 ? koff[kc][q] : 0)];
                     bv[kc][q] = koff[kc][q] >= 0 ? v : 0.f;
                 }
-            f32x4 e0 = z4, e1 = z4;
+            f32x4 e0 = sh0, e1 = sh1;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                     e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kc][q], bv[kc][q], e1, 0, 0, 0);
                 }
             // lane owns pixel p, channels 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
-            *(f32x4 *)&Es[p * ES + 4 * g] = r6(e0 * sc0 + sh0);
-            *(f32x4 *)&Es[p * ES + 16 + 4 * g] = r6(e1 * sc1 + sh1);
+            *(f32x4 *)&Es[p * ES + 4 * g] = r6(e0);
+            *(f32x4 *)&Es[p * ES + 16 + 4 * g] = r6(e1);
         }
         __syncthreads();
         // ---- depthwise 3x3 s1 on the stem tile: thread = (channel quad, output column, row half) ----
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
             for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&WD[k * 32 + 4 * c4];
             if (fxb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
             if (fxb + 2 >= 60) { w[2] = z4; w[5] = z4; w[8] = z4; }
-            const f32x4 sc = *(const f32x4 *)&WD[288 + 4 * c4], sh = *(const f32x4 *)&WD[320 + 4 * c4];
+            const f32x4 sh = *(const f32x4 *)&WD[320 + 4 * c4];
             f32x4 rb[3][3];
             auto load_row = [&](int ly, f32x4(&dst)[3]) {               // ly = tile row (always inside the 12x12 tile)
                 const bool ok = (unsigned)(fy0 + ly) < 60u;
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                     for (int k = 0; k < 3; ++k) { rb[0][k] = rb[1][k]; rb[1][k] = rb[2][k]; }
                     load_row(oyl + 2, rb[2]);
                 }
-                f32x4 a = rb[0][0] * w[0];
-                a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                f32x4 a = sh;
+                a += rb[0][0] * w[0]; a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
                 a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
                 a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
-                *(f32x4 *)&Ds[(oyl * T + oxl) * ES + 4 * c4] = r6(a * sc + sh);
+                *(f32x4 *)&Ds[(oyl * T + oxl) * ES + 4 * c4] = r6(a);
             }
         }
         __syncthreads();
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
         for (int pt = wave; pt < POUTP / 16; pt += 4) {
             const f32x4 b0v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 4 * g];
             const f32x4 b1v = *(const f32x4 *)&Ds[(pt * 16 + r16) * ES + 16 + 4 * g];
-            f32x4 acc = z4;
+            f32x4 acc = psh;
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa0[s], b0v[s], acc, 0, 0, 0);
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
             const int po = pt * 16 + r16;
             if (po < POUT) {
                 const int oy = oy0 + po / T, ox = ox0 + po % T;
-                *(f32x4 *)&Y[((size_t)(f * 60 + oy) * 60 + ox) * 16 + 4 * g] = acc * psc + psh;
+                *(f32x4 *)&Y[((size_t)(f * 60 + oy) * 60 + ox) * 16 + 4 * g] = acc;
             }
         }
         // the next iteration rewrites `im` (read in the stem stage, two barriers ago) and then barriers before

@@ -105,11 +105,11 @@ struct Net {
             L.dst_w = dst; dst += wp;
             L.dst_scale = dst; dst += cpad;
             L.dst_shift = dst; dst += cpad;
-            L.dst_wpk = 0;
-            if (L.kind == PW && L.feature >= 1 && L.feature <= 18) {
-                L.dst_wpk = dst;
-                dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
-            }
+            // fused kernels: BN scale folded into the weights (accumulators start at the BN shift):
+            // PW in MFMA lane order, stem [27][32] and depthwise [9][C] as plain scaled copies
+            L.dst_wpk = dst;
+            if (L.kind == PW) dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
+            else dst += wp;
             const double pix = (double)L.hout * L.hout;
             const double f2 = L.kind == STEM ? 2.0 * 27 * 32 * pix : L.kind == DW ? 2.0 * 9 * L.cout * pix
                                                                                    : 2.0 * L.cin * (double)L.cout * pix;
@@ -228,7 +228,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused network head: stem conv + features.1 (dw + linear project) in one launch
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            syn::launch_stem_block1(img, img8, w, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
+            syn::launch_stem_block1(img, img8, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                     P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, X, B, s);
             li += 2;
             mark(1);
@@ -241,7 +241,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
         if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_w, P + D.dst_scale, P + D.dst_shift,
+            syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                   P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
             if (prof_feature == L.feature) a.prof = prof;
             if (syn::launch_fused_block(L.feature, a, B, s)) {
@@ -344,7 +344,15 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
             for (int nn = 0; nn < L.cout; ++nn)
                 memcpy(dw + (size_t)nn * L.kpad, w + (size_t)nn * L.cin, sizeof(float) * L.cin);
         }
-        if (L.dst_wpk) {                 // [N][K] -> Wpk[n_tile][k_chunk][lane][4] (MFMA operand lane order)
+        // eval-mode BatchNorm (eps 1e-5): y = x*scale + shift, the form torch's CPU kernel uses
+        std::vector<float> bn_scale(L.cout);
+        for (int c = 0; c < L.cout; ++c) bn_scale[c] = gamma[c] * (1.0f / sqrtf(var[c] + 1e-5f));
+        if (L.kind != PW) {              // scaled copies of the stem / depthwise filters for the fused kernels
+            float *dp = pk.data() + L.dst_wpk;
+            const size_t taps = L.kind == STEM ? 27 : 9;
+            for (size_t t = 0; t < taps; ++t)
+                for (int c = 0; c < L.cout; ++c) dp[t * L.cout + c] = dw[t * L.cout + c] * bn_scale[c];
+        } else {                         // [N][K] -> Wpk[n_tile][k_chunk][lane][4] (MFMA operand lane order), scale folded in
             float *dp = pk.data() + L.dst_wpk;
             const int ntl = round_up(L.cout, 16) / 16, kch = round_up(L.cin, 16) / 16;
             for (int nt = 0; nt < ntl; ++nt)
@@ -353,15 +361,12 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
                         for (int q = 0; q < 4; ++q) {
                             const int nn = nt * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + q;
                             dp[(((size_t)nt * kch + kc) * 64 + lane) * 4 + q] =
-                                (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] : 0.f;
+                                (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] * bn_scale[nn] : 0.f;
                         }
         }
-        // eval-mode BatchNorm (eps 1e-5) as y = x*scale + shift, the form torch's CPU kernel uses
         for (int c = 0; c < L.cout; ++c) {
-            const float inv = 1.0f / sqrtf(var[c] + 1e-5f);
-            const float a = gamma[c] * inv;
-            pk[L.dst_scale + c] = a;
-            pk[L.dst_shift + c] = beta[c] - mean[c] * a;
+            pk[L.dst_scale + c] = bn_scale[c];
+            pk[L.dst_shift + c] = beta[c] - mean[c] * bn_scale[c];
         }
     }
     // heads: ori[12] | shape[40] | exp[10] concatenated in that order (mobilenetv2_backbone.py:184-188)
