@@ -67,6 +67,16 @@ size_t syn_backbone_flat_count(void);
  * per-channel scale/shift and the weights are repacked for the kernels. */
 int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats);
 
+/* BASELINE config 5: the ResNet-50 backbone (reference backbone_nets/resnet_backbone.py:139-254, resnet50 :304-312).
+ * `flat` = conv1.weight, bn1.{weight,bias,running_mean,running_var}, then per block of layer1..layer4:
+ * conv1, bn1, conv2, bn2, conv3, bn3, [downsample.0, downsample.1], then fc_tex, fc_ori, fc_shape, fc_exp
+ * ({weight,bias} each) -- the reference's state_dict order.  After this call syn_backbone_forward*() run ResNet-50
+ * and return the first 62 of its 102 outputs (ori 12 | shape 40 | exp 10; the texture head is dropped), which is the
+ * adapter the reference's own wrapper would need.  pool = the 2048-d pooled feature. */
+size_t syn_resnet50_flat_count(void);
+int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats);
+double syn_resnet50_flops_per_face(void);
+
 /* ParamsPack (utils/params.py:10-35) + the register_buffer block (synergy3DMM.py:95-105).
  * HOST arrays: w_shp [3*n_vert,40], w_exp [3*n_vert,10], u [3*n_vert] (= u_shp+u_exp),
  * param_mean/param_std [>=62] (first 62 used), keypoints [3*n_lmk] flat indices into the

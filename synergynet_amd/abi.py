@@ -32,6 +32,9 @@ _SIGS = {
     'syn_destroy': (C.c_int, [C.c_void_p]),
     'syn_backbone_flat_count': (C.c_size_t, []),
     'syn_load_backbone': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'syn_resnet50_flat_count': (C.c_size_t, []),
+    'syn_load_backbone_resnet50': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'syn_resnet50_flops_per_face': (C.c_double, []),
     'syn_load_basis': (C.c_int, [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int]),
     'syn_constants_bytes': (C.c_size_t, [C.c_void_p]),
     'syn_export_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

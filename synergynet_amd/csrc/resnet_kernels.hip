@@ -1,0 +1,246 @@
+// gfx950 kernels for the ResNet-50 backbone variant (BASELINE config 5; reference
+// backbone_nets/resnet_backbone.py:90-136 Bottleneck, :139-254 ResNet): 7x7/2 stem + BN + ReLU, 3x3/2 max-pool,
+// and one implicit-GEMM convolution kernel (any kh x kw / stride / pad, NHWC fp32) on v_mfma_f32_16x16x4_f32
+// with a fused BN (+ residual) + ReLU epilogue that serves every 1x1 and 3x3 convolution of the bottlenecks.
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// =====================================================================================
+// Implicit-GEMM convolution.   out[m][n] = act( sum_{tap,k} in[pix(m,tap)][k] * W[n][tap*Cin + k] * scale[n] + shift[n] (+ res[m][n]) )
+// Same operand convention as pointwise_kernel (backbone_kernels.hip): MFMA "A" rows = 16 output channels (weights,
+// [Npad][KH*KW*Cin] row-major), MFMA "B" cols = 16 output pixels; a lane owns 4 consecutive channels of one pixel.
+// The K axis is walked tap by tap, 16 input channels at a time; a lane's operand fetch for tap (ky,kx) is one float4
+// of the input pixel (oy*s-p+ky, ox*s-p+kx), or zeros outside the image (zero padding).  Operands go straight from
+// L1/L2 to registers (no LDS): fp32 MFMA is slow enough that 8 x 1 KiB of operand traffic per 64 MFMAs is noise.
+// Requires Cin % 16 == 0 and Cout % 4 == 0 (true for every ResNet-50 convolution after the stem).
+// act: 0 none, 1 ReLU (applied AFTER the residual add: out = relu(bn3(conv3) + identity), resnet_backbone.py:130-134).
+// =====================================================================================
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in, const float *__restrict__ W,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   const float *__restrict__ residual, float *__restrict__ out, int M,
+                                                   int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
+                                                   int act, int n_tiles, int m_tiles) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt_idx = q % n_tiles;
+    const int mt_idx = (q / n_tiles) * 8 + xcd;           // all channel tiles of one pixel tile share an XCD's L2
+    if (mt_idx >= m_tiles) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = (mt_idx * 4 + wave) * (MT * 16);
+    const int n0 = nt_idx * (NT * 16);
+    if (m0 >= M) return;
+    const int KCH = Cin >> 4, K = KH * KW * Cin, steps = KH * KW * KCH;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    int pb[MT], py[MT], px[MT];                           // batch index, top-left input coords of this lane's pixels
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        int m = m0 + j * 16 + r16;
+        m = m < M ? m : M - 1;
+        const int hw = Hout * Hout;
+        pb[j] = m / hw;
+        const int r = m - pb[j] * hw;
+        py[j] = (r / Hout) * stride - pad;
+        px[j] = (r % Hout) * stride - pad;
+    }
+    const float *wp[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wp[i] = W + (size_t)(n0 + i * 16 + r16) * K + 4 * g;     // W rows are padded to Npad
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = z4;
+
+    auto fetch = [&](int s, f32x4(&wf)[NT], f32x4(&af)[MT]) {
+        const int tap = s / KCH, kc = s - tap * KCH;
+        const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf[i] = *(const f32x4 *)(wp[i] + tap * Cin + kc * 16);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int iy = py[j] + ky, ix = px[j] + kx;
+            const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 16 + 4 * g;
+            const f32x4 v = *(const f32x4 *)p;
+            af[j] = ok ? v : z4;
+        }
+    };
+    f32x4 wf[NT], af[MT], wn[NT], an[MT];
+    fetch(0, wf, af);
+    for (int s = 0; s < steps; ++s) {
+        if (s + 1 < steps) fetch(s + 1, wn, an);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][t], af[j][t], acc[j][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf[i] = wn[i];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) af[j] = an[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + i * 16 + 4 * g;
+        if (n >= N) continue;
+        const f32x4 sc = *(const f32x4 *)&scale[n];
+        const f32x4 sh = *(const f32x4 *)&shift[n];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + j * 16 + r16;
+            if (m >= M) continue;
+            f32x4 v = acc[j][i] * sc + sh;
+            if (residual) v += *(const f32x4 *)&residual[(size_t)m * N + n];
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+            }
+            *(f32x4 *)&out[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+template <int MT, int NT>
+static void launch_conv_t(const float *in, const float *W, const float *scale, const float *shift, const float *residual,
+                          float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
+                          int act, hipStream_t s) {
+    const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
+    const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
+    const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    conv_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
+                                             act, n_tiles, m_tiles);
+}
+
+void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
+                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s) {
+    const int M = B * Hout * Hout;
+    const long tiles64 = ((long)M + 255) / 256 * ((N + 63) / 64);      // every ResNet-50 Cout is a multiple of 64
+    if (tiles64 >= 2048) launch_conv_t<4, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+    else if (tiles64 >= 512) launch_conv_t<2, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+    else launch_conv_t<1, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+}
+
+// =====================================================================================
+// ResNet stem: 7x7 stride-2 pad-3 conv 3->64 + BN + ReLU (resnet_backbone.py:168-171), 120 -> 60, NHWC out.
+// Thread = (output pixel, 4 channels); the 147x64 filter (36.8 KB) sits in LDS.  ~1.4 % of the network's FLOPs.
+// U8 variant fuses the HWC->CHW permute and (x-127.5)/128 like the MobileNetV2 stem.
+// =====================================================================================
+template <bool U8>
+__global__ __launch_bounds__(256) void resnet_stem_kernel(const float *__restrict__ img, const uint8_t *__restrict__ img8,
+                                                          const float *__restrict__ w /*[147][64]*/, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, float *__restrict__ out, int npix) {
+    __shared__ __attribute__((aligned(16))) float sw[147 * 64];
+    for (int i = threadIdx.x; i < 147 * 64 / 4; i += 256) *(f32x4 *)&sw[4 * i] = *(const f32x4 *)&w[4 * i];
+    __syncthreads();
+    const int c4 = threadIdx.x & 15;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= npix) return;
+    const int b = p / 3600, r = p - b * 3600;
+    const int oy = r / 60, ox = r - oy * 60;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = 2 * oy - 3 + ky;
+        if (iy < 0 || iy >= kImg) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = 2 * ox - 3 + kx;
+            if (ix < 0 || ix >= kImg) continue;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float v;
+                if (U8) v = ((float)img8[((size_t)(b * kImg + iy) * kImg + ix) * 3 + ci] - 127.5f) * 0.0078125f;
+                else    v = img[((size_t)(b * 3 + ci) * kImg + iy) * kImg + ix];
+                acc += v * *(const f32x4 *)&sw[(ci * 49 + ky * 7 + kx) * 64 + 4 * c4];
+            }
+        }
+    }
+    const f32x4 sc = *(const f32x4 *)&scale[4 * c4], sh = *(const f32x4 *)&shift[4 * c4];
+    f32x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = fmaxf(acc[t] * sc[t] + sh[t], 0.0f);
+    *(f32x4 *)&out[(size_t)p * 64 + 4 * c4] = o;
+}
+
+void launch_resnet_stem(const float *img, const uint8_t *img8, const float *w, const float *scale, const float *shift,
+                        float *out, int B, hipStream_t s) {
+    const int npix = B * 3600;
+    if (img8) resnet_stem_kernel<true><<<(npix + 15) / 16, 256, 0, s>>>(nullptr, img8, w, scale, shift, out, npix);
+    else      resnet_stem_kernel<false><<<(npix + 15) / 16, 256, 0, s>>>(img, nullptr, w, scale, shift, out, npix);
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) (resnet_backbone.py:172), NHWC; padding never wins the max (-inf).
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ in, float *__restrict__ out, long total,
+                                                           int Hin, int Hout, int C4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    long p = idx / C4;
+    const int ox = (int)(p % Hout);
+    p /= Hout;
+    const int oy = (int)(p % Hout), b = (int)(p / Hout);
+    f32x4 m = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+        if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (ix < 0 || ix >= Hin) continue;
+            const f32x4 v = *(const f32x4 *)&in[((size_t)(b * Hin + iy) * Hin + ix) * (C4 * 4) + 4 * c4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) m[t] = fmaxf(m[t], v[t]);
+        }
+    }
+    *(f32x4 *)&out[(size_t)idx * 4] = m;
+}
+
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s) {
+    const long total = (long)B * Hout * Hout * (C / 4);
+    maxpool3x3s2_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, total, Hin, Hout, C / 4);
+}
+
+// adaptive_avg_pool2d -> flatten -> linear heads (resnet_backbone.py:236-246): feat [B,P,C] NHWC, Wfc [n_out][C].
+__global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__restrict__ feat, const float *__restrict__ Wfc,
+                                                              const float *__restrict__ bias, float *__restrict__ param,
+                                                              float *__restrict__ pool, int P, int C, int n_out, int out_stride) {
+    __shared__ __attribute__((aligned(16))) float sp[2048];
+    const int b = blockIdx.x;
+    const float *f = feat + (size_t)b * P * C;
+    const float inv = 1.0f / (float)P;
+    for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < P; ++p) a += *(const f32x4 *)&f[(size_t)p * C + 4 * c4];
+        a *= inv;
+        *(f32x4 *)&sp[4 * c4] = a;
+        if (pool) *(f32x4 *)&pool[(size_t)b * C + 4 * c4] = a;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = wave; o < n_out; o += 4) {
+        const float *wr = Wfc + (size_t)o * C;
+        float a = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 wv = *(const f32x4 *)&wr[c];
+            const f32x4 xv = *(const f32x4 *)&sp[c];
+            a += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0) param[(size_t)b * out_stride + o] = a + bias[o];
+    }
+}
+
+void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
+                            int C, int n_out, int out_stride, hipStream_t s) {
+    pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride);
+}
+
+}  // namespace syn

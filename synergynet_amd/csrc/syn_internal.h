@@ -58,6 +58,16 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
                  const float *Wfc /*[64,1280]*/, const float *bfc, float *param, float *pool /*nullable*/, int B,
                  hipStream_t s);
 
+// ---- ResNet-50 variant (resnet_kernels.hip) ----
+// implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
+void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
+                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s);
+void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
+                        const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s);
+void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
+                            int C, int n_out, int out_stride, hipStream_t s);
+
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):
 //   Bp[tile][coord x|y|z][chunk][lane][4], K = 52: 0..39 shape, 40..49 expression,

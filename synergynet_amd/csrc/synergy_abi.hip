@@ -134,9 +134,72 @@ const Net &net() {
     return n;
 }
 
+// ---- ResNet-50 (BASELINE config 5): reference backbone_nets/resnet_backbone.py:90-136 (Bottleneck, stride on the 3x3),
+// :139-254 (ResNet: 7x7/2 stem, 3x3/2 max-pool, layers [3,4,6,3], heads tex/ori/shape/exp -> cat(ori,shape,exp,tex)).
+struct RConv {
+    int cin, cout, k, stride, pad, hin, hout;
+    size_t src_w, dst_w, dst_scale, dst_shift;
+};
+struct RBlock { int c1, c2, c3, ds; };
+struct ResNet50 {
+    std::vector<RConv> convs;      // convs[0] = stem
+    std::vector<RBlock> blocks;
+    size_t flat_count = 0, packed_count = 0, src_fc = 0, dst_fc_w = 0, dst_fc_b = 0;
+    size_t buf_big = 0, buf_mid = 0;   // per-face floats: block in/out/identity/stem, bottleneck intermediates
+    double flops = 0;
+    ResNet50() {
+        auto add = [&](int cin, int cout, int k, int stride, int hin) {
+            RConv c{};
+            c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = k / 2; c.hin = hin;
+            c.hout = (hin + 2 * c.pad - k) / stride + 1;
+            convs.push_back(c);
+            return (int)convs.size() - 1;
+        };
+        add(3, 64, 7, 2, 120);                       // -> 60, then max-pool -> 30
+        int inpl = 64, h = 30;
+        static const int planes[4] = {64, 128, 256, 512}, nblk[4] = {3, 4, 6, 3};
+        std::vector<std::pair<int, int>> order;      // state_dict order of conv indices is c1,c2,c3,(ds) per block
+        for (int L = 0; L < 4; ++L)
+            for (int i = 0; i < nblk[L]; ++i) {
+                const int stride = (i == 0 && L > 0) ? 2 : 1, w = planes[L], outc = w * 4;
+                RBlock b{};
+                b.c1 = add(inpl, w, 1, 1, h);
+                b.c2 = add(w, w, 3, stride, h);
+                const int ho = convs[b.c2].hout;
+                b.c3 = add(w, outc, 1, 1, ho);
+                b.ds = (i == 0) ? add(inpl, outc, 1, stride, h) : -1;     // stride != 1 or inplanes != planes*4 (:208-212)
+                blocks.push_back(b);
+                inpl = outc; h = ho;
+            }
+        size_t src = 0, dst = 0;
+        for (auto &c : convs) {
+            const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
+            c.src_w = src; src += wn + 4 * (size_t)c.cout;
+            const int npad = round_up(c.cout, 64);
+            c.dst_w = dst; dst += (size_t)npad * c.cin * c.k * c.k;
+            c.dst_scale = dst; dst += npad;
+            c.dst_shift = dst; dst += npad;
+            flops += 2.0 * c.cin * c.k * c.k * (double)c.cout * c.hout * c.hout;
+            const size_t osz = (size_t)c.cout * c.hout * c.hout;
+            buf_big = osz > buf_big ? osz : buf_big;
+        }
+        buf_mid = 128 * 30 * 30;                      // largest conv1 / conv2 output (layer2.0.conv1: 128 x 30 x 30)
+        src_fc = src; src += (size_t)102 * 2048 + 102;
+        flat_count = src;
+        dst_fc_w = dst; dst += (size_t)104 * 2048;
+        dst_fc_b = dst; dst += 104;
+        packed_count = dst;
+        flops += 2.0 * 2048 * 102;
+    }
+};
+const ResNet50 &resnet50() {
+    static const ResNet50 n;
+    return n;
+}
+
 struct ConstHeader {   // first 256 bytes of an exported constants buffer
     uint64_t magic;
-    uint32_t version, has_backbone, has_basis, n_vert, n_lmk, nvp, nlp, pad0;
+    uint32_t version, has_backbone, has_basis, n_vert, n_lmk, nvp, nlp, arch;
     uint64_t backbone_floats, basis_floats, total_bytes;
     uint8_t reserved[256 - 8 - 8 * 4 - 3 * 8];
 };
@@ -147,6 +210,7 @@ constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
 
 struct syn_handle {
     int device = 0;
+    int arch = 0;                  // 0 = mobilenet_v2 (reference default), 1 = resnet50 (BASELINE config 5)
     float *d_backbone = nullptr;   // packed_count floats
     float *d_basis = nullptr;      // dense tiles | landmark tiles | mean[64] | std[64]
     size_t basis_floats = 0;
@@ -164,7 +228,11 @@ const float *basis_lmk(const syn_handle *h) { return h->d_basis + (size_t)h->nvp
 const float *basis_mean(const syn_handle *h) { return h->d_basis + (size_t)(h->nvp + h->nlp) * 3 * syn::kBasisK; }
 const float *basis_std(const syn_handle *h) { return basis_mean(h) + 64; }
 
-size_t ws_floats_per_face() { return 2 * net().max_io + 2 * net().max_hidden + 64; }
+size_t ws_floats_per_face() {
+    const size_t mb = 2 * net().max_io + 2 * net().max_hidden, rn = 4 * resnet50().buf_big + 2 * resnet50().buf_mid;
+    return (mb > rn ? mb : rn) + 64;          // one workspace serves either backbone; the last 64 floats/face = recon records
+}
+size_t backbone_floats(int arch) { return arch == 1 ? resnet50().packed_count : net().packed_count; }
 
 int ensure_ws(syn_handle *h, int B) {
     const size_t need = ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
@@ -289,6 +357,35 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     return SYN_OK;
 }
 
+int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, float *param, float *pool, hipStream_t s,
+                 int n_out = 62) {
+    const ResNet50 &n = resnet50();
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    float *A = h->ws, *X = A + (size_t)B * n.buf_big, *Y = X + (size_t)B * n.buf_big, *D = Y + (size_t)B * n.buf_big;
+    float *T1 = D + (size_t)B * n.buf_big, *T2 = T1 + (size_t)B * n.buf_mid;
+    const float *P = h->d_backbone;
+    auto conv = [&](const RConv &c, const float *in, const float *res, float *out, int act) {
+        syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
+                         c.stride, c.pad, act, s);
+    };
+    const RConv &st = n.convs[0];
+    syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);     // conv1+bn1+relu (:231-233)
+    syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s);                                                    // maxpool (:234)
+    for (const RBlock &b : n.blocks) {                     // Bottleneck.forward (:114-136)
+        conv(n.convs[b.c1], X, nullptr, T1, 1);
+        conv(n.convs[b.c2], T1, nullptr, T2, 1);
+        const float *identity = X;
+        if (b.ds >= 0) { conv(n.convs[b.ds], X, nullptr, D, 0); identity = D; }
+        conv(n.convs[b.c3], T2, identity, Y, 1);           // out = relu(bn3(conv3) + identity)
+        float *t = X; X = Y; Y = t;
+    }
+    // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
+    syn::launch_pool_fc_generic(X, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, 16, 2048, n_out, n_out, s);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,8 +480,60 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
         }
     }
     DeviceGuard g(h->device);
+    if (h->d_backbone && h->arch != 0) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
     if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
+    h->arch = 0;
+    return SYN_OK;
+}
+
+size_t syn_resnet50_flat_count(void) { return resnet50().flat_count; }
+double syn_resnet50_flops_per_face(void) { return resnet50().flops; }
+
+int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats) {
+    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: NULL argument");
+    const ResNet50 &n = resnet50();
+    if (n_floats != n.flat_count)
+        return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: got %zu floats, ResNet-50 has %zu", n_floats, n.flat_count);
+    std::vector<float> pk(n.packed_count, 0.f);
+    for (const RConv &c : n.convs) {
+        const float *w = flat + c.src_w;
+        const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
+        const float *gamma = w + wn, *beta = gamma + c.cout, *mean = beta + c.cout, *var = mean + c.cout;
+        float *dw = pk.data() + c.dst_w;
+        const int taps = c.k * c.k;
+        if (c.cin == 3) {                 // stem: [64][3][7][7] -> [ci*49 + ky*7 + kx][64]
+            for (int co = 0; co < c.cout; ++co)
+                for (int t = 0; t < 3 * taps; ++t) dw[(size_t)t * c.cout + co] = w[(size_t)co * 3 * taps + t];
+        } else {                          // [N][C][ky][kx] -> [N][(ky*KW + kx)*C + c]
+            for (int nn = 0; nn < c.cout; ++nn)
+                for (int ci = 0; ci < c.cin; ++ci)
+                    for (int t = 0; t < taps; ++t)
+                        dw[(size_t)nn * taps * c.cin + (size_t)t * c.cin + ci] = w[((size_t)nn * c.cin + ci) * taps + t];
+        }
+        for (int ch = 0; ch < c.cout; ++ch) {
+            const float a = gamma[ch] * (1.0f / sqrtf(var[ch] + 1e-5f));
+            pk[c.dst_scale + ch] = a;
+            pk[c.dst_shift + ch] = beta[ch] - mean[ch] * a;
+        }
+    }
+    {   // heads: flat order fc_tex, fc_ori, fc_shape, fc_exp (module order, resnet_backbone.py:185-188);
+        // packed rows in the cat order ori | shape | exp | tex (:246)
+        const float *src = flat + n.src_fc;
+        static const int hn[4] = {40, 12, 40, 10};        // tex, ori, shape, exp
+        static const int row0[4] = {62, 0, 12, 52};
+        for (int k = 0; k < 4; ++k) {
+            memcpy(pk.data() + n.dst_fc_w + (size_t)row0[k] * 2048, src, sizeof(float) * hn[k] * 2048);
+            src += (size_t)hn[k] * 2048;
+            memcpy(pk.data() + n.dst_fc_b + row0[k], src, sizeof(float) * hn[k]);
+            src += hn[k];
+        }
+    }
+    DeviceGuard g(h->device);
+    if (h->d_backbone) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
+    h->arch = 1;
     return SYN_OK;
 }
 
@@ -415,7 +564,7 @@ int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const 
 
 size_t syn_constants_bytes(syn_handle *h) {
     if (!h) return 0;
-    return sizeof(ConstHeader) + ((h->d_backbone ? net().packed_count : 0) + (h->d_basis ? h->basis_floats : 0)) * sizeof(float);
+    return sizeof(ConstHeader) + ((h->d_backbone ? backbone_floats(h->arch) : 0) + (h->d_basis ? h->basis_floats : 0)) * sizeof(float);
 }
 
 int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream) {
@@ -426,7 +575,8 @@ int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *strea
     hd.magic = kMagic; hd.version = 1;
     hd.has_backbone = h->d_backbone ? 1 : 0; hd.has_basis = h->d_basis ? 1 : 0;
     hd.n_vert = h->n_vert; hd.n_lmk = h->n_lmk; hd.nvp = h->nvp; hd.nlp = h->nlp;
-    hd.backbone_floats = hd.has_backbone ? net().packed_count : 0;
+    hd.arch = h->arch;
+    hd.backbone_floats = hd.has_backbone ? backbone_floats(h->arch) : 0;
     hd.basis_floats = hd.has_basis ? h->basis_floats : 0;
     hd.total_bytes = need;
     DeviceGuard g(h->device);
@@ -454,12 +604,14 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
     if (hd.magic != kMagic || hd.version != 1) return fail(SYN_ERR_INVALID, "syn_import_constants: bad magic/version");
     if (hd.total_bytes > bytes) return fail(SYN_ERR_INVALID, "syn_import_constants: header says %llu bytes, buffer has %zu",
                                             (unsigned long long)hd.total_bytes, bytes);
-    if (hd.has_backbone && hd.backbone_floats != net().packed_count)
+    if (hd.has_backbone && (hd.arch > 1 || hd.backbone_floats != backbone_floats((int)hd.arch)))
         return fail(SYN_ERR_INVALID, "syn_import_constants: backbone size mismatch");
     if (hd.has_basis && hd.basis_floats != basis_float_count(hd.nvp, hd.nlp))
         return fail(SYN_ERR_INVALID, "syn_import_constants: basis size mismatch");
     const char *d = (const char *)dev_src + sizeof hd;
     if (hd.has_backbone) {
+        if (h->d_backbone && h->arch != (int)hd.arch) { HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
+        h->arch = (int)hd.arch;
         if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, hd.backbone_floats * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(h->d_backbone, d, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
         d += hd.backbone_floats * sizeof(float);
@@ -483,6 +635,7 @@ int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, f
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_backbone_forward: B=%d", B);
     if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward: backbone weights not loaded");
     DeviceGuard g(h->device);
+    if (h->arch == 1) return run_resnet50(h, img, nullptr, B, param, pool, (hipStream_t)stream);
     return run_backbone(h, img, nullptr, B, param, pool, (hipStream_t)stream);
 }
 
@@ -491,6 +644,7 @@ int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img, int B, float *par
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_backbone_forward_u8: B=%d", B);
     if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_forward_u8: backbone weights not loaded");
     DeviceGuard g(h->device);
+    if (h->arch == 1) return run_resnet50(h, nullptr, img, B, param, pool, (hipStream_t)stream);
     return run_backbone(h, nullptr, img, B, param, pool, (hipStream_t)stream);
 }
 
@@ -583,7 +737,7 @@ int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int
     DeviceGuard g(h->device);
     int rc = ensure_ws(h, B);
     if (rc) return rc;
-    float *rec = h->ws + (size_t)B * (2 * net().max_io + 2 * net().max_hidden);
+    float *rec = h->ws + (size_t)B * (ws_floats_per_face() - 64);
     if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
     else       syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
     HIP_TRY(hipGetLastError());

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import abi
 from .params import ParamsPack
-from .synth import HEADS, mbv2_layers
+from .synth import HEADS, RESNET_HEADS, mbv2_layers, resnet50_convs
 
 BACKBONE_PREFIX = 'I2P.backbone.'
 _BASIS_BUFFERS = ('param_mean', 'param_std', 'w_shp', 'u', 'w_exp', 'u_base', 'w_shp_base', 'w_exp_base')
@@ -61,10 +61,23 @@ def backbone_keys():
     return out
 
 
-def flatten_backbone(sd: dict, prefix: str = '') -> np.ndarray:
-    """state_dict -> the flat fp32 host array of syn_load_backbone (include/synergy_hip.h)."""
+def resnet50_keys():
+    """(state_dict key, shape) of every ResNet-50 tensor, in the order syn_load_backbone_resnet50 expects."""
+    out = []
+    for c in resnet50_convs():
+        out.append((c['key'] + '.weight', (c['cout'], c['cin'], c['k'], c['k'])))
+        for s in ('weight', 'bias', 'running_mean', 'running_var'):
+            out.append((c['bn'] + '.' + s, (c['cout'],)))
+    for name, n in RESNET_HEADS:
+        out.append((name + '.weight', (n, 2048)))
+        out.append((name + '.bias', (n,)))
+    return out
+
+
+def flatten_backbone(sd: dict, prefix: str = '', arch: str = 'mobilenet_v2') -> np.ndarray:
+    """state_dict -> the flat fp32 host array of syn_load_backbone[_resnet50] (include/synergy_hip.h)."""
     parts = []
-    for k, shape in backbone_keys():
+    for k, shape in (resnet50_keys() if arch == 'resnet50' else backbone_keys()):
         v = sd[prefix + k]
         v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
         if tuple(v.shape) != tuple(shape):
@@ -91,8 +104,14 @@ class SynergyNet(nn.Module):
     """Drop-in for reference synergy3DMM.SynergyNet (inference only), backed by HIP kernels."""
 
     def __init__(self, device=None, checkpoint_fp=None, data_dir=None, pack=None, backbone_state=None,
-                 face_detector=None, load_constants=True):
+                 face_detector=None, load_constants=True, arch='mobilenet_v2'):
+        """arch: 'mobilenet_v2' (the reference's hard-coded choice, synergy3DMM.py:76) or 'resnet50' (BASELINE
+        config 5; the reference's own wrapper cannot run it -- SURVEY F6 -- so the first 62 of ResNet's 102
+        outputs are taken, the adapter a maintainer would add)."""
         super().__init__()
+        if arch not in ('mobilenet_v2', 'resnet50'):
+            raise RuntimeError("Please choose [mobilenet_v2, resnet50]")
+        self.arch = arch
         if not torch.cuda.is_available():
             raise RuntimeError('synergynet_amd.SynergyNet needs a ROCm GPU (MI355X); there is no CPU path')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -130,7 +149,7 @@ class SynergyNet(nn.Module):
         self._upload_basis()
 
         # --- backbone weights: key tree identical to the reference's I2P.backbone.* ---
-        for k, shape in backbone_keys():
+        for k, shape in (resnet50_keys() if arch == 'resnet50' else backbone_keys()):
             _register_by_key(self, BACKBONE_PREFIX + k, torch.zeros(shape, dtype=torch.float32))
         if backbone_state is not None:
             sd = {BACKBONE_PREFIX + k: torch.as_tensor(np.asarray(v)) for k, v in backbone_state.items()
@@ -177,9 +196,13 @@ class SynergyNet(nn.Module):
         self._have_basis = True
 
     def _upload_backbone(self):
-        flat = flatten_backbone(self.state_dict(), BACKBONE_PREFIX)
-        assert flat.size == self._lib.syn_backbone_flat_count()
-        abi.check(self._lib.syn_load_backbone(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
+        flat = flatten_backbone(self.state_dict(), BACKBONE_PREFIX, self.arch)
+        if self.arch == 'resnet50':
+            assert flat.size == self._lib.syn_resnet50_flat_count()
+            abi.check(self._lib.syn_load_backbone_resnet50(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
+        else:
+            assert flat.size == self._lib.syn_backbone_flat_count()
+            abi.check(self._lib.syn_load_backbone(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._have_backbone = True
 
     def load_weights(self, path):
@@ -219,6 +242,10 @@ class SynergyNet(nn.Module):
         self._n_vert, self._n_lmk = int(hdr[20:24].view(np.uint32)[0]), int(hdr[24:28].view(np.uint32)[0])
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def pool_dim(self):
+        return 2048 if self.arch == 'resnet50' else 1280
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -237,7 +264,7 @@ class SynergyNet(nn.Module):
         B = x.shape[0]
         with torch.cuda.device(self.device):
             param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
-            pool = torch.empty((B, 1280), dtype=torch.float32, device=self.device) if return_pool else None
+            pool = torch.empty((B, self.pool_dim), dtype=torch.float32, device=self.device) if return_pool else None
             abi.check(self._lib.syn_backbone_forward(self._h, x.data_ptr(), B, param.data_ptr(),
                                                      pool.data_ptr() if return_pool else None, self._stream()))
         if was_cpu:
@@ -256,7 +283,7 @@ class SynergyNet(nn.Module):
         B = x.shape[0]
         with torch.cuda.device(self.device):
             param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
-            pool = torch.empty((B, 1280), dtype=torch.float32, device=self.device) if return_pool else None
+            pool = torch.empty((B, self.pool_dim), dtype=torch.float32, device=self.device) if return_pool else None
             abi.check(self._lib.syn_backbone_forward_u8(self._h, x.data_ptr(), B, param.data_ptr(),
                                                         pool.data_ptr() if return_pool else None, self._stream()))
         return (param, pool) if return_pool else param

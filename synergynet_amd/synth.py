@@ -93,6 +93,49 @@ def make_backbone_state(seed: int = 1234) -> dict:
     return sd
 
 
+def resnet50_convs():
+    """Ordered conv table of the reference ResNet-50 (backbone_nets/resnet_backbone.py:139-254, Bottleneck :90-136):
+    dicts with key (conv weight prefix), bn, cin, cout, k, stride, relu, plus block bookkeeping."""
+    convs = [dict(key='conv1', bn='bn1', cin=3, cout=64, k=7, stride=2, relu=True, role='stem')]
+    inpl = 64
+    for L, (planes, nblk) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), start=1):
+        for i in range(nblk):
+            stride = 2 if (i == 0 and L > 1) else 1
+            pre = f'layer{L}.{i}'
+            convs.append(dict(key=pre + '.conv1', bn=pre + '.bn1', cin=inpl, cout=planes, k=1, stride=1, relu=True, role='c1', block=pre))
+            convs.append(dict(key=pre + '.conv2', bn=pre + '.bn2', cin=planes, cout=planes, k=3, stride=stride, relu=True, role='c2', block=pre))
+            convs.append(dict(key=pre + '.conv3', bn=pre + '.bn3', cin=planes, cout=planes * 4, k=1, stride=1, relu=False, role='c3', block=pre))
+            if i == 0:
+                convs.append(dict(key=pre + '.downsample.0', bn=pre + '.downsample.1', cin=inpl, cout=planes * 4, k=1,
+                                  stride=stride, relu=False, role='ds', block=pre))
+            inpl = planes * 4
+    return convs
+
+
+RESNET_HEADS = [('fc_tex', 40), ('fc_ori', 12), ('fc_shape', 40), ('fc_exp', 10)]      # module order (:185-188)
+
+
+def make_resnet50_state(seed: int = 2468) -> dict:
+    """ResNet-50 state_dict (numpy fp32, reference key names).  Variance-preserving conv init, randomised BN
+    statistics; the last BN of every residual branch gets a small gamma so 16 stacked blocks stay bounded."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for c in resnet50_convs():
+        fan_in = c['cin'] * c['k'] * c['k']
+        gain = 2.0 if c['relu'] else 1.0
+        sd[c['key'] + '.weight'] = (rng.standard_normal((c['cout'], c['cin'], c['k'], c['k'])) * np.sqrt(gain / fan_in)).astype(np.float32)
+        lo, hi = (0.2, 0.4) if c['role'] == 'c3' else (0.8, 1.2)
+        sd[c['bn'] + '.weight'] = rng.uniform(lo, hi, c['cout']).astype(np.float32)
+        sd[c['bn'] + '.bias'] = (rng.standard_normal(c['cout']) * 0.1).astype(np.float32)
+        sd[c['bn'] + '.running_mean'] = (rng.standard_normal(c['cout']) * 0.1).astype(np.float32)
+        sd[c['bn'] + '.running_var'] = rng.uniform(0.8, 1.25, c['cout']).astype(np.float32)
+        sd[c['bn'] + '.num_batches_tracked'] = np.array(1000, dtype=np.int64)
+    for name, n in RESNET_HEADS:
+        sd[name + '.weight'] = (rng.standard_normal((n, 2048)) * 0.02).astype(np.float32)
+        sd[name + '.bias'] = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    return sd
+
+
 def _rotation(yaw, pitch, roll):
     cy, sy = np.cos(yaw), np.sin(yaw)
     cp, sp = np.cos(pitch), np.sin(pitch)

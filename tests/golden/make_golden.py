@@ -93,5 +93,28 @@ def main():
     print('max |d param| for a corner perturbation:', d)
 
 
+def main_resnet50():
+    """BASELINE config 5: outputs of the reference's own resnet50() module (backbone_nets/resnet_backbone.py:304-312,
+    importable as-is: torch-only) on seeded crops -> tests/golden/resnet50_outputs.npz."""
+    import importlib
+    sd = synth.make_resnet50_state(2468)
+    sys.path.insert(0, ref_loader.REF_ROOT)
+    try:
+        m = importlib.import_module('backbone_nets.resnet_backbone')
+    finally:
+        sys.path.remove(ref_loader.REF_ROOT)
+    net = m.resnet50().eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    x = synth.normalize_crops(synth.make_crops(2, seed=31))
+    feats = {}
+    net.avgpool.register_forward_hook(lambda mod, i, o: feats.__setitem__('pool', o.flatten(1)))
+    with torch.no_grad():
+        out = net(torch.from_numpy(x)).numpy()
+    fp = os.path.join(HERE, 'resnet50_outputs.npz')
+    np.savez_compressed(fp, seed=np.array(2468), crops_seed=np.array(31), out102=out, pool=feats['pool'].numpy())
+    print('wrote', fp, os.path.getsize(fp), 'bytes; out[0,:6] =', out[0, :6])
+
+
 if __name__ == '__main__':
     main()
+    main_resnet50()

@@ -222,3 +222,36 @@ def test_get_all_outputs_shapes_and_consistency(model):
     assert model.get_all_outputs(img, rects=[]) == ([], [], [])
     with pytest.raises(RuntimeError, match='face detector'):
         model.get_all_outputs(img)
+
+
+@pytest.fixture(scope='module')
+def resnet_model(pack):
+    import torch
+    assert torch.cuda.is_available()
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    return SynergyNet(device='cuda:0', pack=pack, backbone_state=synth.make_resnet50_state(2468), arch='resnet50')
+
+
+def test_resnet50_matches_reference_golden_and_oracle(resnet_model):
+    """BASELINE config 5 (ResNet-50 backbone + the [:, :62] adapter): HIP path vs the reference module's output
+    (tests/golden/resnet50_outputs.npz) and, on ragged batches, vs the oracle."""
+    import torch
+    from oracle import resnet_torch
+    from synergynet_amd import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resnet50_outputs.npz'))
+    x = synth.normalize_crops(synth.make_crops(2, seed=int(g['crops_seed'])))
+    param, pool = resnet_model.forward_test(torch.from_numpy(x).cuda(), return_pool=True)
+    assert tuple(param.shape) == (2, 62) and tuple(pool.shape) == (2, 2048)
+    assert rel_max(param.cpu().numpy(), g['out102'][:, :62]) < TOL
+    assert rel_max(pool.cpu().numpy(), g['pool']) < TOL
+    sd = synth.make_resnet50_state(2468)
+    for B in (1, 7, 33):
+        crops = synth.make_crops(B, seed=400 + B)
+        want, want_pool = resnet_torch.resnet50_forward(sd, synth.normalize_crops(crops))
+        got, got_pool = resnet_model.forward_crops_u8(crops, return_pool=True)
+        assert rel_max(got.cpu().numpy(), want.numpy()[:, :62]) < TOL
+        assert rel_max(got_pool.cpu().numpy(), want_pool.numpy()) < TOL
+    # the geometry stage is backbone-independent: landmarks + mesh come out of the same kernels
+    mesh = resnet_model.reconstruct(got, dense=True)
+    assert tuple(mesh.shape) == (33, 3, 53215) and torch.isfinite(mesh).all()

@@ -4,6 +4,8 @@ tests/golden/reference_outputs.npz was produced by tests/golden/make_golden.py b
 running /root/reference's own synergy3DMM.SynergyNet / utils.inference functions.
 The tolerance here (1e-5) is 10x tighter than the 1e-4 the HIP path is held to.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -72,3 +74,15 @@ def test_oracle_against_live_reference_fresh_inputs(pack, backbone_sd):
     with torch.no_grad():
         want = model.reconstruct_vertex_62(torch.from_numpy(params), dense=True).numpy()
     assert rel_max(recon_numpy.reconstruct_vertex_62(b, params, dense=True), want) < TOL
+
+
+def test_resnet50_oracle_matches_reference():
+    """BASELINE config 5: oracle/resnet_torch.py vs the reference's own resnet50() module output."""
+    from oracle import resnet_torch
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'resnet50_outputs.npz'))
+    sd = synth.make_resnet50_state(int(g['seed']))
+    x = synth.normalize_crops(synth.make_crops(2, seed=int(g['crops_seed'])))
+    out, pool = resnet_torch.resnet50_forward(sd, x)
+    assert out.shape == (2, 102) and pool.shape == (2, 2048)
+    assert rel_max(out.numpy(), g['out102']) < TOL
+    assert rel_max(pool.numpy(), g['pool']) < TOL
