@@ -78,6 +78,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=1024, help='faces per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--arch', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet50'],
+                    help='resnet50 = BASELINE configs[4] (use --batch 512); the default bench line is mobilenet_v2')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -97,10 +99,11 @@ def main():
     from synergynet_amd.dist import broadcast_constants
     pack = sd = None
     if rank == 0:
-        pack, sd = synth.make_3dmm(), synth.make_backbone_state()
-        model = SynergyNet(device=dev, pack=pack, backbone_state=sd)
+        pack = synth.make_3dmm()
+        sd = synth.make_resnet50_state() if args.arch == 'resnet50' else synth.make_backbone_state()
+        model = SynergyNet(device=dev, pack=pack, backbone_state=sd, arch=args.arch)
     else:
-        model = SynergyNet(device=dev, load_constants=False)
+        model = SynergyNet(device=dev, load_constants=False, arch=args.arch)
     if world > 1:
         broadcast_constants(model, src=0)          # one RCCL broadcast over xGMI, then no collectives
 
@@ -139,7 +142,22 @@ def main():
     # --- roofline of the dominant kernel family, measured live with HIP events on the launch stream:
     # syn_backbone_profile records an event after every launch of one forward (C ABI, include/synergy_hip.h)
     roof = None
-    if rank == 0:
+    if rank == 0 and args.arch == 'resnet50':
+        from synergynet_amd import abi
+        fl = abi.lib().syn_resnet50_flops_per_face() * B
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            model.forward_crops_u8(crops)
+        e1.record()
+        torch.cuda.synchronize()
+        bb_ms = e0.elapsed_time(e1) / 5
+        roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (53 syn::conv_kernel implicit-GEMM launches + stem + max-pool + heads); fp32 v_mfma_f32_16x16x4_f32',
+                    achieved=round(fl / (bb_ms * 1e-3) / 1e12, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(fl / (bb_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    flops_per_launch=fl, ms_per_launch=round(bb_ms, 4))
+    elif rank == 0:
         from synergynet_amd import abi
         lib = abi.lib()
         nmax = 64
@@ -181,12 +199,13 @@ def main():
         out = dict(metric='faces/sec (120x120, 68-lmk + 53215-vert)', value=round(faces / el, 1), unit='faces/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 4),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload='MobileNetV2 120x120 uint8 crops -> 62 params -> 68 landmarks + 53215-vertex mesh '
-                                        '+ pose, ROI affine, all on device (BASELINE configs[2]/[3])',
+                   config=dict(workload=('ResNet-50 (BASELINE configs[4])' if args.arch == 'resnet50' else 'MobileNetV2') +
+                                        ' 120x120 uint8 crops -> 62 params -> 68 landmarks + 53215-vertex mesh '
+                                        '+ pose, ROI affine, all on device' + ('' if args.arch == 'resnet50' else ' (BASELINE configs[2]/[3])'),
                                faces_per_gpu_per_step=B, global_batch=B * world, parallelism=f'face-shard x{world}',
                                collectives='one RCCL broadcast of packed constants at init, none in the timed region'),
                    roofline=roof)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.arch == 'mobilenet_v2':
             out['cpu_baseline'] = cpu_baseline(sd, pack)
         print(json.dumps(out), flush=True)
     if dist is not None:
