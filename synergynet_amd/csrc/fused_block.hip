@@ -234,23 +234,34 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                 f32x4 ea[C::EPB];
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) ea[q] = sh;
-#pragma unroll
-                for (int kc = 0; kc < C::KCH; ++kc) {
-                    f32x4 a;
-                    if (C::WLDS) a = *(const f32x4 *)&Wle[((hc0 / 16 + nt) * C::KCH + kc) * 256 + lane * 4];
-                    else a = a1[jj][kc];
-                    f32x4 b[C::EPB];
+                // operand reads from LDS run exactly one k-chunk ahead of the MFMAs that use them (the scheduling
+                // barrier keeps the compiler from re-serialising read -> wait -> MFMA per chunk)
+                auto ldb = [&](int kc, f32x4(&b)[C::EPB]) {
 #pragma unroll
                     for (int q = 0; q < C::EPB; ++q) {
                         const int pt = pg * C::EPB + q;
                         b[q] = *(const f32x4 *)&Xs[((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XS + kc * 16 + 4 * g];
                     }
+                };
+                auto lda = [&](int kc) -> f32x4 {
+                    if (C::WLDS) return *(const f32x4 *)&Wle[((hc0 / 16 + nt) * C::KCH + kc) * 256 + lane * 4];
+                    return a1[jj][kc];
+                };
+                f32x4 bc[C::EPB], bn[C::EPB], ac = lda(0), an = ac;
+                ldb(0, bc);
+#pragma unroll
+                for (int kc = 0; kc < C::KCH; ++kc) {
+                    if (kc + 1 < C::KCH) { ldb(kc + 1, bn); an = lda(kc + 1); }
                     // unconditional: a ragged last group multiplies a clamped (duplicate) pixel tile, never stored
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int q = 0; q < C::EPB; ++q)
-                            ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[q][s], ea[q], 0, 0, 0);
+                            ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[s], bc[q][s], ea[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < C::EPB; ++q) bc[q] = bn[q];
+                    ac = an;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) {
@@ -320,28 +331,39 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
             __syncthreads();
             SYN_LAP(4);
             // ---- stage 3: project 1x1, K = this hidden chunk, accumulators stay in registers ----
+            {
+                auto ldab = [&](int kc, f32x4(&a)[C::AN], f32x4(&b)[C::AP]) {
 #pragma unroll
-            for (int kc = 0; kc < C::KC3; ++kc) {
-                f32x4 a[C::AN], b[C::AP];
+                    for (int i = 0; i < C::AN; ++i) {
+                        const int nt = wn + i * C::WN;
+                        if (C::WLDS) a[i] = *(const f32x4 *)&Wlp[(((nt < C::NT_O ? nt : 0) * (C::HID / 16)) + hc0 / 16 + kc) * 256 + lane * 4];
+                        else a[i] = a3[i][kc];
+                    }
 #pragma unroll
-                for (int i = 0; i < C::AN; ++i) {
-                    const int nt = wn + i * C::WN;
-                    if (C::WLDS) a[i] = *(const f32x4 *)&Wlp[(((nt < C::NT_O ? nt : 0) * (C::HID / 16)) + hc0 / 16 + kc) * 256 + lane * 4];
-                    else a[i] = a3[i][kc];
+                    for (int j = 0; j < C::AP; ++j) {
+                        const int pt = wp + j * C::WP;
+                        b[j] = *(const f32x4 *)&Ds[((pt < C::PT_O ? pt : 0) * 16 + r16) * C::ES + kc * 16 + 4 * g];
+                    }
+                };
+                f32x4 ac[C::AN], bc[C::AP], an[C::AN], bn[C::AP];
+                ldab(0, ac, bc);
+#pragma unroll
+                for (int kc = 0; kc < C::KC3; ++kc) {
+                    if (kc + 1 < C::KC3) ldab(kc + 1, an, bn);
+                    // unconditional straight-line MFMAs: tiles past NT_O / PT_O use clamped operands and are never stored
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+                            for (int j = 0; j < C::AP; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[i][s], bc[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < C::AN; ++i) ac[i] = an[i];
+#pragma unroll
+                    for (int j = 0; j < C::AP; ++j) bc[j] = bn[j];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int j = 0; j < C::AP; ++j) {
-                    const int pt = wp + j * C::WP;
-                    b[j] = *(const f32x4 *)&Ds[((pt < C::PT_O ? pt : 0) * 16 + r16) * C::ES + kc * 16 + 4 * g];
-                }
-                // unconditional straight-line MFMAs: tiles past NT_O / PT_O use clamped operands and are never stored
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < C::AN; ++i)
-#pragma unroll
-                        for (int j = 0; j < C::AP; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
             }
             SYN_LAP(5);
             // no barrier here: the next stage 1 only writes Es / Wds (their readers finished before the barrier
@@ -393,7 +415,7 @@ static void launch_cfg(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_pe
 }
 
 //                      CIN  HID COUT HIN S  RES    TH  TW NF  HC NW EPB WN WP  WLDS
-using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false,  6,  6, 1, 96, 8, 3, 2, 4, true>;    // features.2   60 -> 30
+using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false, 10, 10, 1, 32, 8, 7, 2, 4, true>;    // features.2   60 -> 30
 using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 8, 2, 2, 4, true>;    // features.3   30
 using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 144, 8, 2, 2, 4, true>;   // features.4   30 -> 15
 using Cfg5 = BlockCfg<  32, 192,  32, 15, 1, true,  15, 15, 1, 32, 8, 4, 2, 4, false>;   // features.5,6 15

@@ -142,4 +142,153 @@ void launch_head(const float *X, const float *Wpk, const float *scale, const flo
     head_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wpk, scale, shift, Wfc, bfc, param, pool, B, ablate);
 }
 
+
+// =====================================================================================
+// Same tail, but the 320 -> 1280 GEMM runs on the bf16 matrix pipe with fp32-equivalent accuracy:
+// every fp32 operand x is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 significant bits, by
+// truncation: h = x & 0xffff0000, m = (x - h) & ..., l = (x - h - m) & ...), and the product is rebuilt from the six
+// partial products that reach 2^-16 relative weight:  h*h + (h*m + m*h) + (m*m + h*l + l*h)   (dropped: m*l, l*m,
+// l*l <= 2^-24).  bf16 x bf16 products are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the
+// result carries fp32-class rounding error while issuing 6 MFMAs of K=32 (~17 cycles each) instead of 8 fp32 MFMAs
+// of K=4 (32 cycles each) per 16x16x32 block -- and, unlike the fp32-input MFMA, the bf16 MFMA does not share the
+// vector pipe with VALU work.  Weights are split and lane-ordered offline; activations are split once when the
+// input tile is staged into LDS.
+// =====================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int KC32 = K / 32;            // 10 k-chunks of 32
+constexpr int XSD = K / 2 + 4;          // dwords per pixel row of one bf16 plane (164: 16-byte aligned, 4 mod 64 banks)
+constexpr int PLANE = PX * XSD;         // dwords per plane
+// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
+                                                          const unsigned *__restrict__ Wb3 /*[80][10][3][64][4] dwords*/,
+                                                          const float *__restrict__ shift, const float *__restrict__ Wfc,
+                                                          const float *__restrict__ bfc, float *__restrict__ param,
+                                                          float *__restrict__ pool, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned Xb[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) float Ps[NF * N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int f0 = blockIdx.x * NF;
+
+    u32x4 ring[5][3];                                   // weight pieces of 5 k-chunks in flight
+    auto lda = [&](int nt, int kc, u32x4(&dst)[3]) {
+        const unsigned *w = Wb3 + ((size_t)(nt * KC32 + kc) * 3) * 256 + lane * 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = *(const u32x4 *)(w + p * 256);
+    };
+#pragma unroll
+    for (int kc = 0; kc < 5; ++kc) lda(wave, kc, ring[kc]);
+    // input tile -> three bf16 planes in LDS (the split happens exactly once per element)
+    for (int it = tid; it < PX * (K / 4); it += 256) {
+        const int c4 = it % (K / 4), p = it / (K / 4);
+        const int f = f0 + (p >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f < B) v = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2(v[0], v[1], h0, m0, l0);
+        split2(v[2], v[3], h1, m1, l1);
+        *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){h0, h1};
+        *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){m0, m1};
+        *(u32x2 *)&Xb[2 * PLANE + p * XSD + 2 * c4] = (u32x2){l0, l1};
+    }
+    __syncthreads();
+
+    for (int nt = wave; nt < NTL; nt += 4) {
+        const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g];
+        f32x4 acc[NF] = {sh, sh, sh, sh};
+        u32x4 bc[NF][3], bn[NF][3];
+        auto ldb = [&](int kc, u32x4(&b)[NF][3]) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANE + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
+        };
+        ldb(0, bc);
+#pragma unroll
+        for (int kc = 0; kc < KC32; ++kc) {
+            if (kc + 1 < KC32) ldb(kc + 1, bn);
+            const u32x4 ah = ring[kc % 5][0], am = ring[kc % 5][1], al = ring[kc % 5][2];
+            // six partial products, smallest first; 4 independent accumulators interleaved
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(al, bc[j][0], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][2], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(am, bc[j][1], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(am, bc[j][0], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][1], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][0], acc[j]);
+            // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
+            if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
+            else if (nt + 4 < NTL) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = row16_sum(r6h(acc[j][t]));
+            if (r16 == 0) *(f32x4 *)&Ps[j * N + nt * 16 + 4 * g] = v * 0.0625f;
+        }
+    }
+    __syncthreads();
+    if (pool) {
+        for (int it = tid; it < NF * (N / 4); it += 256) {
+            const int j = it / (N / 4), c4 = it % (N / 4);
+            if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
+        }
+    }
+    f32x4 xv[NF][N / 256];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
+#pragma unroll 2
+    for (int o = wave; o < kParam; o += 4) {
+        const float *wr = Wfc + (size_t)o * N;
+        f32x4 wv[N / 256];
+#pragma unroll
+        for (int i = 0; i < N / 256; ++i) wv[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
+        const float bo = bfc[o];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i)
+                a += wv[i][0] * xv[j][i][0] + wv[i][1] * xv[j][i][1] + wv[i][2] * xv[j][i][2] + wv[i][3] * xv[j][i][3];
+            const float tot = wave64_sum(a);
+            if (lane == 0 && f0 + j < B) param[(size_t)(f0 + j) * kParam + o] = tot + bo;
+        }
+    }
+}
+
+void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
+                        float *param, float *pool, int B, hipStream_t s) {
+    head_bf16x3_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
+}
 }  // namespace syn

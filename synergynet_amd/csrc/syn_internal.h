@@ -58,6 +58,10 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
                  const float *Wfc /*[64,1280]*/, const float *bfc, float *param, float *pool /*nullable*/, int B,
                  hipStream_t s);
 
+// same tail with the GEMM on the bf16 matrix pipe via an exact 3-way bf16 split of fp32 operands (head_kernel.hip)
+void launch_head_bf16x3(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
+                        const float *bfc, float *param, float *pool, int B, hipStream_t s);
+
 // ---- ResNet-50 variant (resnet_kernels.hip) ----
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,

@@ -65,7 +65,7 @@ struct Net {
     size_t flat_count = 0;      // floats in the host flat input (incl. heads)
     size_t src_fc = 0;
     size_t packed_count = 0;    // floats in the packed device blob
-    size_t dst_fc_w = 0, dst_fc_b = 0;
+    size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_b3 = 0;   // dst_head_b3: features.18 weights as 3 bf16 pieces (dwords)
     size_t max_io = 0, max_hidden = 0;   // per-face activation floats (block in/out, expanded)
     double flops = 0, pw_flops = 0;
     Net() {
@@ -124,6 +124,7 @@ struct Net {
         flat_count = src;
         dst_fc_w = dst; dst += 64 * 1280;
         dst_fc_b = dst; dst += 64;
+        dst_head_b3 = dst; dst += (size_t)80 * 10 * 3 * 256;
         packed_count = dst;
         flops += 2.0 * 1280 * 62;
     }
@@ -330,6 +331,12 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             // input: expanded H1, or the block input X for the t=1 block (no expand conv, :58-60)
             const bool has_expand = li > 0 && n.layers[li - 1].kind == PW && n.layers[li - 1].feature == L.feature;
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
+        } else if (L.feature == 18 && h->fusion >= 2 && stop_feature != 18) {
+            syn::launch_head_bf16x3(X, reinterpret_cast<const unsigned *>(P + n.dst_head_b3), sh, P + n.dst_fc_w, P + n.dst_fc_b,
+                                    param, pool, B, s);
+            mark(19);
+            HIP_TRY(hipGetLastError());
+            return SYN_OK;
         } else if (L.feature == 18 && h->fusion && stop_feature != 18) {
             syn::launch_head(X, P + L.dst_wpk, sc, sh, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, s);
             mark(19);
@@ -465,6 +472,33 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
             pk[L.dst_scale + c] = bn_scale[c];
             pk[L.dst_shift + c] = beta[c] - mean[c] * bn_scale[c];
         }
+    }
+    {   // features.18 (BN scale folded in) split exactly into three bf16 pieces per weight, lane-ordered for
+        // v_mfma_f32_16x16x32_bf16: [n_tile 80][k_chunk 10][piece 3][lane 64][4 dwords], lane (r16, g) holds
+        // k = 32*kc + 8*g + e, e = 0..7, two bf16 per dword (even e in the low half)
+        const Layer &L = n.layers.back();
+        const float *w = flat + L.src_w;
+        const float *gamma = w + (size_t)L.cout * L.cin, *var = gamma + 3 * (size_t)L.cout;
+        unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + n.dst_head_b3);
+        auto split = [](float x, unsigned (&pc)[3]) {
+            for (int i = 0; i < 3; ++i) {
+                unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                float hf; memcpy(&hf, &u, 4);
+                pc[i] = u >> 16; x -= hf;
+            }
+        };
+        for (int nt = 0; nt < 80; ++nt)
+            for (int kc = 0; kc < 10; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned lo[3], hi[3];
+                        const int nn = nt * 16 + (lane & 15), k0 = kc * 32 + 8 * (lane >> 4) + 2 * d;
+                        const float sc = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
+                        split(w[(size_t)nn * L.cin + k0] * sc, lo);
+                        split(w[(size_t)nn * L.cin + k0 + 1] * sc, hi);
+                        for (int pcs = 0; pcs < 3; ++pcs)
+                            dp[(((size_t)(nt * 10 + kc) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
+                    }
     }
     // heads: ori[12] | shape[40] | exp[10] concatenated in that order (mobilenetv2_backbone.py:184-188)
     {
