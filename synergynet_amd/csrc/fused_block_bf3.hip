@@ -1,0 +1,373 @@
+// Fused inverted-residual block with both 1x1 GEMMs on the bf16 matrix pipe at fp32-equivalent accuracy
+// (the late MobileNetV2 blocks, CIN % 32 == 0).  Same dataflow as fused_block.hip:
+//
+//   stage 1  expand   E = ReLU6(BN(X . We^T))        LDS(bf16 x3) x regs(bf16 x3) -> fp32 acc -> LDS fp32
+//   stage 2  dw 3x3   D = ReLU6(BN(dw(E)))            fp32 VALU, LDS -> LDS (split into bf16 x3 on the way out)
+//   stage 3  project  acc += D . Wp[:, chunk]^T       LDS(bf16 x3) x regs(bf16 x3) -> fp32 acc in VGPRs
+//
+// but every fp32 operand x of a GEMM is carried as three bf16 pieces x = h + m + l (EXACT: 8+8+8 significant bits,
+// by truncation) and each 16x16x32 block product is rebuilt from the six partial products of weight >= 2^-16:
+//   h*h + (h*m + m*h) + (m*m + h*l + l*h)        (dropped: m*l, l*m, l*l  <= 2^-24 relative)
+// bf16 x bf16 products are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the result has
+// fp32-class error (measured 1.4e-6 on the network output, same as the fp32-MFMA path) while issuing 6 MFMAs of
+// K=32 (~17 cycles each) instead of 8 fp32-input MFMAs of K=4 (32 cycles each) -- and the bf16 MFMA does not share
+// the vector pipe with VALU work, which the fp32-input MFMA does (tools/ubench/mfma_valu_overlap.hip).
+// Weights are split and lane-ordered offline ([n_tile][k32 chunk][piece][lane][4 dwords]); activations are split once,
+// where they are written to LDS (input tile in stage 0, depthwise output in stage 2).
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+__device__ __forceinline__ float relu6b(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ f32x4 relu6b(f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = relu6b(v[i]);
+    return r;
+}
+constexpr int cdivb(int a, int b) { return (a + b - 1) / b; }
+constexpr int rupb(int a, int b) { return cdivb(a, b) * b; }
+// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
+__device__ __forceinline__ void split2b(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x4 mfmab(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six partial products of one (channel tile, pixel tile, k32 chunk), smallest terms first
+__device__ __forceinline__ f32x4 mac6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+    c = mfmab(a[2], b[0], c);
+    c = mfmab(a[0], b[2], c);
+    c = mfmab(a[1], b[1], c);
+    c = mfmab(a[1], b[0], c);
+    c = mfmab(a[0], b[1], c);
+    c = mfmab(a[0], b[0], c);
+    return c;
+}
+}  // namespace
+
+template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int NF_, int HC_, int NW_, int EPB_, int WN_, int WP_>
+struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
+    static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, NF = NF_, HC = HC_, NW = NW_,
+                         EPB = EPB_, WN = WN_, WP = WP_;
+    static constexpr bool RES = RES_;
+    static constexpr int NT = NW * 64;
+    static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
+    static constexpr int TH = HOUT, TW = HOUT, IH = HIN, IW = HIN;
+    static constexpr int PIN = NF * IH * IW, PINP = rupb(PIN, 16);
+    static constexpr int POUT = NF * TH * TW, POUTP = rupb(POUT, 16);
+    static constexpr int COUTP = rupb(COUT, 16);
+    static constexpr int KE = CIN / 32, KP = HC / 32;                            // k32 chunks of expand / project
+    static constexpr int XSD = CIN / 2 + 4, DSD = HC / 2 + 4, ES = HC + 4;       // LDS row strides (dwords / floats)
+    static constexpr int XPL = PINP * XSD, DPL = POUTP * DSD;                    // dwords per bf16 plane
+    static constexpr int NT_E = HC / 16, PT_IN = PINP / 16, PG = cdivb(PT_IN, EPB), JOBS = NT_E * PG;
+    static constexpr int JPW = cdivb(JOBS, NW);
+    static constexpr int NT_O = COUTP / 16, PT_O = POUTP / 16;
+    static constexpr int AN = cdivb(NT_O, WN), AP = cdivb(PT_O, WP);
+    static constexpr int X_ITEMS = PINP * (CIN / 4), X_IPT = cdivb(X_ITEMS, NT);
+    static constexpr int C4N = HC / 4, COLS = NF * TW;
+    static constexpr int RS_ = NT / (C4N * COLS);
+    static constexpr int RS = RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_);
+    static constexpr int RPS = cdivb(TH, RS), DW_THREADS = C4N * COLS * cdivb(TH, RPS);
+    static constexpr int WDR_THREADS = 11 * HC / 4;
+    static constexpr int LDS_DWORDS = 3 * XPL + PINP * ES + 3 * DPL + 11 * HC;
+    static_assert(CIN % 32 == 0 && HC % 32 == 0 && HID % HC == 0, "k32 chunking");
+    static_assert(WN * WP == NW, "wave grid");
+    static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
+    static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(WDR_THREADS <= NT, "one depthwise-weight float4 per thread");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
+    const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/, const float *__restrict__ e_shift,
+    const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][3][64][4]*/,
+    const float *__restrict__ p_shift, float *__restrict__ Y, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
+    unsigned *Xb = smem;                                         // 3 planes [PINP][XSD]
+    float *Es = reinterpret_cast<float *>(Xb + 3 * C::XPL);      // [PINP][ES] fp32
+    unsigned *Db = reinterpret_cast<unsigned *>(Es + C::PINP * C::ES);   // 3 planes [POUTP][DSD]
+    float *Wds = reinterpret_cast<float *>(Db + 3 * C::DPL);     // [11][HC]: 9 taps | (unused) | shift
+    constexpr int NT = C::NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wn = wave % C::WN, wp = wave / C::WN;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int f0 = blockIdx.x * C::NF;
+
+    // ---- prefetch: expand weights of chunk 0 and its depthwise filter (registers) ----
+    u32x4 a1[C::JPW][C::KE][3];
+    f32x4 e1h[C::JPW];
+    u32x4 a3[C::AN][C::KP][3];
+    f32x4 wdr = z4;
+    auto fetch_a1 = [&](int hc0) {
+#pragma unroll
+        for (int jj = 0; jj < C::JPW; ++jj) {
+            const int job = wave + jj * C::NW;
+            if (job < C::JOBS) {
+                const unsigned *wa = We3 + ((size_t)(hc0 / 16 + job % C::NT_E) * C::KE) * 768 + lane * 4;
+#pragma unroll
+                for (int kc = 0; kc < C::KE; ++kc)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a1[jj][kc][p] = *(const u32x4 *)(wa + (kc * 3 + p) * 256);
+                e1h[jj] = *(const f32x4 *)&e_shift[hc0 + (job % C::NT_E) * 16 + 4 * g];
+            }
+        }
+        if (tid < C::WDR_THREADS) {
+            const int row = tid / (C::HC / 4), c4 = tid % (C::HC / 4);
+            if (row < 9) wdr = *(const f32x4 *)&Wd[row * C::HID + hc0 + 4 * c4];
+            else if (row == 10) wdr = *(const f32x4 *)&d_shift[hc0 + 4 * c4];
+        }
+    };
+    auto fetch_a3 = [&](int hc0) {
+#pragma unroll
+        for (int i = 0; i < C::AN; ++i) {
+            int nt = wn + i * C::WN;
+            nt = nt < C::NT_O ? nt : 0;
+            const unsigned *wa = Wp3 + ((size_t)nt * (C::HID / 32) + hc0 / 32) * 768 + lane * 4;
+#pragma unroll
+            for (int kc = 0; kc < C::KP; ++kc)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a3[i][kc][p] = *(const u32x4 *)(wa + (kc * 3 + p) * 256);
+        }
+    };
+    fetch_a1(0);
+
+    // ---- stage 0: input tile -> three bf16 planes (exact split), zero beyond the batch / tile ----
+#pragma unroll
+    for (int ii = 0; ii < C::X_IPT; ++ii) {
+        const int it = tid + ii * NT;
+        if (it >= C::X_ITEMS) break;
+        const int c4 = it % (C::CIN / 4), p = it / (C::CIN / 4);
+        f32x4 v = z4;
+        if (p < C::PIN) {
+            const int f = f0 + p / (C::IH * C::IW);
+            if (f < B) v = *(const f32x4 *)&X[((size_t)f * C::IH * C::IW + p % (C::IH * C::IW)) * C::CIN + 4 * c4];
+        }
+        unsigned h0, m0, l0, h1, m1, l1;
+        split2b(v[0], v[1], h0, m0, l0);
+        split2b(v[2], v[3], h1, m1, l1);
+        *(u32x2 *)&Xb[0 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){h0, h1};
+        *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){m0, m1};
+        *(u32x2 *)&Xb[2 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){l0, l1};
+    }
+    if (C::POUTP > C::POUT)
+        for (int it = tid; it < 3 * (C::POUTP - C::POUT) * C::DSD; it += NT) {
+            const int p = it / ((C::POUTP - C::POUT) * C::DSD), r = it % ((C::POUTP - C::POUT) * C::DSD);
+            Db[p * C::DPL + C::POUT * C::DSD + r] = 0u;
+        }
+    f32x4 psh[C::AN];
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i) {
+        const int n = (wn + i * C::WN) * 16 + 4 * g;
+        psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
+    }
+    f32x4 acc[C::AN][C::AP];
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+        for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];
+    __syncthreads();
+
+    for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
+        if (tid < C::WDR_THREADS) *(f32x4 *)&Wds[4 * tid] = wdr;
+        // ---- stage 1: expand 1x1 (bf16 x3) + BN shift + ReLU6 -> Es (fp32) ----
+#pragma unroll
+        for (int jj = 0; jj < C::JPW; ++jj) {
+            const int job = wave + jj * C::NW;
+            if (job >= C::JOBS) break;
+            const int nt = job % C::NT_E, pg = job / C::NT_E;
+            f32x4 ea[C::EPB];
+#pragma unroll
+            for (int q = 0; q < C::EPB; ++q) ea[q] = e1h[jj];
+            auto ldb = [&](int kc, u32x4(&b)[C::EPB][3]) {
+#pragma unroll
+                for (int q = 0; q < C::EPB; ++q) {
+                    const int pt = pg * C::EPB + q;
+                    const int row = ((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XSD + kc * 16 + 4 * g;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[q][p] = *(const u32x4 *)&Xb[p * C::XPL + row];
+                }
+            };
+            u32x4 bc[C::EPB][3], bn[C::EPB][3];
+            ldb(0, bc);
+#pragma unroll
+            for (int kc = 0; kc < C::KE; ++kc) {
+                if (kc + 1 < C::KE) ldb(kc + 1, bn);
+#pragma unroll
+                for (int q = 0; q < C::EPB; ++q) ea[q] = mac6(a1[jj][kc], bc[q], ea[q]);
+#pragma unroll
+                for (int q = 0; q < C::EPB; ++q)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bc[q][p] = bn[q][p];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < C::EPB; ++q) {
+                const int pt = pg * C::EPB + q;
+                if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6b(ea[q]);
+            }
+        }
+        fetch_a3(hc0);
+        __syncthreads();
+        // ---- stage 2: depthwise 3x3 + BN shift + ReLU6 (fp32 VALU), output split into bf16 x3 planes ----
+        for (int t = tid; t < C::DW_THREADS; t += NT) {
+            const int c4 = t % C::C4N, q = t / C::C4N;
+            const int col = q % C::COLS, seg = q / C::COLS;
+            const int fi = col / C::TW, oxl = col % C::TW;
+            const int ixb = oxl * C::S - 1;
+            f32x4 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&Wds[k * C::HC + 4 * c4];
+            if (ixb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
+            if (ixb + 2 >= C::HIN) { w[2] = z4; w[5] = z4; w[8] = z4; }
+            const int lx1 = ixb + 1;
+            const int lx0 = lx1 > 0 ? lx1 - 1 : 0, lx2 = lx1 + 1 < C::IW ? lx1 + 1 : C::IW - 1;
+            const f32x4 sh = *(const f32x4 *)&Wds[10 * C::HC + 4 * c4];
+            const float *ebase = Es + (size_t)fi * C::IH * C::IW * C::ES + 4 * c4;
+            f32x4 rb[3][3];
+            auto load_row = [&](int iy, f32x4(&dst)[3]) {
+                const bool ok = (unsigned)iy < (unsigned)C::HIN;
+                const int ly = iy < 0 ? 0 : (iy > C::IH - 1 ? C::IH - 1 : iy);
+                const float *er = ebase + ly * C::IW * C::ES;
+                dst[0] = *(const f32x4 *)(er + lx0 * C::ES);
+                dst[1] = *(const f32x4 *)(er + lx1 * C::ES);
+                dst[2] = *(const f32x4 *)(er + lx2 * C::ES);
+                if (!ok) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
+            };
+#pragma unroll
+            for (int r = 0; r < C::RPS; ++r) {
+                const int oyl = seg * C::RPS + r;
+                if (oyl >= C::TH) break;
+                const int iyb = oyl * C::S - 1;
+                if (r == 0) {
+                    load_row(iyb, rb[0]); load_row(iyb + 1, rb[1]); load_row(iyb + 2, rb[2]);
+                } else if (C::S == 1) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { rb[0][k] = rb[1][k]; rb[1][k] = rb[2][k]; }
+                    load_row(iyb + 2, rb[2]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rb[0][k] = rb[2][k];
+                    load_row(iyb + 1, rb[1]); load_row(iyb + 2, rb[2]);
+                }
+                f32x4 a = sh;
+                a += rb[0][0] * w[0]; a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
+                a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
+                a = relu6b(a);
+                const int po = (fi * C::TH + oyl) * C::TW + oxl;
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2b(a[0], a[1], h0, m0, l0);
+                split2b(a[2], a[3], h1, m1, l1);
+                *(u32x2 *)&Db[0 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){h0, h1};
+                *(u32x2 *)&Db[1 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){m0, m1};
+                *(u32x2 *)&Db[2 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){l0, l1};
+            }
+        }
+        fetch_a1(hc0 + C::HC < C::HID ? hc0 + C::HC : 0);
+        __syncthreads();
+        // ---- stage 3: project 1x1 (bf16 x3), K = this hidden chunk, accumulators stay in registers ----
+        {
+            auto ldb = [&](int kc, u32x4(&b)[C::AP][3]) {
+#pragma unroll
+                for (int j = 0; j < C::AP; ++j) {
+                    const int pt = wp + j * C::WP;
+                    const int row = ((pt < C::PT_O ? pt : 0) * 16 + r16) * C::DSD + kc * 16 + 4 * g;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
+                }
+            };
+            u32x4 bc[C::AP][3], bn[C::AP][3];
+            ldb(0, bc);
+#pragma unroll
+            for (int kc = 0; kc < C::KP; ++kc) {
+                if (kc + 1 < C::KP) ldb(kc + 1, bn);
+#pragma unroll
+                for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6(a3[i][kc], bc[j], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < C::AP; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: (+ residual rebuilt exactly from the three input planes) and NHWC store ----
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i) {
+        const int nt = wn + i * C::WN;
+        const int n = nt * 16 + 4 * g;
+        if (nt >= C::NT_O || n >= C::COUT) continue;
+#pragma unroll
+        for (int j = 0; j < C::AP; ++j) {
+            const int pt = wp + j * C::WP;
+            const int po = pt * 16 + r16;
+            if (pt >= C::PT_O || po >= C::POUT) continue;
+            const int f = f0 + po / (C::TH * C::TW);
+            if (f >= B) continue;
+            f32x4 v = acc[i][j];
+            if (C::RES) {                                   // S == 1: output pixel index == input pixel index
+                const int row = po * C::XSD + n / 2;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const u32x2 w2 = *(const u32x2 *)&Xb[p * C::XPL + row];
+                    v[0] += __builtin_bit_cast(float, w2[0] << 16);
+                    v[1] += __builtin_bit_cast(float, w2[0] & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, w2[1] << 16);
+                    v[3] += __builtin_bit_cast(float, w2[1] & 0xffff0000u);
+                }
+            }
+            *(f32x4 *)&Y[((size_t)f * C::TH * C::TW + po % (C::TH * C::TW)) * C::COUT + n] = v;
+        }
+    }
+}
+
+template <class C>
+static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
+    const int grid = (B + C::NF - 1) / C::NF;
+    fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+}
+
+//                      CIN  HID COUT HIN S  RES   NF  HC NW EPB WN WP
+using B5 = Bf3Cfg<   32, 192,  32, 15, 1, true,   1, 32, 8, 4, 2, 4>;    // features.5,6
+using B7 = Bf3Cfg<   32, 192,  64, 15, 2, false,  1, 32, 4, 4, 4, 1>;    // features.7
+using B8 = Bf3Cfg<   64, 384,  64,  8, 1, true,   1, 64, 4, 4, 4, 1>;    // features.8-10
+using B11 = Bf3Cfg<  64, 384,  96,  8, 1, false,  1, 64, 4, 4, 2, 2>;    // features.11
+using B12 = Bf3Cfg<  96, 576,  96,  8, 1, true,   1, 64, 4, 4, 2, 2>;    // features.12,13
+using B14 = Bf3Cfg<  96, 576, 160,  8, 2, false,  2, 64, 4, 4, 4, 1>;    // features.14
+using B15 = Bf3Cfg< 160, 960, 160,  4, 1, true,   4, 64, 4, 4, 2, 2>;    // features.15,16
+using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // features.17
+
+bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
+    if (!a.We3 || !a.Wp3) return false;
+    switch (feature) {
+        case 5: case 6: launch_bf3<B5>(a, B, s); return true;
+        case 7: launch_bf3<B7>(a, B, s); return true;
+        case 8: case 9: case 10: launch_bf3<B8>(a, B, s); return true;
+        case 11: launch_bf3<B11>(a, B, s); return true;
+        case 12: case 13: launch_bf3<B12>(a, B, s); return true;
+        case 14: launch_bf3<B14>(a, B, s); return true;
+        case 15: case 16: launch_bf3<B15>(a, B, s); return true;
+        case 17: launch_bf3<B17>(a, B, s); return true;
+        default: return false;
+    }
+}
+
+}  // namespace syn

@@ -45,8 +45,11 @@ struct FusedBlockArgs {
     const float *Wp, *p_scale, *p_shift;              // project: Wpk[COUTP/16][HID/16][64][4], [COUTP], [COUTP]
     float *Y;                                         // block output NHWC
     unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
+    const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
+bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 
 // features.0 + features.1 fused (stem_block1.hip): image -> NHWC [B,60,60,16].
 void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w0, const float *s0,

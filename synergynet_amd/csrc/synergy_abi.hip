@@ -55,6 +55,7 @@ struct Layer {
     size_t src_w;        // offsets (floats) into the flat host input
     size_t dst_w, dst_scale, dst_shift;   // offsets (floats) into the packed device blob
     size_t dst_wpk;      // PW layers of fused blocks: weights in MFMA lane order (fused_block.hip)
+    size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -110,6 +111,11 @@ struct Net {
             L.dst_wpk = dst;
             if (L.kind == PW) dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
             else dst += wp;
+            L.dst_wb3 = 0;
+            if (L.kind == PW && L.feature >= 5 && L.feature <= 17 && L.cin % 32 == 0) {
+                L.dst_wb3 = dst;
+                dst += (size_t)round_up(L.cout, 16) * L.cin * 3 / 2;      // 3 bf16 per weight
+            }
             const double pix = (double)L.hout * L.hout;
             const double f2 = L.kind == STEM ? 2.0 * 27 * 32 * pix : L.kind == DW ? 2.0 * 9 * L.cout * pix
                                                                                    : 2.0 * L.cin * (double)L.cout * pix;
@@ -218,7 +224,8 @@ struct syn_handle {
     int n_vert = 0, n_lmk = 0, nvp = 0, nlp = 0;
     float *ws = nullptr;
     size_t ws_bytes = 0;
-    int fusion = 1;                // 1: fused inverted-residual blocks, 0: one kernel per layer (SYNERGY_HIP_FUSION)
+    int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
+                                   // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
 };
 
 namespace {
@@ -313,7 +320,11 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                   P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
             if (prof_feature == L.feature) a.prof = prof;
-            if (syn::launch_fused_block(L.feature, a, B, s)) {
+            if (h->fusion >= 2 && L.dst_wb3 && Pj.dst_wb3) {
+                a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
+                a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
+            }
+            if ((a.We3 && !a.prof && syn::launch_fused_block_bf3(L.feature, a, B, s)) || syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
                 mark(L.feature);
@@ -466,6 +477,30 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
                             const int nn = nt * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + q;
                             dp[(((size_t)nt * kch + kc) * 64 + lane) * 4 + q] =
                                 (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] * bn_scale[nn] : 0.f;
+                        }
+        }
+        if (L.dst_wb3) {                 // [N][K] -> [n_tile][k32 chunk][piece][lane][4 dwords], BN scale folded in
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wb3);
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            const int ntl = round_up(L.cout, 16) / 16, kch = L.cin / 32;
+            for (int nt = 0; nt < ntl; ++nt)
+                for (int kc = 0; kc < kch; ++kc)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                            const int nn = nt * 16 + (lane & 15), k0 = kc * 32 + 8 * (lane >> 4) + 2 * d;
+                            if (nn < L.cout) {
+                                split(w[(size_t)nn * L.cin + k0] * bn_scale[nn], lo);
+                                split(w[(size_t)nn * L.cin + k0 + 1] * bn_scale[nn], hi);
+                            }
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[(((size_t)(nt * kch + kc) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
                         }
         }
         for (int c = 0; c < L.cout; ++c) {

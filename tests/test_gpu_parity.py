@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope='module', params=['fused-blocks', 'per-layer', 'fused+bf16x3'])
+@pytest.fixture(scope='module', params=['fused+bf16x3', 'fused-fp32', 'per-layer'])
 def model(request, pack, backbone_sd):
     """The backbone schedules of the library (SYNERGY_HIP_FUSION, read at syn_create): 1 = fused inverted-residual
     blocks on the fp32 MFMA, 0 = one kernel per layer, 2 = fused + GEMMs on the bf16 matrix pipe through the exact
@@ -23,7 +23,7 @@ def model(request, pack, backbone_sd):
     import torch
     assert torch.cuda.is_available(), 'GPU tests need an MI355X'
     from synergynet_amd.synergy3DMM import SynergyNet
-    os.environ['SYNERGY_HIP_FUSION'] = {'fused-blocks': '1', 'per-layer': '0', 'fused+bf16x3': '2'}[request.param]
+    os.environ['SYNERGY_HIP_FUSION'] = {'fused-fp32': '1', 'per-layer': '0', 'fused+bf16x3': '2'}[request.param]
     try:
         m = SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
         m._test_fusion = os.environ['SYNERGY_HIP_FUSION']
