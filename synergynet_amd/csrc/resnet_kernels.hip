@@ -128,6 +128,152 @@ void launch_conv(const float *in, const float *W, const float *scale, const floa
 }
 
 // =====================================================================================
+// The same implicit GEMM on the bf16 matrix pipe with fp32-equivalent accuracy (exact 3-way bf16 operand split, six
+// partial products per K=32 block -- see fused_block_bf3.hip).  Weights are split and lane-ordered offline:
+//   W3[n_tile][tap*Cin/32 + kc][piece][lane][4 dwords],  lane (channel l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
+// Activations stay fp32 in HBM; a lane fetches its 8 consecutive input channels (two float4) and splits them in
+// registers -- that VALU work runs beside the bf16 MFMAs of the other resident waves (separate pipes).
+// Requires Cin % 32 == 0.
+// =====================================================================================
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (&pc)[3]) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned u0 = __builtin_bit_cast(unsigned, x[2 * d]), u1 = __builtin_bit_cast(unsigned, x[2 * d + 1]);
+        const float r0 = x[2 * d] - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x[2 * d + 1] - __builtin_bit_cast(float, u1 & 0xffff0000u);
+        const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+        pc[0][d] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        pc[1][d] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        pc[2][d] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       const float *__restrict__ residual, float *__restrict__ out, int M,
+                                                       int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
+                                                       int act, int n_tiles, int m_tiles) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt_idx = q % n_tiles;
+    const int mt_idx = (q / n_tiles) * 8 + xcd;
+    if (mt_idx >= m_tiles) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = (mt_idx * 4 + wave) * (MT * 16);
+    const int n0 = nt_idx * (NT * 16);
+    if (m0 >= M) return;
+    const int KCH = Cin >> 5, steps = KH * KW * KCH;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    int pb[MT], py[MT], px[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        int m = m0 + j * 16 + r16;
+        m = m < M ? m : M - 1;
+        const int hw = Hout * Hout;
+        pb[j] = m / hw;
+        const int r = m - pb[j] * hw;
+        py[j] = (r / Hout) * stride - pad;
+        px[j] = (r % Hout) * stride - pad;
+    }
+    const unsigned *wp[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wp[i] = W3 + (size_t)(n0 / 16 + i) * steps * 768 + lane * 4;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = z4;
+
+    auto fetch = [&](int s, u32x4(&wf)[NT][3], f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+        const int tap = s / KCH, kc = s - tap * KCH;
+        const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wf[i][p] = *(const u32x4 *)(wp[i] + ((size_t)s * 3 + p) * 256);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int iy = py[j] + ky, ix = px[j] + kx;
+            const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 32 + 8 * g;
+            const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+            a0[j] = ok ? v0 : z4;
+            a1[j] = ok ? v1 : z4;
+        }
+    };
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    u32x4 wf[NT][3], wn[NT][3];
+    f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
+    fetch(0, wf, c0, c1);
+    for (int s = 0; s < steps; ++s) {
+        if (s + 1 < steps) fetch(s + 1, wn, n0v, n1v);
+        u32x4 bp[MT][3];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pbk[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[j][i] = mm(wf[i][pa[t]], bp[j][pbk[t]], acc[j][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wf[i][p] = wn[i][p];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + i * 16 + 4 * g;
+        if (n >= N) continue;
+        const f32x4 sc = *(const f32x4 *)&scale[n];
+        const f32x4 sh = *(const f32x4 *)&shift[n];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + j * 16 + r16;
+            if (m >= M) continue;
+            f32x4 v = acc[j][i] * sc + sh;
+            if (residual) v += *(const f32x4 *)&residual[(size_t)m * N + n];
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+            }
+            *(f32x4 *)&out[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+template <int MT, int NT>
+static void launch_conv_bf3_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+                              float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
+                              hipStream_t s) {
+    const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
+    const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
+    const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    conv_bf3_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
+                                                 act, n_tiles, m_tiles);
+}
+
+void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+                     float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
+                     hipStream_t s) {
+    const int M = B * Hout * Hout;
+    const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
+    if (tiles >= 1024) launch_conv_bf3_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+    else launch_conv_bf3_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+}
+
+// =====================================================================================
 // ResNet stem: 7x7 stride-2 pad-3 conv 3->64 + BN + ReLU (resnet_backbone.py:168-171), 120 -> 60, NHWC out.
 // Thread = (output pixel, 4 channels); the 147x64 filter (36.8 KB) sits in LDS.  ~1.4 % of the network's FLOPs.
 // U8 variant fuses the HWC->CHW permute and (x-127.5)/128 like the MobileNetV2 stem.

@@ -69,6 +69,10 @@ void launch_head_bf16x3(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
                  int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s);
+// same conv on the bf16 matrix pipe (exact 3-way operand split): W3 [N/16][taps*Cin/32][3][64][4] dwords, Cin % 32 == 0
+void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+                     float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
+                     hipStream_t s);
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s);

@@ -145,7 +145,7 @@ const Net &net() {
 // :139-254 (ResNet: 7x7/2 stem, 3x3/2 max-pool, layers [3,4,6,3], heads tex/ori/shape/exp -> cat(ori,shape,exp,tex)).
 struct RConv {
     int cin, cout, k, stride, pad, hin, hout;
-    size_t src_w, dst_w, dst_scale, dst_shift;
+    size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: 3-way bf16 split, MFMA lane order (dwords)
 };
 struct RBlock { int c1, c2, c3, ds; };
 struct ResNet50 {
@@ -186,6 +186,8 @@ struct ResNet50 {
             c.dst_w = dst; dst += (size_t)npad * c.cin * c.k * c.k;
             c.dst_scale = dst; dst += npad;
             c.dst_shift = dst; dst += npad;
+            c.dst_w3 = 0;
+            if (c.cin % 32 == 0) { c.dst_w3 = dst; dst += (size_t)npad * c.cin * c.k * c.k * 3 / 2; }
             flops += 2.0 * c.cin * c.k * c.k * (double)c.cout * c.hout * c.hout;
             const size_t osz = (size_t)c.cout * c.hout * c.hout;
             buf_big = osz > buf_big ? osz : buf_big;
@@ -384,6 +386,11 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     float *T1 = D + (size_t)B * n.buf_big, *T2 = T1 + (size_t)B * n.buf_mid;
     const float *P = h->d_backbone;
     auto conv = [&](const RConv &c, const float *in, const float *res, float *out, int act) {
+        if (h->fusion >= 2 && c.dst_w3) {
+            syn::launch_conv_bf3(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
+                                 c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s);
+            return;
+        }
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
                          c.stride, c.pad, act, s);
     };
@@ -579,6 +586,29 @@ int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats
                 for (int ci = 0; ci < c.cin; ++ci)
                     for (int t = 0; t < taps; ++t)
                         dw[(size_t)nn * taps * c.cin + (size_t)t * c.cin + ci] = w[((size_t)nn * c.cin + ci) * taps + t];
+        }
+        if (c.dst_w3) {   // [N][tap*Cin + ci] -> [n_tile][tap*Cin/32 + kc][piece][lane][4 dwords]
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_w3);
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            const int kch = c.cin / 32, steps = taps * kch, K = taps * c.cin;
+            for (int nt = 0; nt < c.cout / 16; ++nt)
+                for (int st = 0; st < steps; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned lo[3], hi[3];
+                            const int nn = nt * 16 + (lane & 15);
+                            const int k0 = (st / kch) * c.cin + (st % kch) * 32 + 8 * (lane >> 4) + 2 * d;
+                            split(dw[(size_t)nn * K + k0], lo);
+                            split(dw[(size_t)nn * K + k0 + 1], hi);
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[((((size_t)nt * steps + st) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
+                        }
         }
         for (int ch = 0; ch < c.cout; ++ch) {
             const float a = gamma[ch] * (1.0f / sqrtf(var[ch] + 1e-5f));
