@@ -109,6 +109,15 @@ int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, f
 int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img_hwc, int B, float *param,
                             float *pool, void *stream);
 
+/* Pre-processing of get_all_outputs (synergy3DMM.py:187-188): crop_img (utils/inference.py:95-125, zero padding outside
+ * the frame) + cv2.resize(..., (120,120), INTER_LANCZOS4) for B detections of ONE frame, on device.
+ * frame [H,W,3] uint8 HWC; box [B,4] = int(round()) of the enlarged square box (sx,sy,ex,ey);
+ * xofs/yofs [B,120] = first of the 8 source taps in crop coordinates, xcoef/ycoef [B,120,8] = OpenCV's 11-bit fixed
+ * point Lanczos-4 weights (the host computes these tables: synergynet_amd/inference.py lanczos4_tables);
+ * out [B,120,120,3] uint8, the input of syn_backbone_forward_u8.  All pointers are device pointers. */
+int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int *box, const int *xofs,
+                    const int16_t *xcoef, const int *yofs, const int16_t *ycoef, uint8_t *out, int B, void *stream);
+
 /* reconstruct_vertex_62 (synergy3DMM.py:116-149) fused with the ROI affine of
  * _predict_vertices (utils/inference.py:127-138).
  * param [B,param_len] whitened; param_len must be 62 (else SYN_ERR_PARAM_LEN).

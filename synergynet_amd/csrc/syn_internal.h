@@ -65,6 +65,10 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
 void launch_head_bf16x3(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
                         const float *bfc, float *param, float *pool, int B, hipStream_t s);
 
+// ---- on-device crop + Lanczos-4 resize (preproc_kernels.hip) ----
+void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, const int *xofs, const short *xcoef,
+                        const int *yofs, const short *ycoef, uint8_t *out, int B, hipStream_t s);
+
 // ---- ResNet-50 variant (resnet_kernels.hip) ----
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,

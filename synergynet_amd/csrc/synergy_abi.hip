@@ -827,6 +827,16 @@ int syn_debug_feature(syn_handle *h, const float *img, int B, int feature, float
     return run_backbone(h, img, nullptr, B, nullptr, nullptr, (hipStream_t)stream, feature, out);
 }
 
+int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int *box, const int *xofs, const int16_t *xcoef,
+                    const int *yofs, const int16_t *ycoef, uint8_t *out, int B, void *stream) {
+    if (!h || !frame || !box || !xofs || !xcoef || !yofs || !ycoef || !out) return fail(SYN_ERR_INVALID, "syn_crop_resize: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(SYN_ERR_INVALID, "syn_crop_resize: B=%d H=%d W=%d", B, H, W);
+    DeviceGuard g(h->device);
+    syn::launch_crop_resize(frame, H, W, box, xofs, xcoef, yofs, ycoef, out, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
 int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
                     float *out, void *stream) {
     if (!h || !param || !out) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");

@@ -83,6 +83,12 @@ def _lanczos4_taps(n_dst: int, n_src: int):
     return sx - 3, icoef
 
 
+def lanczos4_tables(n_src: int, n_dst: int = 120):
+    """(first tap in source coordinates [n_dst] int32, fixed-point weights [n_dst,8] int16) for syn_crop_resize."""
+    x0, c = _lanczos4_taps(n_dst, n_src)
+    return x0.astype(np.int32), c.astype(np.int16)
+
+
 def resize_lanczos4(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """uint8 [h,w(,c)] -> uint8 [out_h,out_w(,c)], separable 8-tap Lanczos, replicated borders."""
     img = np.asarray(img)

@@ -357,6 +357,22 @@ class SynergyNet(nn.Module):
         ang, t3d = self.predict_pose_batch(p, roi)
         return [float(v) for v in ang[0].cpu().numpy()], t3d[0].cpu().numpy()
 
+    def crop_resize(self, frame, boxes, xofs, xcoef, yofs, ycoef):
+        """crop_img + cv2.resize(INTER_LANCZOS4) of B detections of one uint8 frame [H,W,3] on the device
+        (syn_crop_resize); returns uint8 crops [B,120,120,3] on the device."""
+        fr = torch.as_tensor(np.ascontiguousarray(frame))
+        if fr.dtype != torch.uint8 or fr.dim() != 3 or fr.shape[2] != 3:
+            raise RuntimeError('frame must be uint8 [H,W,3]')
+        fr = fr.to(self.device)
+        dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(self.device)
+        bx, xo, xc, yo, yc = dev(boxes, np.int32), dev(xofs, np.int32), dev(xcoef, np.int16), dev(yofs, np.int32), dev(ycoef, np.int16)
+        B = bx.shape[0]
+        with torch.cuda.device(self.device):
+            out = torch.empty((B, 120, 120, 3), dtype=torch.uint8, device=self.device)
+            abi.check(self._lib.syn_crop_resize(self._h, fr.data_ptr(), fr.shape[0], fr.shape[1], bx.data_ptr(), xo.data_ptr(),
+                                                xc.data_ptr(), yo.data_ptr(), yc.data_ptr(), out.data_ptr(), B, self._stream()))
+        return out
+
     def get_all_outputs(self, input, rects=None):
         """reference synergy3DMM.py:167-207: BGR uint8 image [H,W,3] -> (list of (3,68) landmarks,
         list of (3,53215) meshes, list of [angles_deg, translation]) with one entry per face.
@@ -365,7 +381,7 @@ class SynergyNet(nn.Module):
         per-face loop.  `rects` = detections [[xmin,ymin,xmax,ymax,score], ...]; when omitted the
         pluggable `face_detector(image)` is called (the reference constructs FaceBoxes here,
         :170-171; that detector is outside this repo's scope)."""
-        from .inference import crop_img, resize_lanczos4
+        from .inference import lanczos4_tables
         if rects is None:
             if self.face_detector is None:
                 raise RuntimeError('no face detector: pass rects=[[xmin,ymin,xmax,ymax,score],...] or set '
@@ -374,7 +390,7 @@ class SynergyNet(nn.Module):
         pts_res, vertices_lst, poses = [], [], []
         if len(rects) == 0:
             return pts_res, vertices_lst, poses
-        crops, rois = [], []
+        rois, boxes, xo, xc, yo, yc = [], [], [], [], [], []
         for rect in rects:
             roi_box = rect                      # aliases and mutates the caller's list like the reference (:178,185)
             HCenter = (rect[1] + rect[3]) / 2
@@ -382,11 +398,17 @@ class SynergyNet(nn.Module):
             side_len = roi_box[3] - roi_box[1]
             margin = side_len * 1.2 // 2
             roi_box[0], roi_box[1], roi_box[2], roi_box[3] = WCenter - margin, HCenter - margin, WCenter + margin, HCenter + margin
-            img = crop_img(input, roi_box)
-            crops.append(resize_lanczos4(img, 120, 120))
             rois.append([float(v) for v in roi_box[:5]])
-        crops = np.stack(crops)
+            sx, sy, ex, ey = [int(round(v)) for v in roi_box[:4]]         # crop_img's rounding (utils/inference.py:98)
+            if ex - sx <= 0 or ey - sy <= 0:
+                raise ValueError('degenerate detection box')
+            boxes.append([sx, sy, ex, ey])
+            a, b = lanczos4_tables(ex - sx)
+            xo.append(a); xc.append(b)
+            a, b = lanczos4_tables(ey - sy)
+            yo.append(a); yc.append(b)
         rois = np.asarray(rois, dtype=np.float32)
+        crops = self.crop_resize(input, np.asarray(boxes, dtype=np.int32), np.stack(xo), np.stack(xc), np.stack(yo), np.stack(yc))
         param = self.forward_crops_u8(crops)
         lmk = self.reconstruct(param, roi=rois, dense=False, transform=True).cpu().numpy()
         mesh = self.reconstruct(param, roi=rois, dense=True, transform=True).cpu().numpy()

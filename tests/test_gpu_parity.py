@@ -256,3 +256,33 @@ def test_resnet50_matches_reference_golden_and_oracle(resnet_model):
     # the geometry stage is backbone-independent: landmarks + mesh come out of the same kernels
     mesh = resnet_model.reconstruct(got, dense=True)
     assert tuple(mesh.shape) == (33, 3, 53215) and torch.isfinite(mesh).all()
+
+
+def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
+    """syn_crop_resize (row f-1) vs synergynet_amd.inference.crop_img + resize_lanczos4 on boxes that overhang every
+    border of the frame, and get_all_outputs' landmarks vs the batched path on those host-made crops."""
+    import torch
+    from synergynet_amd.inference import crop_img, lanczos4_tables, resize_lanczos4
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(360, 500, 3), dtype=np.uint8)
+    boxes = np.array([[40, 30, 300, 290], [-35, -20, 140, 155], [380, 250, 560, 430], [100, 100, 220, 220], [200, -50, 421, 171]], np.int32)
+    xo, xc, yo, yc = [], [], [], []
+    for sx, sy, ex, ey in boxes:
+        a, b = lanczos4_tables(ex - sx); xo.append(a); xc.append(b)
+        a, b = lanczos4_tables(ey - sy); yo.append(a); yc.append(b)
+    got = model.crop_resize(img, boxes, np.stack(xo), np.stack(xc), np.stack(yo), np.stack(yc)).cpu().numpy()
+    for i, bx in enumerate(boxes):
+        want = resize_lanczos4(crop_img(img, [float(v) for v in bx] + [1.0]), 120, 120)
+        assert np.array_equal(got[i], want), f'box {i}'
+    rects = [[100.0, 80.0, 260.0, 270.0, 0.99], [400.0, 200.0, 490.0, 350.0, 0.95]]
+    lm, mesh, pose = model.get_all_outputs(img, rects=[list(r) for r in rects])
+    crops, rois = [], []
+    for r in rects:
+        r = list(r)
+        hc, wc = (r[1] + r[3]) / 2, (r[0] + r[2]) / 2
+        m = (r[3] - r[1]) * 1.2 // 2
+        r[0], r[1], r[2], r[3] = wc - m, hc - m, wc + m, hc + m
+        crops.append(resize_lanczos4(crop_img(img, r), 120, 120)); rois.append(r)
+    p = model.forward_crops_u8(np.stack(crops))
+    want = model.reconstruct(p, roi=np.asarray(rois, np.float32), dense=False).cpu().numpy()
+    assert np.array_equal(np.stack(lm), want)
