@@ -47,7 +47,7 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int rup(int a, int b) { return cdiv(a, b) * b; }
 
 template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int TH_, int TW_, int NF_, int HC_, int NW_,
-          int EPB_, int WN_, int WP_, bool WLDS_>
+          int EPB_, int WN_, int WP_, bool WLDS_, int DWRS_ = 0>
 struct BlockCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, TH = TH_, TW = TW_, NF = NF_,
                          HC = HC_, NW = NW_, EPB = EPB_, WN = WN_, WP = WP_;
@@ -71,7 +71,7 @@ struct BlockCfg {
     // depthwise stage mapping: thread = (channel quad, output column of a face, row segment)
     static constexpr int C4N = HC / 4, COLS = NF * TW;
     static constexpr int RS_ = NT / (C4N * COLS);
-    static constexpr int RS = RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_);
+    static constexpr int RS = DWRS_ > 0 ? DWRS_ : (RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_));   // row segments per column (DWRS_ overrides)
     static constexpr int RPS = cdiv(TH, RS), DW_THREADS = C4N * COLS * cdiv(TH, RPS);
     // LDS carve (floats)
     static constexpr int XS_FLOATS = PINP * XS, ES_FLOATS = PINP * ES, DS_FLOATS = POUTP * ES;
@@ -415,8 +415,8 @@ static void launch_cfg(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_pe
 }
 
 //                      CIN  HID COUT HIN S  RES    TH  TW NF  HC NW EPB WN WP  WLDS
-using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false, 10, 10, 1, 32, 8, 7, 2, 4, true>;    // features.2   60 -> 30
-using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 8, 2, 2, 4, true>;    // features.3   30
+using Cfg2 = BlockCfg<  16,  96,  24, 60, 2, false, 10, 10, 1, 32, 8, 7, 2, 4, true>;       // features.2   60 -> 30
+using Cfg3 = BlockCfg<  24, 144,  24, 30, 1, true,  10, 10, 1, 48, 8, 2, 2, 4, true>;       // features.3   30
 using Cfg4 = BlockCfg<  24, 144,  32, 30, 2, false,  5,  5, 1, 144, 8, 2, 2, 4, true>;   // features.4   30 -> 15
 using Cfg5 = BlockCfg<  32, 192,  32, 15, 1, true,  15, 15, 1, 32, 8, 4, 2, 4, false>;   // features.5,6 15
 using Cfg7 = BlockCfg<  32, 192,  64, 15, 2, false,  8,  8, 1, 32, 4, 4, 4, 1, false>;   // features.7   15 -> 8
