@@ -72,6 +72,9 @@ def cpu_baseline(sd, pack, budget_s=24.0):
 
 
 def main():
+    # native libraries (RCCL, HIP) print banners on fd 1: keep the real stdout for the ONE JSON line only
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -90,7 +93,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SYN_BENCH_FORCE_DIST') == '1':      # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -104,7 +107,7 @@ def main():
         model = SynergyNet(device=dev, pack=pack, backbone_state=sd, arch=args.arch)
     else:
         model = SynergyNet(device=dev, load_constants=False, arch=args.arch)
-    if world > 1:
+    if dist is not None:
         broadcast_constants(model, src=0)          # one RCCL broadcast over xGMI, then no collectives
 
     B = args.batch
@@ -209,7 +212,8 @@ def main():
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1 and args.arch == 'mobilenet_v2':
             out['cpu_baseline'] = cpu_baseline(sd, pack)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
