@@ -58,12 +58,13 @@ __device__ __forceinline__ f32x4 mac6(const u32x4 (&a)[3], const u32x4 (&b)[3], 
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int NF_, int HC_, int NW_, int EPB_, int WN_, int WP_>
+template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int NF_, int HC_, int NW_, int EPB_, int WN_, int WP_, int OCC_ = 1>
 struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, NF = NF_, HC = HC_, NW = NW_,
                          EPB = EPB_, WN = WN_, WP = WP_;
     static constexpr bool RES = RES_;
     static constexpr int NT = NW * 64;
+    static constexpr int WPE = OCC_ * NW / 4;     // waves per SIMD the register budget is sized for (OCC workgroups per CU)
     static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
     static constexpr int TH = HOUT, TW = HOUT, IH = HIN, IW = HIN;
     static constexpr int PIN = NF * IH * IW, PINP = rupb(PIN, 16);
@@ -86,15 +87,21 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
     static_assert(CIN % 32 == 0 && HC % 32 == 0 && HID % HC == 0, "k32 chunking");
     static_assert(WN * WP == NW, "wave grid");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
-    static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(LDS_DWORDS * 4 * OCC_ <= 160 * 1024, "LDS budget");
+    static_assert(OCC_ * NW % 4 == 0, "whole waves per SIMD");
     static_assert(WDR_THREADS <= NT, "one depthwise-weight float4 per thread");
 };
 
-template <class C>
-__global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
+// PROF: as in fused_block.hip -- wave 0 accumulates s_memtime deltas per stage into prof[0..7].
+#define SYNB_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+
+template <class C, bool PROF = false>
+__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_bf3_kernel(
     const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/, const float *__restrict__ e_shift,
     const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][3][64][4]*/,
-    const float *__restrict__ p_shift, float *__restrict__ Y, int B) {
+    const float *__restrict__ p_shift, float *__restrict__ Y, int B,
+    unsigned long long *prof = nullptr) {
+    unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
     unsigned *Xb = smem;                                         // 3 planes [PINP][XSD]
     float *Es = reinterpret_cast<float *>(Xb + 3 * C::XPL);      // [PINP][ES] fp32
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
 #pragma unroll
         for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];
     __syncthreads();
+    SYNB_LAP(0);
 
     for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
         if (tid < C::WDR_THREADS) *(f32x4 *)&Wds[4 * tid] = wdr;
@@ -222,7 +230,9 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
             }
         }
         fetch_a3(hc0);
+        SYNB_LAP(1);
         __syncthreads();
+        SYNB_LAP(2);
         // ---- stage 2: depthwise 3x3 + BN shift + ReLU6 (fp32 VALU), output split into bf16 x3 planes ----
         for (int t = tid; t < C::DW_THREADS; t += NT) {
             const int c4 = t % C::C4N, q = t / C::C4N;
@@ -279,7 +289,9 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
             }
         }
         fetch_a1(hc0 + C::HC < C::HID ? hc0 + C::HC : 0);
+        SYNB_LAP(3);
         __syncthreads();
+        SYNB_LAP(4);
         // ---- stage 3: project 1x1 (bf16 x3), K = this hidden chunk, accumulators stay in registers ----
         {
             auto ldb = [&](int kc, u32x4(&b)[C::AP][3]) {
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SYNB_LAP(5);
     }
 
     // ---- epilogue: (+ residual rebuilt exactly from the three input planes) and NHWC store ----
@@ -337,21 +350,29 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_bf3_kernel(
             *(f32x4 *)&Y[((size_t)f * C::TH * C::TW + po % (C::TH * C::TW)) * C::COUT + n] = v;
         }
     }
+    SYNB_LAP(6);
+    if (PROF && tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], 1ull);
+    }
 }
 
 template <class C>
 static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::NF - 1) / C::NF;
-    fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+    if (a.prof)
+        fused_block_bf3_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.prof);
+    else
+        fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
 }
 
 //                      CIN  HID COUT HIN S  RES   NF  HC NW EPB WN WP
 using B5 = Bf3Cfg<   32, 192,  32, 15, 1, true,   1, 32, 8, 4, 2, 4>;    // features.5,6
-using B7 = Bf3Cfg<   32, 192,  64, 15, 2, false,  1, 32, 4, 4, 4, 1>;    // features.7
-using B8 = Bf3Cfg<   64, 384,  64,  8, 1, true,   1, 64, 4, 4, 4, 1>;    // features.8-10
-using B11 = Bf3Cfg<  64, 384,  96,  8, 1, false,  1, 64, 4, 4, 2, 2>;    // features.11
-using B12 = Bf3Cfg<  96, 576,  96,  8, 1, true,   1, 64, 4, 4, 2, 2>;    // features.12,13
-using B14 = Bf3Cfg<  96, 576, 160,  8, 2, false,  2, 64, 4, 4, 4, 1>;    // features.14
+using B7 = Bf3Cfg<   32, 192,  64, 15, 2, false,  1, 32, 8, 4, 4, 2>;    // features.7
+using B8 = Bf3Cfg<   64, 384,  64,  8, 1, true,   1, 64, 4, 4, 4, 1, 2>;    // features.8-10
+using B11 = Bf3Cfg<  64, 384,  96,  8, 1, false,  1, 64, 4, 4, 2, 2, 2>;    // features.11
+using B12 = Bf3Cfg<  96, 576,  96,  8, 1, true,   1, 32, 4, 2, 2, 2, 2>;    // features.12,13
+using B14 = Bf3Cfg<  96, 576, 160,  8, 2, false,  1, 64, 4, 4, 4, 1, 2>;    // features.14
 using B15 = Bf3Cfg< 160, 960, 160,  4, 1, true,   4, 64, 4, 4, 2, 2>;    // features.15,16
 using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // features.17
 

@@ -326,7 +326,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
             }
-            if ((a.We3 && !a.prof && syn::launch_fused_block_bf3(L.feature, a, B, s)) || syn::launch_fused_block(L.feature, a, B, s)) {
+            if ((a.We3 && syn::launch_fused_block_bf3(L.feature, a, B, s)) || syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
                 mark(L.feature);
