@@ -218,6 +218,22 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
         for (int i = 0; i < C::AN; ++i)
 #pragma unroll
             for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];        // BN shift = accumulator start
+        // Tiled blocks: hidden pixels of the halo ring that lie outside the image must read as ZERO in the depthwise
+        // stage (zero padding applies to the expanded map).  The expand epilogue writes them as med3(e, 0, 0) instead
+        // of med3(e, 0, 6) -- the ceiling is a per-lane register, so the padding costs no instruction anywhere.
+        float ehi[C::JPW][C::EPB];
+        if (!C::WHOLE) {
+#pragma unroll
+            for (int jj = 0; jj < C::JPW; ++jj)
+#pragma unroll
+                for (int q = 0; q < C::EPB; ++q) {
+                    const int job = wave + jj * C::NW;
+                    const int p = ((job / C::NT_E) * C::EPB + q) * 16 + r16;
+                    const int r = p % (C::IH * C::IW);
+                    const int iy = iy0 + r / C::IW, ix = ix0 + r % C::IW;
+                    ehi[jj][q] = ((unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) ? 6.0f : 0.0f;
+                }
+        }
 
         for (int hc0 = 0; hc0 < C::HID; hc0 += C::HC) {
             const float *wdc = C::WLDS ? Wds + hc0 : Wds;                 // depthwise filter of this chunk
@@ -266,7 +282,13 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) {
                     const int pt = pg * C::EPB + q;
-                    if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6_(ea[q]);
+                    if (pt < C::PT_IN) {
+                        f32x4 ev;
+                        const float hi = C::WHOLE ? 6.0f : ehi[jj][q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ev[e] = __builtin_amdgcn_fmed3f(ea[q][e], 0.0f, hi);
+                        *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = ev;
+                    }
                 }
             }
             if (!C::WLDS) fetch_a3(hc0);          // in flight during the depthwise stage
@@ -285,22 +307,24 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                 f32x4 w[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&wdc[k * WDS + 4 * c4];
-                if (ixb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
-                if (ixb + 2 >= C::HIN) { w[2] = z4; w[5] = z4; w[8] = z4; }
+                if (C::WHOLE) {     // no halo ring in LDS: out-of-image column taps get weight 0 (their address is clamped)
+                    if (ixb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
+                    if (ixb + 2 >= C::HIN) { w[2] = z4; w[5] = z4; w[8] = z4; }
+                }
                 const int lx1 = ixb + 1 - ix0;
-                const int lx0 = lx1 > 0 ? lx1 - 1 : 0, lx2 = lx1 + 1 < C::IW ? lx1 + 1 : C::IW - 1;
+                const int lx0 = C::WHOLE ? (lx1 > 0 ? lx1 - 1 : 0) : lx1 - 1;
+                const int lx2 = C::WHOLE ? (lx1 + 1 < C::IW ? lx1 + 1 : C::IW - 1) : lx1 + 1;
                 const f32x4 sh = *(const f32x4 *)&wdc[10 * WDS + 4 * c4];
                 const float *ebase = Es + (size_t)fi * C::IH * C::IW * C::ES + 4 * c4;
                 f32x4 rb[3][3];
                 auto load_row = [&](int iy, f32x4(&dst)[3]) {
-                    const bool ok = (unsigned)iy < (unsigned)C::HIN;
                     int ly = iy - iy0;
-                    ly = ly < 0 ? 0 : (ly > C::IH - 1 ? C::IH - 1 : ly);
+                    if (C::WHOLE) ly = ly < 0 ? 0 : (ly > C::IH - 1 ? C::IH - 1 : ly);
                     const float *er = ebase + ly * C::IW * C::ES;
                     dst[0] = *(const f32x4 *)(er + lx0 * C::ES);
                     dst[1] = *(const f32x4 *)(er + lx1 * C::ES);
                     dst[2] = *(const f32x4 *)(er + lx2 * C::ES);
-                    if (!ok) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
+                    if (C::WHOLE && !((unsigned)iy < (unsigned)C::HIN)) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
                 };
 #pragma unroll
                 for (int r = 0; r < C::RPS; ++r) {

@@ -60,14 +60,14 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     for (int i = tid; i < (POUTP - POUT) * ES; i += NTH) Ds[POUT * ES + i] = 0.f;
     // stem filter as MFMA "A" fragments: lane (channel r16 of tile nt, k-slot g): k = 16*kc + 4*g + q < 27
     f32x4 wa[2][2];
-    int koff[2][4];                     // LDS offset of patch element k inside the image planes (-1: zero pad)
+    int koff[2][4];                     // LDS offset of patch element k inside the image planes
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = 16 * kc + 4 * g + q;
             const int ci = k / 9, rr = k % 9;
-            koff[kc][q] = k < 27 ? ci * IT * ITS + (rr / 3) * ITS + rr % 3 : -1;
+            koff[kc][q] = k < 27 ? ci * IT * ITS + (rr / 3) * ITS + rr % 3 : 0;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) wa[nt][kc][q] = k < 27 ? w0[k * 32 + nt * 16 + r16] : 0.f;
         }
@@ -174,8 +174,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = im[base + (koff[kc][q] >= 0 ? koff[kc][q] : 0)];
-                    bv[kc][q] = koff[kc][q] >= 0 ? v : 0.f;
+                    bv[kc][q] = im[base + koff[kc][q]];          // padded k slots (27..31) read element 0: their filter taps are 0
                 }
             f32x4 e0 = sh0, e1 = sh1;
 #pragma unroll
@@ -186,30 +185,31 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                     e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kc][q], bv[kc][q], e1, 0, 0, 0);
                 }
             // lane owns pixel p, channels 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
-            *(f32x4 *)&Es[p * ES + 4 * g] = r6(e0);
-            *(f32x4 *)&Es[p * ES + 16 + 4 * g] = r6(e1);
+            // stem pixels of the halo ring outside the 60x60 map are the depthwise stage's zero padding: clamp them to
+            // [0, 0] instead of [0, 6] (the ceiling is a per-lane value, so the padding costs nothing downstream)
+            const float hi = ((unsigned)(fy0 + p / FT) < 60u && (unsigned)(fx0 + p % FT) < 60u) ? 6.0f : 0.0f;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = __builtin_amdgcn_fmed3f(e0[e], 0.0f, hi); v1[e] = __builtin_amdgcn_fmed3f(e1[e], 0.0f, hi); }
+            *(f32x4 *)&Es[p * ES + 4 * g] = v0;
+            *(f32x4 *)&Es[p * ES + 16 + 4 * g] = v1;
         }
         __syncthreads();
         // ---- depthwise 3x3 s1 on the stem tile: thread = (channel quad, output column, row half) ----
-        // column taps outside the 60x60 map are folded into the thread's filter copy, rows outside load as 0
+        // (out-of-map taps read the zeros the stem epilogue wrote)
         if (!(ablate & 4) && tid < 8 * T * 2) {
             const int c4 = tid & 7, q2 = tid >> 3;
             const int oxl = q2 % T, seg = q2 / T;
-            const int fxb = fx0 + oxl;                                   // stem x of tap kx = 0
             f32x4 w[9];
 #pragma unroll
             for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&WD[k * 32 + 4 * c4];
-            if (fxb < 0) { w[0] = z4; w[3] = z4; w[6] = z4; }
-            if (fxb + 2 >= 60) { w[2] = z4; w[5] = z4; w[8] = z4; }
             const f32x4 sh = *(const f32x4 *)&WD[320 + 4 * c4];
             f32x4 rb[3][3];
             auto load_row = [&](int ly, f32x4(&dst)[3]) {               // ly = tile row (always inside the 12x12 tile)
-                const bool ok = (unsigned)(fy0 + ly) < 60u;
                 const float *er = Es + (ly * FT + oxl) * ES + 4 * c4;
                 dst[0] = *(const f32x4 *)(er);
                 dst[1] = *(const f32x4 *)(er + ES);
                 dst[2] = *(const f32x4 *)(er + 2 * ES);
-                if (!ok) { dst[0] = z4; dst[1] = z4; dst[2] = z4; }
             };
 #pragma unroll
             for (int r = 0; r < T / 2; ++r) {
