@@ -60,8 +60,11 @@ struct BlockCfg {
     static constexpr int IH = WHOLE ? HIN : (TH - 1) * S + 3, IW = WHOLE ? HIN : (TW - 1) * S + 3;   // input tile
     static constexpr int PIN = NF * IH * IW, PINP = rup(PIN, 16);
     static constexpr int POUT = NF * TH * TW, POUTP = rup(POUT, 16);
-    static constexpr int CINP = rup(CIN, 16), COUTP = rup(COUT, 16);
-    static constexpr int KCH = CINP / 16, KC3 = HC / 16;                         // k-chunks of expand / project
+    // expand K is walked in chunks of 16 (4 MFMA steps); a trailing half chunk of 8 (CIN = 24) takes 2 steps, with
+    // lane group g holding k = 16*kc + 2g + {0,1} (the host packs the weights of that chunk the same way)
+    static constexpr bool KHALF = (CIN % 16 == 8);
+    static constexpr int CINP = rup(CIN, 8), COUTP = rup(COUT, 16);
+    static constexpr int KCH = cdiv(CINP, 16), KC3 = HC / 16;                    // k-chunks of expand / project
     static constexpr int XS = CINP + 4, ES = HC + 4;                             // LDS row strides (floats)
     static constexpr int NT_E = HC / 16, PT_IN = PINP / 16, PG = cdiv(PT_IN, EPB), JOBS = NT_E * PG;
     static constexpr int JPW = cdiv(JOBS, NW);                                   // expand jobs per wave
@@ -256,7 +259,13 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
 #pragma unroll
                     for (int q = 0; q < C::EPB; ++q) {
                         const int pt = pg * C::EPB + q;
-                        b[q] = *(const f32x4 *)&Xs[((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XS + kc * 16 + 4 * g];
+                        const float *xp = &Xs[((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XS + kc * 16];
+                        if (C::KHALF && kc == C::KCH - 1) {
+                            const float2 h2 = *(const float2 *)(xp + 2 * g);
+                            b[q] = (f32x4){h2.x, h2.y, 0.f, 0.f};
+                        } else {
+                            b[q] = *(const f32x4 *)(xp + 4 * g);
+                        }
                     }
                 };
                 auto lda = [&](int kc) -> f32x4 {
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(C::NW * 64) void fused_block_kernel(
                     if (kc + 1 < C::KCH) { ldb(kc + 1, bn); an = lda(kc + 1); }
                     // unconditional: a ragged last group multiplies a clamped (duplicate) pixel tile, never stored
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < ((C::KHALF && kc == C::KCH - 1) ? 2 : 4); ++s)
 #pragma unroll
                         for (int q = 0; q < C::EPB; ++q)
                             ea[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[s], bc[q][s], ea[q], 0, 0, 0);

@@ -481,7 +481,11 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
                 for (int kc = 0; kc < kch; ++kc)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int q = 0; q < 4; ++q) {
-                            const int nn = nt * 16 + (lane & 15), kk = kc * 16 + 4 * (lane >> 4) + q;
+                            // a trailing half chunk (cin % 16 == 8: the CIN = 24 expand layers) is walked in 2 MFMA steps:
+                            // lane group g holds k = 16*kc + 2g + {0,1}, slots 2,3 unused (fused_block.hip, KHALF)
+                            const bool half = (L.cin % 16 == 8) && kc == kch - 1;
+                            const int nn = nt * 16 + (lane & 15);
+                            const int kk = half ? (q < 2 ? kc * 16 + 2 * (lane >> 4) + q : L.cin) : kc * 16 + 4 * (lane >> 4) + q;
                             dp[(((size_t)nt * kch + kc) * 64 + lane) * 4 + q] =
                                 (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] * bn_scale[nn] : 0.f;
                         }
