@@ -18,6 +18,8 @@
 namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int T = 10;                 // output tile edge (60 = 6 tiles)
@@ -31,6 +33,8 @@ constexpr int NTH = 256;
 constexpr int ROWDW = 20;             // dwords per uint8 patch row (covers 3 lead bytes + 75 + tail)
 constexpr int U8_IPT = (IT * ROWDW + NTH - 1) / NTH;      // 2 dword loads per thread per tile
 constexpr int F32_IPT = (3 * IT * IT + NTH - 1) / NTH;    // 8 scalar loads per thread per tile
+// LDS offset of im2col element k = ci*9 + ky*3 + kx inside the image planes (padded slots 27..31 read element 0)
+constexpr int koff_of(int k) { return k < 27 ? (k / 9) * IT * ITS + ((k % 9) / 3) * ITS + k % 3 : 0; }
 __device__ __forceinline__ float r6(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 __device__ __forceinline__ f32x4 r6(f32x4 v) {
     f32x4 r;
@@ -40,9 +44,13 @@ __device__ __forceinline__ f32x4 r6(f32x4 v) {
 }
 }  // namespace
 
-template <bool U8>
+// BF: (uint8 crops only) the stem GEMM runs on the bf16 matrix pipe.  A normalised uint8 pixel (2x - 255) / 256 has 8
+// significant bits, i.e. it IS a bf16 number, so only the filter needs the exact 3-way split (w0b3): 3 MFMAs of K = 32
+// per (16 pixels x 16 channels) instead of 8 fp32-input MFMAs of K = 4, products exact, fp32 accumulation.
+template <bool U8, bool BF>
 __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     const float *__restrict__ img, const uint8_t *__restrict__ img8, const float *__restrict__ w0 /*[27][32]*/,
+    const unsigned *__restrict__ w0b3 /*[2][3][64][4]*/,
     const float *__restrict__ s0, const float *__restrict__ b0, const float *__restrict__ wd /*[9][32]*/,
     const float *__restrict__ sd, const float *__restrict__ bd, const float *__restrict__ wp /*Wpk[1][2][64][4]*/,
     const float *__restrict__ sp, const float *__restrict__ bp, float *__restrict__ Y, int total_tiles, int ablate) {
@@ -60,17 +68,26 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     for (int i = tid; i < (POUTP - POUT) * ES; i += NTH) Ds[POUT * ES + i] = 0.f;
     // stem filter as MFMA "A" fragments: lane (channel r16 of tile nt, k-slot g): k = 16*kc + 4*g + q < 27
     f32x4 wa[2][2];
+    u32x4 wb[2][3];                     // BF: filter pieces (h, m, l) of the two channel tiles
     int koff[2][4];                     // LDS offset of patch element k inside the image planes
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int k = 16 * kc + 4 * g + q;
-            const int ci = k / 9, rr = k % 9;
-            koff[kc][q] = k < 27 ? ci * IT * ITS + (rr / 3) * ITS + rr % 3 : 0;
+            const int j = 4 * kc + q;
+            const int k = BF ? 8 * g + j : 16 * kc + 4 * g + q;                // BF: lane group g holds k = 8g .. 8g+7
+            koff[kc][q] = BF ? (g == 0 ? koff_of(j) : g == 1 ? koff_of(8 + j) : g == 2 ? koff_of(16 + j) : koff_of(24 + j))
+                             : (g == 0 ? koff_of(16 * kc + q) : g == 1 ? koff_of(16 * kc + 4 + q)
+                                : g == 2 ? koff_of(16 * kc + 8 + q) : koff_of(16 * kc + 12 + q));
+            if (!BF)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) wa[nt][kc][q] = k < 27 ? w0[k * 32 + nt * 16 + r16] : 0.f;
+                for (int nt = 0; nt < 2; ++nt) wa[nt][kc][q] = k < 27 ? w0[k * 32 + nt * 16 + r16] : 0.f;
         }
+    if (BF)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) wb[nt][pc] = *(const u32x4 *)(w0b3 + ((nt * 3 + pc) * 64 + lane) * 4);
     // BN scales are folded into the filters by the host; accumulators start at the BN shift
     const f32x4 sh0 = *(const f32x4 *)&b0[4 * g], sh1 = *(const f32x4 *)&b0[16 + 4 * g];
     const f32x4 pa0 = *(const f32x4 *)(wp + lane * 4), pa1 = *(const f32x4 *)(wp + 256 + lane * 4);
@@ -177,13 +194,32 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                     bv[kc][q] = im[base + koff[kc][q]];          // padded k slots (27..31) read element 0: their filter taps are 0
                 }
             f32x4 e0 = sh0, e1 = sh1;
+            if (BF) {
+                // the pixel values are exact bf16 numbers: pack their high halves, two k per dword (even k low)
+                unsigned bw[8];
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][kc][q], bv[kc][q], e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kc][q], bv[kc][q], e1, 0, 0, 0);
+                for (int e = 0; e < 8; ++e) {
+                    const float t = bv[e >> 2][e & 3];      // (bit_cast applied to a vector-element lvalue reads element 0)
+                    bw[e] = __builtin_bit_cast(unsigned, t);
                 }
+                u32x4 bb;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) bb[d] = __builtin_amdgcn_perm(bw[2 * d + 1], bw[2 * d], 0x07060302u);
+                const bf16x8 b8 = __builtin_bit_cast(bf16x8, bb);
+#pragma unroll
+                for (int pc = 2; pc >= 0; --pc) {          // smallest filter piece first
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[0][pc]), b8, e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wb[1][pc]), b8, e1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][kc][q], bv[kc][q], e0, 0, 0, 0);
+                        e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kc][q], bv[kc][q], e1, 0, 0, 0);
+                    }
+            }
             // lane owns pixel p, channels 4g..4g+3 (tile 0) and 16+4g.. (tile 1)
             // stem pixels of the halo ring outside the 60x60 map are the depthwise stage's zero padding: clamp them to
             // [0, 0] instead of [0, 6] (the ceiling is a per-lane value, so the padding costs nothing downstream)
@@ -249,7 +285,7 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     }
 }
 
-void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, const float *s0, const float *b0,
+void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, const unsigned *w0b3, const float *s0, const float *b0,
                         const float *wd, const float *sd, const float *bd, const float *wp, const float *sp,
                         const float *bp, float *Y, int B, hipStream_t s) {
     const int total = B * 36;
@@ -257,8 +293,9 @@ void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, 
     // layer would only start when the first two finish (measured 361 -> 322 us at B = 1024 going from 3 to 2)
     const int grid = total < 256 * 2 ? total : 256 * 2;
     static const int ablate = getenv("SYN_ABLATE_STEM") ? atoi(getenv("SYN_ABLATE_STEM")) : 0;   // profiling only: skip stages
-    if (img8) stem_block1_kernel<true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
-    else      stem_block1_kernel<false><<<grid, NTH, 0, s>>>(img, nullptr, w0, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    if (img8 && w0b3) stem_block1_kernel<true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    else if (img8)    stem_block1_kernel<true, false><<<grid, NTH, 0, s>>>(nullptr, img8, w0, nullptr, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    else              stem_block1_kernel<false, false><<<grid, NTH, 0, s>>>(img, nullptr, w0, nullptr, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
 }
 
 }  // namespace syn

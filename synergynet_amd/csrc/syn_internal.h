@@ -52,7 +52,7 @@ bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 
 // features.0 + features.1 fused (stem_block1.hip): image -> NHWC [B,60,60,16].
-void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w0, const float *s0,
+void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w0, const unsigned *w0b3, const float *s0,
                         const float *b0, const float *wd, const float *sd, const float *bd, const float *wp_pk,
                         const float *sp, const float *bp, float *Y, int B, hipStream_t s);
 

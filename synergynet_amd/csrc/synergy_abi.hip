@@ -116,6 +116,10 @@ struct Net {
                 L.dst_wb3 = dst;
                 dst += (size_t)round_up(L.cout, 16) * L.cin * 3 / 2;      // 3 bf16 per weight
             }
+            if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
+                L.dst_wb3 = dst;
+                dst += 2 * 3 * 64 * 4;
+            }
             const double pix = (double)L.hout * L.hout;
             const double f2 = L.kind == STEM ? 2.0 * 27 * 32 * pix : L.kind == DW ? 2.0 * 9 * L.cout * pix
                                                                                    : 2.0 * L.cin * (double)L.cout * pix;
@@ -306,7 +310,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused network head: stem conv + features.1 (dw + linear project) in one launch
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            syn::launch_stem_block1(img, img8, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
+            syn::launch_stem_block1(img, img8, P + L.dst_wpk, h->fusion >= 2 ? reinterpret_cast<const unsigned *>(P + L.dst_wb3) : nullptr, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                     P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, X, B, s);
             li += 2;
             mark(1);
@@ -490,7 +494,25 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
                                 (nn < L.cout && kk < L.cin) ? w[(size_t)nn * L.cin + kk] * bn_scale[nn] : 0.f;
                         }
         }
-        if (L.dst_wb3) {                 // [N][K] -> [n_tile][k32 chunk][piece][lane][4 dwords], BN scale folded in
+        if (L.dst_wb3 && L.kind == STEM) {   // K = 27 (ci*9 + ky*3 + kx) padded to one k32 chunk; lane (r16, g): k = 8g + e
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wb3);
+            for (int nt = 0; nt < 2; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                        const int co = nt * 16 + (lane & 15);
+                        for (int e = 0; e < 2; ++e) {
+                            const int k = 8 * (lane >> 4) + 2 * d + e;
+                            float x = k < 27 ? w[co * 27 + k] * bn_scale[co] : 0.f;
+                            for (int i = 0; i < 3; ++i) {
+                                unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                                float hf; memcpy(&hf, &u, 4);
+                                pc[e][i] = u >> 16; x -= hf;
+                            }
+                        }
+                        for (int i = 0; i < 3; ++i) dp[((size_t)(nt * 3 + i) * 64 + lane) * 4 + d] = pc[0][i] | (pc[1][i] << 16);
+                    }
+        } else if (L.dst_wb3) {          // [N][K] -> [n_tile][k32 chunk][piece][lane][4 dwords], BN scale folded in
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wb3);
             auto split = [](float x, unsigned (&pc)[3]) {
                 for (int i = 0; i < 3; ++i) {

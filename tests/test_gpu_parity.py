@@ -92,7 +92,15 @@ def test_u8_ingest_equals_fp32_ingest(model, golden):
     from synergynet_amd import synth
     p8 = model.forward_crops_u8(golden['crops_u8'])
     pf = model.forward_test(torch.from_numpy(synth.normalize_crops(golden['crops_u8'])).cuda())
-    assert np.array_equal(p8.cpu().numpy(), pf.cpu().numpy())     # same arithmetic, bit-identical
+    # the uint8 path against the REAL reference's output (golden), at the stated tolerance
+    assert rel_max(p8.cpu().numpy(), golden['param_net']) < TOL
+    assert rel_l2(p8.cpu().numpy(), golden['param_net']) < TOL
+    if model._test_fusion == '2':
+        # bf16x3 schedule: the uint8 stem runs on the bf16 matrix pipe (normalised uint8 pixels are exact bf16
+        # numbers, the filter is split exactly 3-way) while fp32 crops take the fp32 MFMA -> equal to fp32 rounding
+        assert rel_max(p8.cpu().numpy(), pf.cpu().numpy()) < 1e-5
+    else:
+        assert np.array_equal(p8.cpu().numpy(), pf.cpu().numpy())     # same arithmetic, bit-identical
 
 
 @pytest.mark.parametrize('B', [1, 5, 33, 70])
