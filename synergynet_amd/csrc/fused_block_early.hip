@@ -1,0 +1,355 @@
+// Fused inverted-residual block for the EARLY MobileNetV2 blocks (features.2-4: 60x60 / 30x30 maps, 16-32 channels in,
+// 96-144 hidden) with both 1x1 GEMMs on the bf16 matrix pipe at fp32-equivalent accuracy (exact 3-way operand split,
+// see fused_block_bf3.hip).  Reference: backbone_nets/mobilenetv2_backbone.py:33-70 (InvertedResidual.forward).
+//
+// These blocks are spatially tiled (halo ring recomputed) and their weights are tiny, so the dataflow differs from the
+// late blocks:
+//   * a workgroup is PERSISTENT; all weights of the block live in LDS, already split and in MFMA lane order;
+//   * every wave OWNS pixel tiles of the input tile: it loads their channels straight from global memory into
+//     registers (next tile prefetched while the current one computes), splits them into the three bf16 pieces ONCE per
+//     tile and keeps them as the MFMA "B" operand for every hidden channel tile of every chunk -- the block input
+//     never touches LDS and the expand stage issues no LDS operand read besides the (wave-broadcast) weight fragments;
+//   * expand  E = ReLU6(X . We^T + b)   -> LDS fp32  (out-of-image halo pixels written as 0: the ReLU ceiling trick)
+//     depthwise D = ReLU6(dw3x3(E) + b)  -> LDS, split into three bf16 planes on the way out
+//     project  acc += D . Wp[:, chunk]^T -> fp32 accumulators in registers (K of a chunk padded to a multiple of 32)
+//   With the fp32-input MFMA gone, the vector pipe only carries the depthwise FMAs, the splits and the epilogues; the
+//   matrix pipe runs the GEMMs concurrently (fp32-input MFMAs were 50-85% of these blocks' time before).
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int cdive(int a, int b) { return (a + b - 1) / b; }
+constexpr int rupe(int a, int b) { return cdive(a, b) * b; }
+// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
+__device__ __forceinline__ void split2e(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x4 mfmae(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six partial products of weight >= 2^-16 of one (channel tile, pixel tile, k32 chunk), smallest terms first
+__device__ __forceinline__ f32x4 mac6e(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+    c = mfmae(a[2], b[0], c);
+    c = mfmae(a[0], b[2], c);
+    c = mfmae(a[1], b[1], c);
+    c = mfmae(a[1], b[0], c);
+    c = mfmae(a[0], b[1], c);
+    c = mfmae(a[0], b[0], c);
+    return c;
+}
+}  // namespace
+
+#define SYNE_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+
+template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int TH_, int TW_, int NW_, int NG_, int WN_, int WP_>
+struct EarlyCfg {
+    static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, TH = TH_, TW = TW_, NW = NW_, NG = NG_, WN = WN_, WP = WP_;
+    static constexpr int GW = NW / NG, GT = GW * 64;            // waves / threads of one group (a group works on its own tile)
+    static constexpr bool RES = RES_;
+    static constexpr int HC = early_block_hc(HID_);             // hidden chunk (shared with the host packer)
+    static constexpr int HCP = rupe(HC, 32), KP = HCP / 32;     // project K per chunk, padded to k32 steps
+    static constexpr int NCH = HID / HC;
+    static constexpr int NT = NW * 64;
+    static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
+    static constexpr int TILES_Y = cdive(HOUT, TH), TILES_X = cdive(HOUT, TW);
+    static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    static constexpr int PIN = IH * IW, PINP = rupe(PIN, 16), PT_IN = PINP / 16;
+    static constexpr int POUT = TH * TW, POUTP = rupe(POUT, 16), PT_O = POUTP / 16;
+    static constexpr int PPW = cdive(PT_IN, GW);                // input pixel tiles owned by a wave
+    static constexpr int COUTP = rupe(COUT, 16), NT_O = COUTP / 16, NT_E = HC / 16;
+    static constexpr int AN = cdive(NT_O, WN), AP = cdive(PT_O, WP);
+    static constexpr int ES = HC + 4, DSD = HCP / 2 + 4, DPL = POUTP * DSD;
+    // depthwise stage mapping: thread = (channel quad, output column, row segment)
+    static constexpr int C4N = HC / 4;
+    static constexpr int RS_ = GT / (C4N * TW);
+    static constexpr int RS = RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_);
+    static constexpr int RPS = cdive(TH, RS), DW_THREADS = C4N * TW * cdive(TH, RPS);
+    // LDS carve (dwords)
+    static constexpr int ES_DW = PINP * ES, DB_DW = 3 * DPL;
+    static constexpr int WE_DW = (HID / 16) * 768, WP_DW = NT_O * NCH * KP * 768, WD_DW = 11 * HID;
+    static constexpr int LDS_DWORDS = NG * (ES_DW + DB_DW) + WE_DW + WP_DW + WD_DW + HID;
+    static_assert(CIN <= 32 && CIN % 8 == 0, "one k32 step of expand, whole 8-channel lane groups");
+    static_assert(HID % HC == 0 && HC % 16 == 0, "hidden chunking");
+    static_assert(NW % NG == 0 && WN * WP == GW, "wave grid of a group");
+    static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
+    static_assert(HOUT % TH == 0 && HOUT % TW == 0, "whole tiles");
+    static_assert(LDS_DWORDS * 4 <= 160 * 1024, "LDS budget");
+};
+
+template <class C, bool PROF = false>
+__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(cdive(C::NW, 4), cdive(C::NW, 4))))
+void fused_block_early_kernel(
+    const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][3][64][4]*/, const float *__restrict__ e_shift,
+    const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
+    const unsigned *__restrict__ Wp3 /*[NT_O][NCH*KP][3][64][4]*/, const float *__restrict__ p_shift,
+    float *__restrict__ Y, int B, int total_tiles, unsigned long long *prof = nullptr) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
+    constexpr int NT = C::NT, GT = C::GT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave / C::GW, gw = wave % C::GW, gtid = tid % GT;     // group, wave / thread inside the group
+    float *Es = reinterpret_cast<float *>(smem) + grp * C::ES_DW;         // per group: [PINP][ES] fp32
+    unsigned *Db = smem + C::NG * C::ES_DW + grp * C::DB_DW;              // per group: 3 planes [POUTP][DSD]
+    unsigned *Wle = smem + C::NG * (C::ES_DW + C::DB_DW), *Wlp = Wle + C::WE_DW;
+    float *Wds = reinterpret_cast<float *>(Wlp + C::WP_DW);               // [11][HID]: 9 taps | (unused) | shift
+    float *Ebn = Wds + C::WD_DW;                                          // [HID] expand BN shift
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wn = gw % C::WN, wp = gw / C::WN;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, ntiles_done = 0;
+
+    // this wave's input pixel tiles of tile `tile` -> registers (8 channels 8g..8g+7 of pixel pt*16 + r16; zero outside
+    // the image, past CIN and past the tile)
+    f32x4 xr[C::PPW][2];
+    auto load_x = [&](int tile) {
+        const int tx = tile % C::TILES_X, ty = (tile / C::TILES_X) % C::TILES_Y, f = tile / (C::TILES_X * C::TILES_Y);
+        const int iy0 = ty * C::TH * C::S - 1, ix0 = tx * C::TW * C::S - 1;
+#pragma unroll
+        for (int i = 0; i < C::PPW; ++i) {
+            const int p = (gw + i * C::GW) * 16 + r16;
+            const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
+            xr[i][0] = z4; xr[i][1] = z4;
+            if (p < C::PIN && 8 * g < C::CIN && (unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) {
+                const float *src = &X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 8 * g];
+                xr[i][0] = *(const f32x4 *)src;
+                xr[i][1] = *(const f32x4 *)(src + 4);
+            }
+        }
+    };
+
+    // groups take alternate tiles; every wave of the workgroup runs the same number of iterations (and barriers): a
+    // group without a tile in the last round skips the work only
+    const int stride = gridDim.x * C::NG;
+    const int n_iter = (total_tiles - (int)blockIdx.x * C::NG + stride - 1) / stride;
+    int tile = blockIdx.x * C::NG + grp;
+    if (tile < total_tiles) load_x(tile);
+    // ---- once per (persistent) workgroup: all weights of the block -> LDS; the D planes start as zeros ----
+    for (int i = tid; i < C::WE_DW / 4; i += NT) *(u32x4 *)&Wle[4 * i] = *(const u32x4 *)&We3[4 * i];
+    for (int i = tid; i < C::WP_DW / 4; i += NT) *(u32x4 *)&Wlp[4 * i] = *(const u32x4 *)&Wp3[4 * i];
+    for (int i = tid; i < 11 * C::HID / 4; i += NT) {
+        const int row = i / (C::HID / 4), c4 = i % (C::HID / 4);
+        f32x4 v = z4;
+        if (row < 9) v = *(const f32x4 *)&Wd[row * C::HID + 4 * c4];
+        else if (row == 10) v = *(const f32x4 *)&d_shift[4 * c4];
+        *(f32x4 *)&Wds[row * C::HID + 4 * c4] = v;
+    }
+    for (int i = tid; i < C::HID / 4; i += NT) *(f32x4 *)&Ebn[4 * i] = *(const f32x4 *)&e_shift[4 * i];
+    for (int i = gtid; i < C::DB_DW / 4; i += GT) *(u32x4 *)&Db[4 * i] = (u32x4){0u, 0u, 0u, 0u};  // pad rows / pad K columns stay 0
+    f32x4 psh[C::AN];
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i) {
+        const int n = (wn + i * C::WN) * 16 + 4 * g;
+        psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
+    }
+    __syncthreads();
+    // Two groups run the same barrier-separated stage sequence [project(c-1) expand(c)] | [depthwise(c)] | ... one stage
+    // apart: while one group's waves feed the matrix pipe (expand / project), the other group's waves on the same SIMDs
+    // run the depthwise stage on the VALU.  (s_barrier only counts arrivals, so the groups may sit at different barriers.)
+    if (C::NG == 2 && grp == 1) __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it, tile += stride) {
+        const bool live = tile < total_tiles;
+        const int tx = tile % C::TILES_X, ty = (tile / C::TILES_X) % C::TILES_Y, f = tile / (C::TILES_X * C::TILES_Y);
+        const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+        const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;             // image coords of input-tile pixel (0,0)
+
+        // ---- stage 0: split this wave's pixel tiles into bf16 pieces (registers); prefetch the next tile ----
+        u32x4 xb[C::PPW][3];
+        float ehi[C::PPW];             // ReLU6 ceiling of the hidden pixel: 6 inside the image, 0 on the zero-padding ring
+#pragma unroll
+        for (int i = 0; i < C::PPW; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 v = xr[i][h];
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2e(v[0], v[1], h0, m0, l0);
+                split2e(v[2], v[3], h1, m1, l1);
+                xb[i][0][2 * h] = h0; xb[i][0][2 * h + 1] = h1;
+                xb[i][1][2 * h] = m0; xb[i][1][2 * h + 1] = m1;
+                xb[i][2][2 * h] = l0; xb[i][2][2 * h + 1] = l1;
+            }
+            const int p = (gw + i * C::GW) * 16 + r16;
+            const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
+            ehi[i] = ((unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) ? 6.0f : 0.0f;
+        }
+        if (tile + stride < total_tiles) load_x(tile + stride);
+        SYNE_LAP(0);
+
+        f32x4 acc[C::AN][C::AP];
+#pragma unroll
+        for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+            for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];        // BN shift = accumulator start
+
+        for (int c = 0; c < C::NCH; ++c) {
+            const int hc0 = c * C::HC;
+            // ---- stage 1: expand 1x1 (bf16 x3) + BN shift + ReLU6 -> Es (fp32); operands: LDS weights x registers ----
+#pragma unroll
+            for (int nt = 0; nt < C::NT_E; ++nt) {
+                u32x4 a[3];
+                const unsigned *wa = Wle + (size_t)(hc0 / 16 + nt) * 768 + lane * 4;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *(const u32x4 *)(wa + p * 256);
+                const f32x4 sh = *(const f32x4 *)&Ebn[hc0 + nt * 16 + 4 * g];
+#pragma unroll
+                for (int i = 0; i < C::PPW; ++i) {
+                    const int pt = gw + i * C::GW;
+                    if (pt >= C::PT_IN || !live) break;                 // wave-uniform
+                    const f32x4 e = mac6e(a, xb[i], sh);
+                    f32x4 ev;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ev[q] = __builtin_amdgcn_fmed3f(e[q], 0.0f, ehi[i]);
+                    *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = ev;
+                }
+            }
+            SYNE_LAP(1);
+            __syncthreads();
+            SYNE_LAP(2);
+            // ---- stage 2: depthwise 3x3 + BN shift + ReLU6 (fp32 VALU), output split into bf16 x3 planes ----
+            // thread = (channel quad, output column, row segment); 3-row sliding window.  Zero padding needs no code:
+            // hidden pixels outside the image were written as zeros by stage 1.
+            for (int t = live ? gtid : C::DW_THREADS; t < C::DW_THREADS; t += GT) {
+                const int c4 = t % C::C4N, q = t / C::C4N;
+                const int oxl = q % C::TW, seg = q / C::TW;
+                f32x4 w[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&Wds[k * C::HID + hc0 + 4 * c4];
+                const f32x4 sh = *(const f32x4 *)&Wds[10 * C::HID + hc0 + 4 * c4];
+                const float *ebase = Es + (oxl * C::S) * C::ES + 4 * c4;
+                f32x4 rb[3][3];
+                auto load_row = [&](int ly, f32x4(&dst)[3]) {
+                    const float *er = ebase + ly * C::IW * C::ES;
+                    dst[0] = *(const f32x4 *)(er);
+                    dst[1] = *(const f32x4 *)(er + C::ES);
+                    dst[2] = *(const f32x4 *)(er + 2 * C::ES);
+                };
+#pragma unroll
+                for (int r = 0; r < C::RPS; ++r) {
+                    const int oyl = seg * C::RPS + r;
+                    if (oyl >= C::TH) break;
+                    const int lyb = oyl * C::S;                          // input-tile row of tap ky = 0
+                    if (r == 0) {
+                        load_row(lyb, rb[0]); load_row(lyb + 1, rb[1]); load_row(lyb + 2, rb[2]);
+                    } else if (C::S == 1) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { rb[0][k] = rb[1][k]; rb[1][k] = rb[2][k]; }
+                        load_row(lyb + 2, rb[2]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) rb[0][k] = rb[2][k];
+                        load_row(lyb + 1, rb[1]); load_row(lyb + 2, rb[2]);
+                    }
+                    f32x4 a = sh;
+                    a += rb[0][0] * w[0]; a += rb[0][1] * w[1]; a += rb[0][2] * w[2];
+                    a += rb[1][0] * w[3]; a += rb[1][1] * w[4]; a += rb[1][2] * w[5];
+                    a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = __builtin_amdgcn_fmed3f(a[e], 0.0f, 6.0f);
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split2e(a[0], a[1], h0, m0, l0);
+                    split2e(a[2], a[3], h1, m1, l1);
+                    const int dofs = (oyl * C::TW + oxl) * C::DSD + 2 * c4;
+                    *(u32x2 *)&Db[0 * C::DPL + dofs] = (u32x2){h0, h1};
+                    *(u32x2 *)&Db[1 * C::DPL + dofs] = (u32x2){m0, m1};
+                    *(u32x2 *)&Db[2 * C::DPL + dofs] = (u32x2){l0, l1};
+                }
+            }
+            SYNE_LAP(3);
+            __syncthreads();
+            SYNE_LAP(4);
+            // ---- stage 3: project 1x1 (bf16 x3), K = this hidden chunk (zero padded to k32 steps) ----
+            if (live)
+#pragma unroll
+            for (int kc = 0; kc < C::KP; ++kc) {
+                u32x4 b[C::AP][3];
+#pragma unroll
+                for (int j = 0; j < C::AP; ++j) {
+                    const int pt = wp + j * C::WP;
+                    const int row = ((pt < C::PT_O ? pt : 0) * 16 + r16) * C::DSD + kc * 16 + 4 * g;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
+                }
+#pragma unroll
+                for (int i = 0; i < C::AN; ++i) {
+                    int nt = wn + i * C::WN;
+                    nt = nt < C::NT_O ? nt : 0;
+                    u32x4 a[3];
+                    const unsigned *wa = Wlp + ((size_t)(nt * C::NCH + c) * C::KP + kc) * 768 + lane * 4;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *(const u32x4 *)(wa + p * 256);
+#pragma unroll
+                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6e(a, b[j], acc[i][j]);
+                }
+            }
+            SYNE_LAP(5);
+            // no barrier: the next stage 1 only writes Es (its readers finished before the barrier above); the D planes
+            // are rewritten only after the next barrier, which every wave reaches after this stage
+        }
+
+        // ---- epilogue: (+ residual, re-read from global: the block input is L2-hot) and NHWC store ----
+#pragma unroll
+        for (int i = 0; i < C::AN; ++i) {
+            const int nt = wn + i * C::WN;
+            const int n = nt * 16 + 4 * g;
+            if (nt >= C::NT_O || n >= C::COUT) continue;
+#pragma unroll
+            for (int j = 0; j < C::AP; ++j) {
+                const int pt = wp + j * C::WP;
+                const int po = pt * 16 + r16;
+                if (pt >= C::PT_O || po >= C::POUT || !live) continue;
+                const int oy = oy0 + po / C::TW, ox = ox0 + po % C::TW;
+                f32x4 v = acc[i][j];
+                const size_t o = ((size_t)(f * C::HOUT + oy) * C::HOUT + ox) * C::COUT + n;
+                if (C::RES) v += *(const f32x4 *)&X[o];                 // x + conv(x): same shape, same index
+                *(f32x4 *)&Y[o] = v;
+            }
+        }
+        ntiles_done += live ? 1 : 0;
+        SYNE_LAP(6);
+    }
+    if (C::NG == 2 && grp == 0) __syncthreads();
+    if (PROF && gtid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], ntiles_done);
+    }
+}
+
+template <class C>
+static void launch_early(const FusedBlockArgs &a, int B, hipStream_t s) {
+    const int total = B * C::TILES_X * C::TILES_Y;
+    const int wgs = (total + C::NG - 1) / C::NG;
+    const int grid = wgs < 256 ? wgs : 256;            // persistent: one workgroup per CU
+    if (a.prof)
+        fused_block_early_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, total, a.prof);
+    else
+        fused_block_early_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, total);
+}
+
+//                       CIN  HID COUT HIN S  RES   TH  TW  NW NG WN WP
+using E2 = EarlyCfg<  16,  96,  24, 60, 2, false, 10, 10, 8, 1, 2, 4>;    // features.2   60 -> 30
+using E3 = EarlyCfg<  24, 144,  24, 30, 1, true,  10, 10, 8, 1, 2, 4>;    // features.3   30
+using E4 = EarlyCfg<  24, 144,  32, 30, 2, false,  5,  5, 8, 2, 2, 2>;    // features.4   30 -> 15
+
+bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
+    if (!a.We3 || !a.Wp3) return false;
+    switch (feature) {
+        case 2: launch_early<E2>(a, B, s); return true;
+        case 3: launch_early<E3>(a, B, s); return true;
+        case 4: launch_early<E4>(a, B, s); return true;
+        default: return false;
+    }
+}
+
+}  // namespace syn

@@ -48,6 +48,10 @@ struct FusedBlockArgs {
     const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of
+// early_block_hc(HID) channels, each zero padded to a multiple of 32 in the project GEMM's K: the host packs Wp3 that way.
+constexpr int early_block_hc(int hid) { return hid % 32 == 0 ? 32 : 48; }
+bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 

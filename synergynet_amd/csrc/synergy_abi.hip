@@ -116,6 +116,14 @@ struct Net {
                 L.dst_wb3 = dst;
                 dst += (size_t)round_up(L.cout, 16) * L.cin * 3 / 2;      // 3 bf16 per weight
             }
+            if (L.kind == PW && L.feature >= 2 && L.feature <= 4) {
+                // early blocks: expand K (16 / 24) zero padded to one k32 step; project K = hidden chunks of
+                // early_block_hc() channels, each padded to k32 steps (fused_block_early.hip)
+                L.dst_wb3 = dst;
+                const int hc = L.relu6 ? L.cin : syn::early_block_hc(L.cin);
+                const int steps = (L.relu6 ? 1 : L.cin / hc) * (round_up(hc, 32) / 32);
+                dst += (size_t)(round_up(L.cout, 16) / 16) * steps * 768;
+            }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
                 dst += 2 * 3 * 64 * 4;
@@ -330,7 +338,8 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
             }
-            if ((a.We3 && syn::launch_fused_block_bf3(L.feature, a, B, s)) || syn::launch_fused_block(L.feature, a, B, s)) {
+            if ((a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
+                syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
                 mark(L.feature);
@@ -521,19 +530,25 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
                     pc[i] = u >> 16; x -= hf;
                 }
             };
-            const int ntl = round_up(L.cout, 16) / 16, kch = L.cin / 32;
+            // K is walked as `nch` chunks of `hc` real channels, each zero padded to `hcp` (a multiple of 32):
+            // late blocks hc = hcp = cin; early expand hc = cin (16 / 24), hcp = 32; early project hc = early_block_hc
+            const bool early = L.feature >= 2 && L.feature <= 4;
+            const int hc = !early ? L.cin : (L.relu6 ? L.cin : syn::early_block_hc(L.cin));
+            const int hcp = round_up(hc, 32), nch = L.cin / hc, spc = hcp / 32;     // k32 steps per chunk
+            const int ntl = round_up(L.cout, 16) / 16, kch = nch * spc;
             for (int nt = 0; nt < ntl; ++nt)
-                for (int kc = 0; kc < kch; ++kc)
+                for (int st = 0; st < kch; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            unsigned lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-                            const int nn = nt * 16 + (lane & 15), k0 = kc * 32 + 8 * (lane >> 4) + 2 * d;
-                            if (nn < L.cout) {
-                                split(w[(size_t)nn * L.cin + k0] * bn_scale[nn], lo);
-                                split(w[(size_t)nn * L.cin + k0 + 1] * bn_scale[nn], hi);
+                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            const int nn = nt * 16 + (lane & 15);
+                            for (int e = 0; e < 2; ++e) {
+                                const int within = (st % spc) * 32 + 8 * (lane >> 4) + 2 * d + e;
+                                const int kk = (st / spc) * hc + within;
+                                if (nn < L.cout && within < hc) split(w[(size_t)nn * L.cin + kk] * bn_scale[nn], pc[e]);
                             }
                             for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[(((size_t)(nt * kch + kc) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
+                                dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
         }
         for (int c = 0; c < L.cout; ++c) {
