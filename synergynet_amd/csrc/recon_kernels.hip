@@ -21,6 +21,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store to be
+// acknowledged (vmcnt(0)), which would expose the latency of each face tile's 48 KB of output stores once per iteration.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kFaceRec = 64;   // floats per face in the prepared record: alpha[52] | M[9] | T[3]
 constexpr int kStageStride = 132;  // floats per row of the store-transpose stage: 4 tiles x 32 vertices + pad (16-byte aligned rows)
 
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
             st[kStageStride] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
             st[2 * kStageStride] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
         }
-        __syncthreads();
+        lds_barrier();
         // cooperative store: 32 lanes x float4 = one 512-byte run of one (face, coord) row; 2 rows per instruction
         if (!(ablate & 2)) {
             const int seg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
                 }
             }
         }
-        __syncthreads();   // stage and the M/T slices are rewritten by the next face tile
+        lds_barrier();     // stage and the M/T slices are rewritten by the next face tile
     }
 }
 
@@ -199,6 +203,210 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
     const int grid = ((n_units + 7) / 8) * 8;
     static const int ablate = getenv("SYN_ABLATE_RECON") ? atoi(getenv("SYN_ABLATE_RECON")) : 0;   // profiling only
     recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units, ablate);
+}
+
+// =====================================================================================
+// The same contraction on the bf16 matrix pipe at fp32-equivalent accuracy.
+//
+// Both operands are carried as three bf16 pieces x = h + m + l (exact: 8+8+8 significant bits by truncation; the basis
+// is split by the host, alpha by the prologue kernel) and each block product is rebuilt from the six partial products of
+// weight >= 2^-16 with v_mfma_f32_32x32x16_bf16 (fp32 accumulation, exact products).  K = 48 runs on the MFMA (3 steps of
+// 16, 54 MFMAs of 32 cycles per face tile and wave instead of 78 fp32-input MFMAs of 64 cycles); the last two expression
+// columns are two fp32 FMAs per output in the epilogue and the mean shape u is the accumulator's start value.
+// =====================================================================================
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+__device__ __forceinline__ void split2r(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+}  // namespace
+
+// Prologue: one workgroup (64 lanes) per 32-face tile.  Lane (i = l&31, hh = l>>5) is face f0+i: it de-whitens the 24
+// shape/expression coefficients k = 16*step + 8*hh + e it feeds to the MFMA, splits them and writes them in operand
+// order; lanes hh = 0 also write the face's 16-float record M[9] | T[3] | alpha48 | alpha49 | 0 | 0.
+__global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restrict__ param, const float *__restrict__ mean,
+                                                           const float *__restrict__ stdv, const float *__restrict__ roi,
+                                                           int transform, unsigned *__restrict__ rec3, int B) {
+    const int ft = blockIdx.x, l = threadIdx.x, i = l & 31, hh = l >> 5;
+    const int b = ft * 32 + i;
+    const bool ok = b < B;
+    const float *pp = param + (size_t)(ok ? b : 0) * kParam;
+    unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        u32x4 pc[3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int k = 12 + 16 * ks + 8 * hh + 2 * d;                 // alpha_k = param[12 + k] (parse_param_62)
+            const float a0 = ok ? pp[k] * stdv[k] + mean[k] : 0.f, a1 = ok ? pp[k + 1] * stdv[k + 1] + mean[k + 1] : 0.f;
+            unsigned h, m, lo;
+            split2r(a0, a1, h, m, lo);
+            pc[0][d] = h; pc[1][d] = m; pc[2][d] = lo;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *(u32x4 *)&rt[((ks * 3 + p) * 64 + l) * 4] = pc[p];
+    }
+    if (hh == 0) {
+        float r[16];
+        float p12[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) p12[q] = ok ? pp[q] * stdv[q] + mean[q] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sc = 1.0f, of = 0.0f;
+            if (roi && ok) {
+                const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
+                const float scx = (ex - sx) / 120.0f, scy = (ey - sy) / 120.0f;
+                if (c == 0) { sc = scx; of = sx; }
+                else if (c == 1) { sc = scy; of = sy; }
+                else { sc = (scx + scy) * 0.5f; }
+            }
+            float m0 = p12[4 * c + 0], m1 = p12[4 * c + 1], m2 = p12[4 * c + 2], t = p12[4 * c + 3];
+            if (transform && c == 1) { m0 = -m0; m1 = -m1; m2 = -m2; t = (float)(kImg + 1) - t; }
+            r[3 * c + 0] = m0 * sc; r[3 * c + 1] = m1 * sc; r[3 * c + 2] = m2 * sc;
+            r[9 + c] = t * sc + of;
+        }
+        r[12] = ok ? pp[12 + 48] * stdv[12 + 48] + mean[12 + 48] : 0.f;
+        r[13] = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
+        r[14] = 0.f; r[15] = 0.f;
+        float *rr = reinterpret_cast<float *>(rt + 9 * 256) + i * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(f32x4 *)&rr[4 * q] = (f32x4){r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
+                     int n_vert, int n_tiles, int n_split, int ftiles_per_split, int n_ftiles, int n_units) {
+    __shared__ __attribute__((aligned(16))) float smt[4][32][16];
+    __shared__ __attribute__((aligned(16))) float stage[96 * kStageStride];   // [face*3 + coord][4 tiles x 32 vertices]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
+    const int tg = unit / n_split, split = unit - tg * n_split;
+    int T = tg * 4 + wave;
+    T = T < n_tiles ? T : n_tiles - 1;
+    const int j = lane & 31, h = lane >> 5;
+
+    // resident basis fragments of this vertex tile: 3 coords x 3 k16 steps x 3 pieces, plus columns 48, 49 and the mean
+    u32x4 bb[3][3][3];
+    float b48[3], b49[3], bu[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned *bc = basis3 + ((size_t)T * 3 + c) * kBasisB3;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bb[c][ks][p] = *(const u32x4 *)(bc + ((ks * 3 + p) * 64 + lane) * 4);
+        const float *bx = reinterpret_cast<const float *>(bc + 9 * 256);
+        b48[c] = bx[j]; b49[c] = bx[32 + j]; bu[c] = bx[64 + j];
+    }
+    const int ft0 = split * ftiles_per_split;
+    int ft1 = ft0 + ftiles_per_split;
+    ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
+    float(*mt)[16] = smt[wave];
+    const int v_base = tg * 128;
+
+    for (int ft = ft0; ft < ft1; ++ft) {
+        const int f0 = ft * 32;
+        const unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+        u32x4 aa[2][3];                                                      // alpha pieces, one k16 step ahead
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aa[0][p] = *(const u32x4 *)(rt + (p * 64 + lane) * 4);
+        // the 32 face records of this tile -> the wave's private LDS slice (2 KiB: 64 lanes x 2 float4)
+        {
+            const float *rr = reinterpret_cast<const float *>(rt + 9 * 256);
+            *(f32x4 *)&mt[0][lane * 4] = *(const f32x4 *)(rr + lane * 4);
+            *(f32x4 *)&mt[0][256 + lane * 4] = *(const f32x4 *)(rr + 256 + lane * 4);
+        }
+        f32x16 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = bu[c];                  // mean shape = accumulator start
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 3)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) aa[cur ^ 1][p] = *(const u32x4 *)(rt + (((ks + 1) * 3 + p) * 64 + lane) * 4);
+            // six partial products, smallest first; the three coordinate planes interleave as independent chains
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = mfma32(aa[cur][PA[q]], bb[c][ks][PB[q]], acc[c]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // columns 48, 49 + pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const f32x4 q0 = *(const f32x4 *)&mt[i][0];
+            const f32x4 q1 = *(const f32x4 *)&mt[i][4];
+            const f32x4 q2 = *(const f32x4 *)&mt[i][8];
+            const f32x4 q3 = *(const f32x4 *)&mt[i][12];
+            const float sx = acc[0][r] + q3[0] * b48[0] + q3[1] * b49[0];
+            const float sy = acc[1][r] + q3[0] * b48[1] + q3[1] * b49[1];
+            const float sz = acc[2][r] + q3[0] * b48[2] + q3[1] * b49[2];
+            float *st = stage + (i * 3) * kStageStride + wave * 32 + j;
+            st[0] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
+            st[kStageStride] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
+            st[2 * kStageStride] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);    // keep the record reads of at most two rows in flight (registers)
+        }
+        lds_barrier();
+        {   // cooperative store: 32 lanes x float4 = one 512-byte run of one (face, coord) row; 2 rows per instruction
+            const int seg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+            const int vq = v_base + 4 * seg;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int row = k * 8 + rsub;                 // = face_in_tile * 3 + coord
+                const int f = f0 + row / 3, c = row % 3;
+                const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
+                if (f < B) {
+                    float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
+                    if (vq + 3 < n_vert) *(f32x4 *)o = vv;
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (vq + t < n_vert) o[t] = vv[t];
+                    }
+                }
+            }
+        }
+        lds_barrier();     // stage and the record slices are rewritten by the next face tile
+    }
+}
+
+void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
+                           int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec3f) {
+    unsigned *rec3 = reinterpret_cast<unsigned *>(rec3f);
+    const int n_ftiles = (B + 31) / 32;
+    recon_prep_b3_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
+    const int n_tiles = nvp / 32;
+    const int n_groups = (n_tiles + 3) / 4;                   // a workgroup = 4 consecutive vertex tiles
+    int n_split = (3072 + n_groups - 1) / n_groups;           // >= 3072 workgroups (see launch_reconstruct)
+    n_split = n_split < 1 ? 1 : n_split;
+    n_split = n_split > n_ftiles ? n_ftiles : n_split;
+    const int per = (n_ftiles + n_split - 1) / n_split;
+    n_split = (n_ftiles + per - 1) / per;
+    const int n_units = n_groups * n_split;
+    const int grid = ((n_units + 7) / 8) * 8;
+    recon_b3_kernel<<<grid, 256, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units);
 }
 
 // -------------------------------------------------------------------------------------

@@ -96,6 +96,18 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
                         const float *basis, int n_vert, int nvp, const float *roi,
                         int transform, float *out, int B, hipStream_t s, float *rec);
 
+// Same contraction on the bf16 matrix pipe (exact 3-way split of both operands, v_mfma_f32_32x32x16_bf16).
+//   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 3][lane 64][4 dwords] for k = 0..47
+//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), then fp32 [3][32]: column 48, column 49, mean u.
+//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces in the same lane order (rows = faces), then 32 x 16 fp32
+//           records M[9] | T[3] | alpha48 | alpha49 | 0 | 0.
+constexpr int kBasisB3 = 3 * 3 * 256 + 96;
+constexpr int kRecTileB3 = 3 * 3 * 256 + 32 * 16;
+constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)
+constexpr int kRecSlack = 4096;
+void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
+                           int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec3);
+
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
                  double *angles, float *t3d, int B, hipStream_t s);
 

@@ -244,20 +244,24 @@ struct syn_handle {
 
 namespace {
 
-size_t basis_float_count(int nvp, int nlp) { return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 128; }
+size_t basis_float_count(int nvp, int nlp) {        // fp32 tiles | mean, std | bf16 x3 tiles (dense, landmark)
+    return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 128 + (size_t)((nvp + nlp) / 32) * 3 * syn::kBasisB3;
+}
 const float *basis_dense(const syn_handle *h) { return h->d_basis; }
 const float *basis_lmk(const syn_handle *h) { return h->d_basis + (size_t)h->nvp * 3 * syn::kBasisK; }
 const float *basis_mean(const syn_handle *h) { return h->d_basis + (size_t)(h->nvp + h->nlp) * 3 * syn::kBasisK; }
 const float *basis_std(const syn_handle *h) { return basis_mean(h) + 64; }
+const unsigned *basis3_dense(const syn_handle *h) { return reinterpret_cast<const unsigned *>(basis_mean(h) + 128); }
+const unsigned *basis3_lmk(const syn_handle *h) { return basis3_dense(h) + (size_t)(h->nvp / 32) * 3 * syn::kBasisB3; }
 
 size_t ws_floats_per_face() {
     const size_t mb = 2 * net().max_io + 2 * net().max_hidden, rn = 4 * resnet50().buf_big + 2 * resnet50().buf_mid;
-    return (mb > rn ? mb : rn) + 64;          // one workspace serves either backbone; the last 64 floats/face = recon records
+    return (mb > rn ? mb : rn) + syn::kRecFloatsPerFace;   // one workspace serves either backbone; the tail = reconstruction records
 }
 size_t backbone_floats(int arch) { return arch == 1 ? resnet50().packed_count : net().packed_count; }
 
 int ensure_ws(syn_handle *h, int B) {
-    const size_t need = ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
+    const size_t need = ((size_t)B * ws_floats_per_face() + syn::kRecSlack) * sizeof(float);
     if (need <= h->ws_bytes) return SYN_OK;
     if (h->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     HIP_TRY(hipMalloc((void **)&h->ws, need));
@@ -287,6 +291,44 @@ void pack_basis_tiles(float *dst, int n_rows_valid, int n_tiles, const float *w_
             for (int lane = 0; lane < 64; ++lane)
                 for (int s = 0; s < 2; ++s)
                     d[6 * 256 + lane * 2 + s] = wfull(32 * t + (lane & 31), c, 48 + 2 * (lane >> 5) + s);
+        }
+}
+
+// bf16 x3 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3)
+void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
+                         const int64_t *rows) {
+    auto wfull = [&](int v, int c, int k) -> float {
+        if (v >= n_rows_valid) return 0.f;
+        const size_t row = rows ? (size_t)rows[3 * v + c] : (size_t)3 * v + c;
+        if (k < 40) return w_shp[row * 40 + k];
+        if (k < 50) return w_exp[row * 10 + (k - 40)];
+        return u[row];
+    };
+    auto split = [](float x, unsigned (&pc)[3]) {
+        for (int i = 0; i < 3; ++i) {
+            unsigned uu; memcpy(&uu, &x, 4); uu &= 0xffff0000u;
+            float hf; memcpy(&hf, &uu, 4);
+            pc[i] = uu >> 16; x -= hf;
+        }
+    };
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < 3; ++c) {
+            unsigned *d = dst + ((size_t)t * 3 + c) * syn::kBasisB3;
+            for (int ks = 0; ks < 3; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int dd = 0; dd < 4; ++dd) {
+                        unsigned lo[3], hi[3];
+                        const int k0 = 16 * ks + 8 * (lane >> 5) + 2 * dd;
+                        split(wfull(32 * t + (lane & 31), c, k0), lo);
+                        split(wfull(32 * t + (lane & 31), c, k0 + 1), hi);
+                        for (int pc = 0; pc < 3; ++pc) d[((ks * 3 + pc) * 64 + lane) * 4 + dd] = lo[pc] | (hi[pc] << 16);
+                    }
+            float *x = reinterpret_cast<float *>(d + 9 * 256);
+            for (int j = 0; j < 32; ++j) {
+                x[j] = wfull(32 * t + j, c, 48);
+                x[32 + j] = wfull(32 * t + j, c, 49);
+                x[64 + j] = wfull(32 * t + j, c, 50);
+            }
         }
 }
 
@@ -694,6 +736,9 @@ int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const 
     float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
     memcpy(ms, param_mean, sizeof(float) * 62);
     memcpy(ms + 64, param_std, sizeof(float) * 62);
+    unsigned *b3 = reinterpret_cast<unsigned *>(ms + 128);
+    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
+    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
     DeviceGuard g(h->device);
     if (h->d_basis && h->basis_floats != total) { HIP_TRY(hipFree(h->d_basis)); h->d_basis = nullptr; }
     if (!h->d_basis) HIP_TRY(hipMalloc((void **)&h->d_basis, total * sizeof(float)));
@@ -767,7 +812,7 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
 
 size_t syn_workspace_bytes(syn_handle *, int B) {
     if (B <= 0) return 0;
-    return ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
+    return ((size_t)B * ws_floats_per_face() + syn::kRecSlack) * sizeof(float);
 }
 
 int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, float *pool, void *stream) {
@@ -887,8 +932,12 @@ int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int
     DeviceGuard g(h->device);
     int rc = ensure_ws(h, B);
     if (rc) return rc;
-    float *rec = h->ws + (size_t)B * (ws_floats_per_face() - 64);
-    if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
+    float *rec = h->ws + (size_t)B * (ws_floats_per_face() - syn::kRecFloatsPerFace);
+    if (h->fusion >= 2) {
+        if (dense) syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), basis3_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
+        else       syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), basis3_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
+    }
+    else if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
     else       syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
