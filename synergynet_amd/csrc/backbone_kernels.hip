@@ -11,7 +11,7 @@ namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
 
 // =====================================================================================
 // Stem: 3x3 stride-2 conv 3->32 + BN + ReLU6 (features.0, mobilenetv2_backbone.py:129).

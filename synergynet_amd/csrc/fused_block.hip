@@ -35,7 +35,7 @@ namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float relu6_(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float relu6_(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }   // one v_med3 (fminf(fmaxf()) adds a canonicalising v_max)
 __device__ __forceinline__ f32x4 relu6_(f32x4 v) {
     f32x4 r;
 #pragma unroll

@@ -24,7 +24,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-__device__ __forceinline__ float relu6b(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float relu6b(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }   // one v_med3 (fminf(fmaxf()) adds a canonicalising v_max)
 __device__ __forceinline__ f32x4 relu6b(f32x4 v) {
     f32x4 r;
 #pragma unroll

@@ -17,7 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int NF = 4, PX = NF * 16, K = 320, KCH = K / 16, N = 1280, NTL = N / 16, XS = K + 4;
-__device__ __forceinline__ float r6h(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float r6h(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
 // sum over the 16 lanes of a DPP row, result in every lane of the row: 4 VALU adds, no LDS traffic
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror)
 __device__ __forceinline__ float row16_sum(float v) {

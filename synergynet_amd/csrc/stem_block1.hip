@@ -35,7 +35,7 @@ constexpr int U8_IPT = (IT * ROWDW + NTH - 1) / NTH;      // 2 dword loads per t
 constexpr int F32_IPT = (3 * IT * IT + NTH - 1) / NTH;    // 8 scalar loads per thread per tile
 // LDS offset of im2col element k = ci*9 + ky*3 + kx inside the image planes (padded slots 27..31 read element 0)
 constexpr int koff_of(int k) { return k < 27 ? (k / 9) * IT * ITS + ((k % 9) / 3) * ITS + k % 3 : 0; }
-__device__ __forceinline__ float r6(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+__device__ __forceinline__ float r6(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
 __device__ __forceinline__ f32x4 r6(f32x4 v) {
     f32x4 r;
 #pragma unroll
