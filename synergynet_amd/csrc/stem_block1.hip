@@ -57,14 +57,11 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     __shared__ __attribute__((aligned(16))) float im[3 * IT * ITS];
     __shared__ __attribute__((aligned(16))) float Es[PIN * ES];
     __shared__ __attribute__((aligned(16))) float Ds[POUTP * ES];
-    __shared__ __attribute__((aligned(16))) float WD[11 * 32];          // depthwise filter [9][32] | scale | shift
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
-    // ---- per-workgroup constants: depthwise filter in LDS; stem / project fragments + BN in registers ----
-    for (int i = tid; i < 9 * 32 / 4; i += NTH) *(f32x4 *)&WD[4 * i] = *(const f32x4 *)&wd[4 * i];
-    if (tid < 8) { *(f32x4 *)&WD[288 + 4 * tid] = *(const f32x4 *)&sd[4 * tid]; *(f32x4 *)&WD[320 + 4 * tid] = *(const f32x4 *)&bd[4 * tid]; }
+    // ---- per-workgroup constants: stem / depthwise / project filters + BN in registers ----
     for (int i = tid; i < (POUTP - POUT) * ES; i += NTH) Ds[POUT * ES + i] = 0.f;
     // stem filter as MFMA "A" fragments: lane (channel r16 of tile nt, k-slot g): k = 16*kc + 4*g + q < 27
     f32x4 wa[2][2];
@@ -92,6 +89,12 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     const f32x4 sh0 = *(const f32x4 *)&b0[4 * g], sh1 = *(const f32x4 *)&b0[16 + 4 * g];
     const f32x4 pa0 = *(const f32x4 *)(wp + lane * 4), pa1 = *(const f32x4 *)(wp + 256 + lane * 4);
     const f32x4 psh = *(const f32x4 *)&bp[4 * g];
+
+    // depthwise filter + BN shift of this thread's channel quad: constant for the whole (persistent) kernel -> registers
+    f32x4 dww[9], dwsh;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dww[k] = *(const f32x4 *)&wd[k * 32 + 4 * (tid & 7)];
+    dwsh = *(const f32x4 *)&bd[4 * (tid & 7)];
 
     // ---- image patch prefetch (registers) ----
     unsigned xr8[U8_IPT];
@@ -236,10 +239,8 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
         if (!(ablate & 4) && tid < 8 * T * 2) {
             const int c4 = tid & 7, q2 = tid >> 3;
             const int oxl = q2 % T, seg = q2 / T;
-            f32x4 w[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[k] = *(const f32x4 *)&WD[k * 32 + 4 * c4];
-            const f32x4 sh = *(const f32x4 *)&WD[320 + 4 * c4];
+            const f32x4 (&w)[9] = dww;
+            const f32x4 sh = dwsh;
             f32x4 rb[3][3];
             auto load_row = [&](int ly, f32x4(&dst)[3]) {               // ly = tile row (always inside the 12x12 tile)
                 const float *er = Es + (ly * FT + oxl) * ES + 4 * c4;
