@@ -187,10 +187,10 @@ def main():
             except Exception:
                 traffic = None
         roof = dict(bound='mfma',
-                    kernel=f'syn::fused_block[_bf3]_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
-                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs); fp32 results: features.2-4 on '
-                           f'v_mfma_f32_16x16x4_f32, features.5-17 on v_mfma_f32_16x16x32_bf16 with an exact 3-way bf16 operand '
-                           f'split (6 MFMAs per K=32); priced against the fp32 (f32-input) MFMA peak',
+                    kernel=f'syn::fused_block_{{early,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
+                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs); fp32-accurate results on '
+                           f'v_mfma_f32_16x16x32_bf16 with an exact 3-way bf16 split of both operands (6 MFMAs per K=32 block); '
+                           f'algorithmic fp32 FLOPs priced against the fp32 (f32-input) MFMA peak',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                     flops_per_launch=round(fam_fl / len(fam)), ms_per_launch=round(fam_ms / len(fam), 5),
