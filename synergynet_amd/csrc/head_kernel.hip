@@ -16,7 +16,7 @@ namespace syn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int NF = 4, PX = NF * 16, K = 320, KCH = K / 16, N = 1280, NTL = N / 16, XS = K + 4;
+constexpr int NF = 2, PX = NF * 16, K = 320, KCH = K / 16, N = 1280, NTL = N / 16, XS = K + 4;
 __device__ __forceinline__ float r6h(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
 // sum over the 16 lanes of a DPP row, result in every lane of the row: 4 VALU adds, no LDS traffic
 // (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror)
@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
         for (int kc = 0; kc < KCH; ++kc) a[kc] = an[kc];
         const f32x4 sh = hn;
         if (!(ablate & 1) && nt + 4 < NTL) fetch(nt + 4);
-        f32x4 acc[NF] = {sh, sh, sh, sh};             // BN shift = accumulator start
+        f32x4 acc[NF];                                // BN shift = accumulator start
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[j] = sh;
         // LDS operand reads run exactly one k-chunk ahead of the MFMAs; the scheduling barriers stop the compiler
         // from hoisting all 80 reads to the top (that spilled the weight fragments to scratch)
         f32x4 bc[NF], bn[NF];
@@ -213,18 +215,21 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
 
     for (int nt = wave; nt < NTL; nt += 4) {
         const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g];
-        f32x4 acc[NF] = {sh, sh, sh, sh};
-        u32x4 bc[NF][3], bn[NF][3];
+        f32x4 acc[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[j] = sh;
+        u32x4 bq[2][NF][3];                             // pixel operands of the current / next k-chunk (ping-pong, no copies)
         auto ldb = [&](int kc, u32x4(&b)[NF][3]) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANE + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
         };
-        ldb(0, bc);
+        ldb(0, bq[0]);
 #pragma unroll
         for (int kc = 0; kc < KC32; ++kc) {
-            if (kc + 1 < KC32) ldb(kc + 1, bn);
+            if (kc + 1 < KC32) ldb(kc + 1, bq[(kc + 1) & 1]);
+            const u32x4(&bc)[NF][3] = bq[kc & 1];
             const u32x4 ah = ring[kc % 5][0], am = ring[kc % 5][1], al = ring[kc % 5][2];
             // six partial products, smallest first; 4 independent accumulators interleaved
 #pragma unroll
@@ -242,10 +247,6 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
             // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
             if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
             else if (nt + 4 < NTL) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -268,12 +269,20 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
-#pragma unroll 2
-    for (int o = wave; o < kParam; o += 4) {
-        const float *wr = Wfc + (size_t)o * N;
-        f32x4 wv[N / 256];
+    // the 62 head rows, 4 waves x 16 rounds; the next row's weights are fetched while the current one is reduced
+    f32x4 wq[2][N / 256];
+    auto ldw = [&](int o, f32x4(&w)[N / 256]) {
+        const float *wr = Wfc + (size_t)(o < kParam ? o : kParam - 1) * N;
 #pragma unroll
-        for (int i = 0; i < N / 256; ++i) wv[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
+        for (int i = 0; i < N / 256; ++i) w[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
+    };
+    ldw(wave, wq[0]);
+#pragma unroll
+    for (int r = 0; r < (kParam + 3) / 4; ++r) {
+        const int o = wave + 4 * r;
+        if (r + 1 < (kParam + 3) / 4) ldw(o + 4, wq[(r + 1) & 1]);
+        if (o >= kParam) continue;
+        const f32x4(&wv)[N / 256] = wq[r & 1];
         const float bo = bfc[o];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
