@@ -210,17 +210,13 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
                     for (int p = 0; p < 3; ++p) b[q][p] = *(const u32x4 *)&Xb[p * C::XPL + row];
                 }
             };
-            u32x4 bc[C::EPB][3], bn[C::EPB][3];
-            ldb(0, bc);
+            u32x4 bq[2][C::EPB][3];                     // pixel operands of the current / next k32 chunk (ping-pong)
+            ldb(0, bq[0]);
 #pragma unroll
             for (int kc = 0; kc < C::KE; ++kc) {
-                if (kc + 1 < C::KE) ldb(kc + 1, bn);
+                if (kc + 1 < C::KE) ldb(kc + 1, bq[(kc + 1) & 1]);
 #pragma unroll
-                for (int q = 0; q < C::EPB; ++q) ea[q] = mac6(a1[jj][kc], bc[q], ea[q]);
-#pragma unroll
-                for (int q = 0; q < C::EPB; ++q)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) bc[q][p] = bn[q][p];
+                for (int q = 0; q < C::EPB; ++q) ea[q] = mac6(a1[jj][kc], bq[kc & 1][q], ea[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -303,19 +299,15 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
                     for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
                 }
             };
-            u32x4 bc[C::AP][3], bn[C::AP][3];
-            ldb(0, bc);
+            u32x4 bq[2][C::AP][3];
+            ldb(0, bq[0]);
 #pragma unroll
             for (int kc = 0; kc < C::KP; ++kc) {
-                if (kc + 1 < C::KP) ldb(kc + 1, bn);
+                if (kc + 1 < C::KP) ldb(kc + 1, bq[(kc + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < C::AN; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6(a3[i][kc], bc[j], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < C::AP; ++j)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) bc[j][p] = bn[j][p];
+                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6(a3[i][kc], bq[kc & 1][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
