@@ -51,6 +51,13 @@ __device__ __forceinline__ f32x4 mac6e(const u32x4 (&a)[3], const u32x4 (&b)[3],
 }
 }  // namespace
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+namespace {
+__device__ __forceinline__ f32x16 mfmae32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+}  // namespace
+
 #define SYNE_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
 
 template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int TH_, int TW_, int NW_, int NG_, int WN_, int WP_>
@@ -65,9 +72,14 @@ struct EarlyCfg {
     static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
     static constexpr int TILES_Y = cdive(HOUT, TH), TILES_X = cdive(HOUT, TW);
     static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
-    static constexpr int PIN = IH * IW, PINP = rupe(PIN, 16), PT_IN = PINP / 16;
+    static constexpr int PIN = IH * IW, PINP = rupe(PIN, CIN_ == 16 ? 32 : 16), PT_IN = PINP / 16;
     static constexpr int POUT = TH * TW, POUTP = rupe(POUT, 16), PT_O = POUTP / 16;
-    static constexpr int PPW = cdive(PT_IN, GW);                // input pixel tiles owned by a wave
+    // CIN = 16: the expand GEMM runs on v_mfma_f32_32x32x16_bf16 -- K = 16 is exactly one step (the 16x16x32 form would
+    // spend half of its K on zeros): 32-pixel x 32-channel tiles, lane (j = l&31, h = l>>5) holds k = 8h .. 8h+7
+    static constexpr bool K16 = (CIN == 16);
+    static constexpr int PXT = K16 ? 32 : 16;                  // pixels per expand tile
+    static constexpr int PT_X = PINP / PXT;
+    static constexpr int PPW = cdive(PT_X, GW);                // input pixel tiles owned by a wave
     static constexpr int COUTP = rupe(COUT, 16), NT_O = COUTP / 16, NT_E = HC / 16;
     static constexpr int AN = cdive(NT_O, WN), AP = cdive(PT_O, WP);
     static constexpr int ES = HC + 4, DSD = HCP / 2 + 4, DPL = POUTP * DSD;
@@ -78,10 +90,11 @@ struct EarlyCfg {
     static constexpr int RPS = cdive(TH, RS), DW_THREADS = C4N * TW * cdive(TH, RPS);
     // LDS carve (dwords)
     static constexpr int ES_DW = PINP * ES, DB_DW = 3 * DPL;
-    static constexpr int WE_DW = (HID / 16) * 768, WP_DW = NT_O * NCH * KP * 768, WD_DW = 11 * HID;
+    static constexpr int WE_DW = (CIN_ == 16 ? HID / 32 : HID / 16) * 768, WP_DW = NT_O * NCH * KP * 768, WD_DW = 11 * HID;
     static constexpr int LDS_DWORDS = NG * (ES_DW + DB_DW) + WE_DW + WP_DW + WD_DW + HID;
     static_assert(CIN <= 32 && CIN % 8 == 0, "one k32 step of expand, whole 8-channel lane groups");
     static_assert(HID % HC == 0 && HC % 16 == 0, "hidden chunking");
+    static_assert(CIN_ != 16 || HC % 32 == 0, "32-channel expand tiles");
     static_assert(NW % NG == 0 && WN * WP == GW, "wave grid of a group");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
     static_assert(HOUT % TH == 0 && HOUT % TW == 0, "whole tiles");
@@ -106,6 +119,7 @@ void fused_block_early_kernel(
     float *Wds = reinterpret_cast<float *>(Wlp + C::WP_DW);               // [11][HID]: 9 taps | (unused) | shift
     float *Ebn = Wds + C::WD_DW;                                          // [HID] expand BN shift
     const int r16 = lane & 15, g = lane >> 4;
+    const int xl = C::K16 ? (lane & 31) : r16, xg = C::K16 ? (lane >> 5) : g;   // expand operand: pixel in tile, channel octet
     const int wn = gw % C::WN, wp = gw / C::WN;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, ntiles_done = 0;
@@ -118,11 +132,11 @@ void fused_block_early_kernel(
         const int iy0 = ty * C::TH * C::S - 1, ix0 = tx * C::TW * C::S - 1;
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
-            const int p = (gw + i * C::GW) * 16 + r16;
+            const int p = (gw + i * C::GW) * C::PXT + xl;
             const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
             xr[i][0] = z4; xr[i][1] = z4;
-            if (p < C::PIN && 8 * g < C::CIN && (unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) {
-                const float *src = &X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 8 * g];
+            if (p < C::PIN && 8 * xg < C::CIN && (unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) {
+                const float *src = &X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 8 * xg];
                 xr[i][0] = *(const f32x4 *)src;
                 xr[i][1] = *(const f32x4 *)(src + 4);
             }
@@ -180,7 +194,7 @@ void fused_block_early_kernel(
                 xb[i][1][2 * h] = m0; xb[i][1][2 * h + 1] = m1;
                 xb[i][2][2 * h] = l0; xb[i][2][2 * h + 1] = l1;
             }
-            const int p = (gw + i * C::GW) * 16 + r16;
+            const int p = (gw + i * C::GW) * C::PXT + xl;
             const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
             ehi[i] = ((unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) ? 6.0f : 0.0f;
         }
@@ -196,6 +210,40 @@ void fused_block_early_kernel(
         for (int c = 0; c < C::NCH; ++c) {
             const int hc0 = c * C::HC;
             // ---- stage 1: expand 1x1 (bf16 x3) + BN shift + ReLU6 -> Es (fp32); operands: LDS weights x registers ----
+            if (C::K16) {
+#pragma unroll
+                for (int nt = 0; nt < C::HC / 32; ++nt) {
+                    u32x4 a[3];
+                    const unsigned *wa = Wle + (size_t)(hc0 / 32 + nt) * 768 + lane * 4;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *(const u32x4 *)(wa + p * 256);
+                    // D rows (channels) of register r: (r&3) + 8*(r>>2) + 4*xg  -> four float4 groups of consecutive channels
+                    f32x4 sh4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sh4[q] = *(const f32x4 *)&Ebn[hc0 + nt * 32 + 8 * q + 4 * xg];
+#pragma unroll
+                    for (int i = 0; i < C::PPW; ++i) {
+                        const int pt = gw + i * C::GW;
+                        if (pt >= C::PT_X || !live) break;              // wave-uniform
+                        f32x16 e;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) e[r] = sh4[r >> 2][r & 3];
+                        e = mfmae32(a[2], xb[i][0], e);
+                        e = mfmae32(a[0], xb[i][2], e);
+                        e = mfmae32(a[1], xb[i][1], e);
+                        e = mfmae32(a[1], xb[i][0], e);
+                        e = mfmae32(a[0], xb[i][1], e);
+                        e = mfmae32(a[0], xb[i][0], e);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 ev;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) ev[t] = __builtin_amdgcn_fmed3f(e[4 * q + t], 0.0f, ehi[i]);
+                            *(f32x4 *)&Es[(pt * 32 + xl) * C::ES + nt * 32 + 8 * q + 4 * xg] = ev;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int nt = 0; nt < C::NT_E; ++nt) {
                 u32x4 a[3];

@@ -578,6 +578,19 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
             const int hc = !early ? L.cin : (L.relu6 ? L.cin : syn::early_block_hc(L.cin));
             const int hcp = round_up(hc, 32), nch = L.cin / hc, spc = hcp / 32;     // k32 steps per chunk
             const int ntl = round_up(L.cout, 16) / 16, kch = nch * spc;
+            if (early && L.relu6 && L.cin == 16) {
+                // features.2 expand: K = 16 is one step of v_mfma_f32_32x32x16_bf16 -> [cout/32][piece][lane][4 dwords],
+                // lane (i = l&31 channel of the 32-tile, h = l>>5) holds k = 8h .. 8h+7 (fused_block_early.hip, K16)
+                for (int nt = 0; nt < L.cout / 32; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            const int nn = nt * 32 + (lane & 31);
+                            for (int e = 0; e < 2; ++e) split(w[(size_t)nn * L.cin + 8 * (lane >> 5) + 2 * d + e] * bn_scale[nn], pc[e]);
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[(((size_t)nt * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                        }
+            } else
             for (int nt = 0; nt < ntl; ++nt)
                 for (int st = 0; st < kch; ++st)
                     for (int lane = 0; lane < 64; ++lane)
