@@ -286,17 +286,22 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WPG waves per workgroup = WPG consecutive vertex tiles = one WPG*128-byte run per (face, coord) row and iteration.  Rows of
+// the [B,3,53215] output are only 4-byte aligned, so every run shares its first and last cache line with a neighbouring
+// workgroup; longer runs mean fewer such split lines (tools/ubench/store_pattern.hip: 512 B runs 3.5 TB/s, 1 KiB ~4).
+template <int WPG>
+__global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
                      int n_vert, int n_tiles, int n_split, int ftiles_per_split, int n_ftiles, int n_units) {
-    __shared__ __attribute__((aligned(16))) float smt[4][32][16];
-    __shared__ __attribute__((aligned(16))) float stage[96 * kStageStride];   // [face*3 + coord][4 tiles x 32 vertices]
+    constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float smt[WPG][32][16];
+    __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
     const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
     const int tg = unit / n_split, split = unit - tg * n_split;
-    int T = tg * 4 + wave;
+    int T = tg * WPG + wave;
     T = T < n_tiles ? T : n_tiles - 1;
     const int j = lane & 31, h = lane >> 5;
 
@@ -317,7 +322,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     int ft1 = ft0 + ftiles_per_split;
     ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
     float(*mt)[16] = smt[wave];
-    const int v_base = tg * 128;
+    const int v_base = tg * (WPG * 32);
 
     for (int ft = ft0; ft < ft1; ++ft) {
         const int f0 = ft * 32;
@@ -363,21 +368,22 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
             const float sx = acc[0][r] + q3[0] * b48[0] + q3[1] * b49[0];
             const float sy = acc[1][r] + q3[0] * b48[1] + q3[1] * b49[1];
             const float sz = acc[2][r] + q3[0] * b48[2] + q3[1] * b49[2];
-            float *st = stage + (i * 3) * kStageStride + wave * 32 + j;
+            float *st = stage + (i * 3) * SS + wave * 32 + j;
             st[0] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
-            st[kStageStride] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
-            st[2 * kStageStride] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
+            st[SS] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
+            st[2 * SS] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
             if (r & 1) __builtin_amdgcn_sched_barrier(0);    // keep the record reads of at most two rows in flight (registers)
         }
         lds_barrier();
-        {   // cooperative store: 32 lanes x float4 = one 512-byte run of one (face, coord) row; 2 rows per instruction
-            const int seg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
+        {   // cooperative store: LPR lanes x float4 = one run of one (face, coord) row; WPG*64/LPR rows per instruction
+            constexpr int LPR = WPG * 8, RPI = WPG * 64 / LPR;
+            const int seg = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
             const int vq = v_base + 4 * seg;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const int row = k * 8 + rsub;                 // = face_in_tile * 3 + coord
+            for (int k = 0; k < 96 / RPI; ++k) {
+                const int row = k * RPI + rsub;               // = face_in_tile * 3 + coord
                 const int f = f0 + row / 3, c = row % 3;
-                const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
+                const f32x4 vv = *(const f32x4 *)&stage[row * SS + 4 * seg];
                 if (f < B) {
                     float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
                     if (vq + 3 < n_vert) *(f32x4 *)o = vv;
@@ -398,7 +404,8 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
     const int n_ftiles = (B + 31) / 32;
     recon_prep_b3_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
     const int n_tiles = nvp / 32;
-    const int n_groups = (n_tiles + 3) / 4;                   // a workgroup = 4 consecutive vertex tiles
+    constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower: 347 vs 305 us
+    const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
     int n_split = (3072 + n_groups - 1) / n_groups;           // >= 3072 workgroups (see launch_reconstruct)
     n_split = n_split < 1 ? 1 : n_split;
     n_split = n_split > n_ftiles ? n_ftiles : n_split;
@@ -406,7 +413,7 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
     n_split = (n_ftiles + per - 1) / per;
     const int n_units = n_groups * n_split;
     const int grid = ((n_units + 7) / 8) * 8;
-    recon_b3_kernel<<<grid, 256, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units);
+    recon_b3_kernel<WPG><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units);
 }
 
 // -------------------------------------------------------------------------------------
