@@ -127,6 +127,31 @@ int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int
 int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense,
                     int transform, const float *roi, float *out, void *stream);
 
+/* ---- mesh consumers: what the reference's demo does with the meshes (utils/render.py:31-50) ----
+ * syn_load_triangles: the mesh topology (param_pack `tri`, 0-based, [ntri,3] int32 host pointer), once per handle;
+ * replaces the `triangles` argument of Sim3DR.get_normal / rasterize (Sim3DR/Sim3DR.py:8,14). */
+int syn_load_triangles(syn_handle *h, const int32_t *tri, int ntri, int nver);
+
+/* Sim3DR.get_normal (Sim3DR/Sim3DR.py:8-11 -> lib/rasterize_kernel.cpp:158-215) and, when light != NULL, the vertex
+ * colours of RenderPipeline.__call__ (Sim3DR/lighting.py:37-64) for F meshes in one launch chain.
+ * vertices: device, planar = 1 -> [F,3,nver] (what syn_reconstruct writes), 0 -> [F,nver,3] (the reference's layout);
+ * normal, light: device [F,nver,3] (light may be NULL);
+ * cfg16: HOST pointer to 16 floats: intensity_ambient, color_ambient[3], intensity_directional, color_directional[3],
+ *        intensity_specular, specular_exp, light_pos[3], view_pos[3] (lighting.py:24-32). */
+int syn_mesh_shade(syn_handle *h, const float *vertices, int F, int planar, const float *cfg16, float *normal,
+                   float *light, void *stream);
+
+/* Sim3DR.rasterize (Sim3DR/Sim3DR.py:14-29 -> lib/rasterize_kernel.cpp:219-287, alpha = 1 as the binding defaults):
+ * draws F meshes, in order, into image [H,W,channels] uint8 (device, in place), each with a fresh z-buffer, i.e. the
+ * result of calling the reference once per mesh on the same background.  colors: device [F,nver,channels] float32 in [0,1].
+ * F <= 254, channels <= 4.  reverse: flip y on write (rasterize_kernel.cpp:270). */
+int syn_rasterize(syn_handle *h, const float *vertices, const float *colors, int F, int planar, int channels,
+                  uint8_t *image, int H, int W, int reverse, void *stream);
+
+/* cv2.addWeighted(a, alpha, b, beta, 0) for uint8 arrays of n bytes (utils/render.py:45), device pointers. */
+int syn_add_weighted(syn_handle *h, const uint8_t *a, float alpha, const uint8_t *b, float beta, uint8_t *out,
+                     size_t n, void *stream);
+
 /* predict_pose (utils/inference.py:146-157 -> parse_pose :86-92 -> P2sRt :33-43 ->
  * matrix2angle_corr :45-62).  angles [B,3] degrees (double, like the reference's python
  * floats), t3d [B,3] fp32 with the ROI affine on x,y; roi may be NULL. */

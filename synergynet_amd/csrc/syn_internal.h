@@ -108,6 +108,19 @@ constexpr int kRecSlack = 4096;
 void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
                            int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec3);
 
+// ---- mesh consumers (render_kernels.hip): Sim3DR.get_normal / RenderPipeline / Sim3DR.rasterize / cv2.addWeighted ----
+// vertices: F meshes, planar = 1 -> [F,3,nver] (the layout syn_reconstruct writes), 0 -> [F,nver,3] (the reference's)
+void launch_mesh_normals(const float *vertices, const int *tri, const int *adj_off, const int *adj_tri, float *tri_normal,
+                         float *normal /*[F,nver,3]*/, unsigned *mm /*[F,6] scratch: per-axis min/max keys*/, int F, int nver,
+                         int ntri, int planar, hipStream_t s);
+void launch_mesh_lighting(const float *vertices, const float *normal, const unsigned *mm, const float *cfg /*16 floats, device*/,
+                          float *light /*[F,nver,3]*/, int F, int nver, int planar, hipStream_t s);
+void launch_rasterize(const float *vertices, const int *tri, const float *colors /*[F,nver,c]*/, unsigned long long *zkey /*[h*w]*/,
+                      unsigned char *image /*[h,w,c] in place*/, int F, int nver, int ntri, int h, int w, int c, int planar,
+                      int reverse, hipStream_t s);
+void launch_add_weighted(const unsigned char *a, float alpha, const unsigned char *b, float beta, unsigned char *out, size_t n,
+                         hipStream_t s);
+
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
                  double *angles, float *t3d, int B, hipStream_t s);
 

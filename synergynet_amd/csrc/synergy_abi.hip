@@ -238,6 +238,11 @@ struct syn_handle {
     int n_vert = 0, n_lmk = 0, nvp = 0, nlp = 0;
     float *ws = nullptr;
     size_t ws_bytes = 0;
+    // mesh topology + render scratch (syn_load_triangles / syn_mesh_* / syn_rasterize)
+    int *d_tri = nullptr, *d_adj_off = nullptr, *d_adj_tri = nullptr;
+    int ntri = 0, tri_nver = 0;
+    void *rws = nullptr;           // render scratch: tri normals | min/max keys | z keys
+    size_t rws_bytes = 0;
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
                                    // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
 };
@@ -491,6 +496,10 @@ int syn_destroy(syn_handle *h) {
     if (h->d_backbone) (void)hipFree(h->d_backbone);
     if (h->d_basis) (void)hipFree(h->d_basis);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->d_tri) (void)hipFree(h->d_tri);
+    if (h->d_adj_off) (void)hipFree(h->d_adj_off);
+    if (h->d_adj_tri) (void)hipFree(h->d_adj_tri);
+    if (h->rws) (void)hipFree(h->rws);
     delete h;
     return SYN_OK;
 }
@@ -952,6 +961,92 @@ int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int
     }
     else if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
     else       syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mesh consumers: Sim3DR.get_normal / RenderPipeline / Sim3DR.rasterize / cv2.addWeighted
+// ---------------------------------------------------------------------------------------------
+namespace {
+int ensure_rws(syn_handle *h, size_t bytes) {
+    if (bytes <= h->rws_bytes) return SYN_OK;
+    if (h->rws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->rws)); h->rws = nullptr; h->rws_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->rws, bytes));
+    h->rws_bytes = bytes;
+    return SYN_OK;
+}
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+int syn_load_triangles(syn_handle *h, const int32_t *tri, int ntri, int nver) {
+    if (!h || !tri || ntri <= 0 || nver <= 0) return fail(SYN_ERR_INVALID, "syn_load_triangles: bad argument");
+    if (ntri >= (1 << 24)) return fail(SYN_ERR_INVALID, "syn_load_triangles: ntri=%d exceeds the 24-bit z-key field", ntri);
+    for (int i = 0; i < 3 * ntri; ++i)
+        if (tri[i] < 0 || tri[i] >= nver) return fail(SYN_ERR_INVALID, "syn_load_triangles: tri[%d]=%d out of range", i, tri[i]);
+    // CSR of incident triangles per vertex in ascending triangle order, corner order inside a triangle: exactly the order
+    // in which the reference's sequential loop adds triangle normals to a vertex (rasterize_kernel.cpp:187-198)
+    std::vector<int> off(nver + 1, 0), adj(3 * (size_t)ntri);
+    for (int i = 0; i < 3 * ntri; ++i) off[tri[i] + 1]++;
+    for (int v = 0; v < nver; ++v) off[v + 1] += off[v];
+    std::vector<int> cur(off.begin(), off.end() - 1);
+    for (int t = 0; t < ntri; ++t)
+        for (int j = 0; j < 3; ++j) adj[cur[tri[3 * t + j]]++] = t;
+    DeviceGuard g(h->device);
+    if (h->d_tri) { (void)hipFree(h->d_tri); (void)hipFree(h->d_adj_off); (void)hipFree(h->d_adj_tri); h->d_tri = h->d_adj_off = h->d_adj_tri = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->d_tri, sizeof(int) * 3 * (size_t)ntri));
+    HIP_TRY(hipMalloc((void **)&h->d_adj_off, sizeof(int) * (nver + 1)));
+    HIP_TRY(hipMalloc((void **)&h->d_adj_tri, sizeof(int) * 3 * (size_t)ntri));
+    HIP_TRY(hipMemcpy(h->d_tri, tri, sizeof(int) * 3 * (size_t)ntri, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_adj_off, off.data(), sizeof(int) * (nver + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_adj_tri, adj.data(), sizeof(int) * 3 * (size_t)ntri, hipMemcpyHostToDevice));
+    h->ntri = ntri; h->tri_nver = nver;
+    return SYN_OK;
+}
+
+int syn_mesh_shade(syn_handle *h, const float *vertices, int F, int planar, const float *cfg16, float *normal, float *light,
+                   void *stream) {
+    if (!h || !vertices || !normal) return fail(SYN_ERR_INVALID, "syn_mesh_shade: NULL argument");
+    if (F <= 0) return fail(SYN_ERR_INVALID, "syn_mesh_shade: F=%d", F);
+    if (light && !cfg16) return fail(SYN_ERR_INVALID, "syn_mesh_shade: light requested without a lighting configuration");
+    if (!h->d_tri) return fail(SYN_ERR_NOT_LOADED, "syn_mesh_shade: triangles not loaded");
+    DeviceGuard g(h->device);
+    const size_t tn = align256(sizeof(float) * 3 * (size_t)h->ntri * F), mmb = align256(sizeof(unsigned) * 6 * F + 64);
+    int rc = ensure_rws(h, tn + mmb);
+    if (rc) return rc;
+    float *tri_normal = (float *)h->rws;
+    unsigned *mm = (unsigned *)((char *)h->rws + tn);
+    float *d_cfg = (float *)(mm + 6 * F);            // 16 floats right behind the keys (inside the 64-byte tail)
+    hipStream_t s = (hipStream_t)stream;
+    syn::launch_mesh_normals(vertices, h->d_tri, h->d_adj_off, h->d_adj_tri, tri_normal, normal, mm, F, h->tri_nver, h->ntri, planar, s);
+    if (light) {
+        HIP_TRY(hipMemcpyAsync(d_cfg, cfg16, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+        syn::launch_mesh_lighting(vertices, normal, mm, d_cfg, light, F, h->tri_nver, planar, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+int syn_rasterize(syn_handle *h, const float *vertices, const float *colors, int F, int planar, int channels, uint8_t *image,
+                  int H, int W, int reverse, void *stream) {
+    if (!h || !vertices || !colors || !image) return fail(SYN_ERR_INVALID, "syn_rasterize: NULL argument");
+    if (F <= 0 || F > 254 || H <= 0 || W <= 0 || channels <= 0 || channels > 4)
+        return fail(SYN_ERR_INVALID, "syn_rasterize: F=%d H=%d W=%d channels=%d", F, H, W, channels);
+    if (!h->d_tri) return fail(SYN_ERR_NOT_LOADED, "syn_rasterize: triangles not loaded");
+    DeviceGuard g(h->device);
+    int rc = ensure_rws(h, sizeof(unsigned long long) * (size_t)H * W);
+    if (rc) return rc;
+    syn::launch_rasterize(vertices, h->d_tri, colors, (unsigned long long *)h->rws, image, F, h->tri_nver, h->ntri, H, W, channels,
+                          planar, reverse, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+int syn_add_weighted(syn_handle *h, const uint8_t *a, float alpha, const uint8_t *b, float beta, uint8_t *out, size_t n,
+                     void *stream) {
+    if (!h || !a || !b || !out) return fail(SYN_ERR_INVALID, "syn_add_weighted: NULL argument");
+    DeviceGuard g(h->device);
+    if (n) syn::launch_add_weighted(a, alpha, b, beta, out, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
 }

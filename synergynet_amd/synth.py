@@ -229,3 +229,45 @@ def make_rois(batch: int, seed: int = 11) -> np.ndarray:
     ex = sx + side * rng.uniform(0.9, 1.1, batch)
     ey = sy + side
     return np.stack([sx, sy, ex, ey, rng.uniform(0.9, 1.0, batch)], axis=1).astype(np.float32)
+
+
+def make_grid_topology(rows: int = 231, cols: int = 231, n_vert: int | None = None, n_tri: int | None = None) -> np.ndarray:
+    """Triangles [ntri,3] int32 (0-based, counter-clockwise in image coordinates) of a rows x cols vertex grid, two per
+    cell -- the BFM mesh is such a parametrised surface (53215 vertices, 105840 triangles ~ a 231 x 231 grid).
+    n_vert drops the trailing vertices (and the triangles that use them); n_tri pads by repeating leading triangles
+    (duplicates exercise the rasteriser's first-wins tie rule) or truncates."""
+    r, c = np.meshgrid(np.arange(rows - 1), np.arange(cols - 1), indexing='ij')
+    v00 = (r * cols + c).reshape(-1)
+    v01, v10, v11 = v00 + 1, v00 + cols, v00 + cols + 1
+    tri = np.stack([np.stack([v00, v10, v01], 1), np.stack([v01, v10, v11], 1)], 1).reshape(-1, 3)
+    if n_vert is not None:
+        tri = tri[(tri < n_vert).all(1)]
+    if n_tri is not None:
+        if tri.shape[0] >= n_tri:
+            tri = tri[:n_tri]
+        else:
+            tri = np.concatenate([tri, tri[:n_tri - tri.shape[0]]], 0)
+    return np.ascontiguousarray(tri, dtype=np.int32)
+
+
+def make_face_meshes(n_faces: int, rows: int = 231, cols: int = 231, n_vert: int | None = None, height: int = 450,
+                     width: int = 450, seed: int = 777) -> np.ndarray:
+    """[F,3,N] float32 meshes in IMAGE coordinates (x, y, depth) -- the layout syn_reconstruct writes: bumpy half-ellipsoids
+    on the grid of make_grid_topology, each face with its own centre, size and in-plane rotation."""
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    v, u = np.meshgrid(np.linspace(-1, 1, rows), np.linspace(-1, 1, cols), indexing='ij')
+    u, v = u.reshape(-1), v.reshape(-1)
+    out = np.empty((n_faces, 3, n), dtype=np.float64)
+    for f in range(n_faces):
+        cx, cy = rng.uniform(0.3, 0.7) * width, rng.uniform(0.3, 0.7) * height
+        rx, ry = rng.uniform(0.12, 0.3) * width, rng.uniform(0.15, 0.33) * height
+        a = rng.uniform(-0.4, 0.4)
+        jx, jy = rng.standard_normal(n) * 0.15, rng.standard_normal(n) * 0.15
+        x0, y0 = rx * u + jx, ry * v + jy
+        out[f, 0] = cx + np.cos(a) * x0 - np.sin(a) * y0
+        out[f, 1] = cy + np.sin(a) * x0 + np.cos(a) * y0
+        out[f, 2] = 0.8 * rx * np.cos(0.5 * np.pi * u) * np.cos(0.5 * np.pi * v) + rng.standard_normal(n) * 0.3 - 20.0 * f
+    if n_vert is not None:
+        out = out[:, :, :n_vert]
+    return np.ascontiguousarray(out, dtype=np.float32)

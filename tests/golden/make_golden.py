@@ -115,6 +115,76 @@ def main_resnet50():
     print('wrote', fp, os.path.getsize(fp), 'bytes; out[0,:6] =', out[0, :6])
 
 
+def load_reference_sim3dr():
+    """The REAL reference Sim3DR package (Sim3DR/Sim3DR.py, Sim3DR/lighting.py) imported from /root/reference, with its
+    Cython extension `Sim3DR_Cython` (not built here) replaced by ctypes calls into the reference's own C++ compiled by
+    oracle/Makefile (oracle/_ref/libsim3dr_ref.so).  Nothing is copied."""
+    import ctypes as C
+    import importlib
+    import types
+    from oracle import sim3dr as osim
+    osim.build()
+    lib = C.CDLL(os.path.join(os.path.dirname(osim.__file__), '_ref', 'libsim3dr_ref.so'))
+    lib.ref_get_normal.argtypes = [C.c_void_p] * 3 + [C.c_int] * 2
+    lib.ref_rasterize.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_int]
+    stub = types.ModuleType('Sim3DR_Cython')
+
+    def get_normal(normal, vertices, triangles, nver, ntri):                    # rasterize.pyx:66-74
+        assert normal.dtype == np.float32 and vertices.dtype == np.float32 and triangles.dtype == np.int32
+        lib.ref_get_normal(normal.ctypes.data, vertices.ctypes.data, triangles.ctypes.data, nver, ntri)
+
+    def rasterize(image, vertices, triangles, colors, depth_buffer, ntri, h, w, c, alpha=1, reverse=False):   # rasterize.pyx:96-110
+        assert image.dtype == np.uint8 and vertices.dtype == np.float32 and triangles.dtype == np.int32 and colors.dtype == np.float32
+        lib.ref_rasterize(image.ctypes.data, vertices.ctypes.data, triangles.ctypes.data, colors.ctypes.data,
+                          depth_buffer.ctypes.data, ntri, h, w, c, alpha, int(reverse))
+
+    stub.get_normal, stub.rasterize = get_normal, rasterize
+    sys.modules['Sim3DR_Cython'] = stub
+    sys.path.insert(0, ref_loader.REF_ROOT)
+    try:
+        for k in [k for k in sys.modules if k == 'Sim3DR' or k.startswith('Sim3DR.')]:
+            del sys.modules[k]
+        return importlib.import_module('Sim3DR')
+    finally:
+        sys.path.remove(ref_loader.REF_ROOT)
+
+
+def main_render():
+    """the reference's own RenderPipeline (Sim3DR/lighting.py) + C++ rasteriser on seeded grid meshes with the
+    configuration of utils/render.py:18-27 -> tests/golden/render_golden.npz."""
+    from oracle import sim3dr as osim
+    ref = load_reference_sim3dr()
+    out = {}
+    for name, rows, cols, nv, nt, hw, nf in (('small', 40, 44, None, None, 160, 3), ('full', 231, 231, 53215, 105840, 450, 2)):
+        tri = synth.make_grid_topology(rows, cols, n_vert=nv, n_tri=nt)
+        meshes = synth.make_face_meshes(nf, rows, cols, n_vert=nv, height=hw, width=hw, seed=900 + rows)
+        img = np.random.default_rng(rows).integers(0, 256, (hw, hw, 3), dtype=np.uint8)
+        app = ref.RenderPipeline(**osim.RENDER_CFG)
+        overlap = img.copy()
+        normals, lights = [], []
+        for f in range(nf):
+            ver = np.ascontiguousarray(meshes[f].T)
+            normals.append(ref.get_normal(ver, tri))
+            overlap = app(ver, tri, overlap)
+        if name == 'small':
+            # vertex colours of the reference pipeline: re-run its lighting code path with a rasterize probe
+            captured = []
+            real_rasterize = sys.modules['Sim3DR.lighting'].rasterize
+            sys.modules['Sim3DR.lighting'].rasterize = lambda v, t, c, bg=None, **kw: (captured.append(c.copy()), bg)[1]
+            for f in range(nf):
+                app(np.ascontiguousarray(meshes[f].T), tri, img.copy())
+            sys.modules['Sim3DR.lighting'].rasterize = real_rasterize
+            out['small_normal'] = np.stack(normals)
+            out['small_light'] = np.stack(captured)
+            out['small_img'] = img
+        out[name + '_overlay'] = overlap
+        out[name + '_cfg'] = np.array([rows, cols, nv or rows * cols, nt or tri.shape[0], hw, nf, 900 + rows, rows], dtype=np.int64)
+    path = os.path.join(HERE, 'render_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, 'KB')
+
+
 if __name__ == '__main__':
     main()
     main_resnet50()
+    main_render()
