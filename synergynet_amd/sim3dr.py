@@ -136,9 +136,11 @@ def render_batch(model, img, meshes, alpha=0.6, cfg=None):
     image coordinates (reconstruct(..., roi=..., dense=True)); the topology is the model's `triangles`.
     Returns (solid overlay, blended result) as uint8 device tensors."""
     pipe = RenderPipeline(**(cfg or RENDER_CFG))
-    tri = np.ascontiguousarray(np.asarray(model.triangles).T if np.asarray(model.triangles).shape[0] == 3 else np.asarray(model.triangles))
     F, _, n = meshes.shape
-    _ensure_topology(model, tri, n)
+    if getattr(model, '_tri_obj', None) is not model.triangles or getattr(model, '_tri_key', (None, None))[1] != n:
+        t = np.asarray(model.triangles)                  # the class attribute is [3,ntri] (synergy3DMM.py:105), Sim3DR wants [ntri,3]
+        _ensure_topology(model, np.ascontiguousarray(t.T if t.shape[0] == 3 else t), n)
+        model._tri_obj = model.triangles                 # same object next time: skip the host-side comparison
     img_t = (img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))).to(model.device)
     H, W, ch = img_t.shape
     overlap = img_t.clone()
