@@ -152,6 +152,23 @@ int syn_rasterize(syn_handle *h, const float *vertices, const float *colors, int
 int syn_add_weighted(syn_handle *h, const uint8_t *a, float alpha, const uint8_t *b, float beta, uint8_t *out,
                      size_t n, void *stream);
 
+/* ---- FaceBoxes face detector: the boxes get_all_outputs crops (synergy3DMM.py:169-171) ----
+ * syn_detector_flat_count / syn_load_detector: FaceBoxesNet's state_dict (FaceBoxes/models/faceboxes.py:64-114) flattened in
+ * forward order -- conv1, conv2, inception{1,2,3}.{branch1x1, branch1x1_2, branch3x3_reduce, branch3x3, branch3x3_reduce_2,
+ * branch3x3_2, branch3x3_3}, conv3_1, conv3_2, conv4_1, conv4_2: weight [cout,cin,k,k] | bn weight | bias | running_mean |
+ * running_var;  then loc.i, conf.i (i = 0..2): weight | bias.  Host pointer. */
+size_t syn_detector_flat_count(void);
+int syn_load_detector(syn_handle *h, const float *flat, size_t count);
+/* number of priors for a frame (FaceBoxes/utils/prior_box.py:20) after the optional down-scaling */
+int syn_detector_prior_count(int H, int W, float scale);
+/* FaceBoxes.__call__ (FaceBoxes/FaceBoxes.py:60-127) on one uint8 BGR frame [H,W,3] (device): optional bilinear down-scaling
+ * by `scale` (the caller computes it like :63-70; 1 = none), mean subtraction, network, priors, decoding, score > conf_thr,
+ * top_k by score, NMS (cpu_nms.pyx semantics, IoU >= nms_thr suppresses), first keep_top_k rows.
+ * dets: device [keep_top_k,5] (x1, y1, x2, y2, score) in original-frame pixels, score-descending; n_dets: HOST int, rows
+ * valid (the call synchronises `stream`).  The vis_thres filter (:133-140) is the caller's. */
+int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k,
+               int keep_top_k, float *dets, int *n_dets, void *stream);
+
 /* predict_pose (utils/inference.py:146-157 -> parse_pose :86-92 -> P2sRt :33-43 ->
  * matrix2angle_corr :45-62).  angles [B,3] degrees (double, like the reference's python
  * floats), t3d [B,3] fp32 with the ROI affine on x,y; roi may be NULL. */

@@ -43,6 +43,11 @@ _SIGS = {
     'syn_backbone_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_backbone_forward_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_crop_resize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    'syn_detector_flat_count': (C.c_size_t, []),
+    'syn_load_detector': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'syn_detector_prior_count': (C.c_int, [C.c_int, C.c_int, C.c_float]),
+    'syn_detect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                             C.POINTER(C.c_int), C.c_void_p]),
     'syn_load_triangles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'syn_mesh_shade': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_rasterize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -58,7 +63,8 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(_SIGS)          # exactly the symbols include/synergy_hip.h declares
 # test hook exported by the library but deliberately not part of the public header
 _SIGS = dict(_SIGS, syn_debug_feature=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-             syn_debug_profile_block=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]))
+             syn_debug_profile_block=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+             syn_debug_detect_raw=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5))
 
 
 def lib():

@@ -121,6 +121,18 @@ void launch_rasterize(const float *vertices, const int *tri, const float *colors
 void launch_add_weighted(const unsigned char *a, float alpha, const unsigned char *b, float beta, unsigned char *out, size_t n,
                          hipStream_t s);
 
+// ---- FaceBoxes detector (detector_kernels.hip) ----
+void launch_det_preproc(const unsigned char *frame, int H, int W, float *out, int Ho, int Wo, hipStream_t s);
+void launch_det_conv(const float *in, const float *Wt, const float *shift, float *out, int Hi, int Wi, int cs_in, int ci0, int Cin, int Ho,
+                     int Wo, int cs_out, int co0, int Cout, int K, int stride, int pad, int act, hipStream_t s);
+void launch_det_pool(const float *in, float *out, int Hi, int Wi, int C, int Ho, int Wo, int stride, int is_max, hipStream_t s);
+void launch_det_decode(const float *loc, const float *conf, int P, int Hn, int Wn, int H4, int W4, int H5, int W5, int H6, int W6,
+                       float scale, float thr, float *cand, int *n_cand, int max_cand, float *boxes_out, float *scores_out,
+                       hipStream_t s);
+void launch_det_nms(const float *cand, const int *n_cand, int max_cand, int top_k, float nms_thr, int keep_top_k, float *dets, int *n_out,
+                    hipStream_t s);
+int det_sort_capacity();
+
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
                  double *angles, float *t3d, int B, hipStream_t s);
 

@@ -243,6 +243,10 @@ struct syn_handle {
     int ntri = 0, tri_nver = 0;
     void *rws = nullptr;           // render scratch: tri normals | min/max keys | z keys
     size_t rws_bytes = 0;
+    // FaceBoxes detector: packed weights + per-frame scratch (syn_load_detector / syn_detect)
+    float *d_det = nullptr;
+    void *dws = nullptr;
+    size_t dws_bytes = 0;
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
                                    // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
 };
@@ -500,6 +504,8 @@ int syn_destroy(syn_handle *h) {
     if (h->d_adj_off) (void)hipFree(h->d_adj_off);
     if (h->d_adj_tri) (void)hipFree(h->d_adj_tri);
     if (h->rws) (void)hipFree(h->rws);
+    if (h->d_det) (void)hipFree(h->d_det);
+    if (h->dws) (void)hipFree(h->dws);
     delete h;
     return SYN_OK;
 }
@@ -1049,6 +1055,183 @@ int syn_add_weighted(syn_handle *h, const uint8_t *a, float alpha, const uint8_t
     if (n) syn::launch_add_weighted(a, alpha, b, beta, out, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FaceBoxes detector
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DetConv { int cin, cout, k, stride, pad, kind; size_t src, w, shift; };     // kind: 0 crelu, 1 bn+relu, 2 head (bias)
+struct DetNet {
+    std::vector<DetConv> convs;
+    size_t flat_count = 0, packed_count = 0;
+    DetNet() {
+        auto add = [&](int cin, int cout, int k, int st, int pad, int kind) {
+            DetConv c{cin, cout, k, st, pad, kind, flat_count, packed_count, 0};
+            flat_count += (size_t)cout * cin * k * k + (kind == 2 ? cout : 4 * cout);
+            const int cp = round_up(cout, 4);
+            packed_count += (size_t)k * k * cin * cp;
+            c.shift = packed_count;
+            packed_count += cp;
+            convs.push_back(c);
+        };
+        add(3, 24, 7, 4, 3, 0); add(48, 64, 5, 2, 2, 0);                          // faceboxes.py:71-72
+        for (int i = 0; i < 3; ++i) {                                              // Inception :21-30
+            add(128, 32, 1, 1, 0, 1); add(128, 32, 1, 1, 0, 1); add(128, 24, 1, 1, 0, 1); add(24, 32, 3, 1, 1, 1);
+            add(128, 24, 1, 1, 0, 1); add(24, 32, 3, 1, 1, 1); add(32, 32, 3, 1, 1, 1);
+        }
+        add(128, 128, 1, 1, 0, 1); add(128, 256, 3, 2, 1, 1); add(256, 128, 1, 1, 0, 1); add(128, 256, 3, 2, 1, 1);   // :78-82
+        const int hc[3] = {128, 256, 256}, ha[3] = {21, 1, 1};
+        for (int i = 0; i < 3; ++i) { add(hc[i], ha[i] * 4, 3, 1, 1, 2); add(hc[i], ha[i] * 2, 3, 1, 1, 2); }          // :104-114
+    }
+};
+const DetNet &detnet() { static DetNet n; return n; }
+int ensure_dws(syn_handle *h, size_t bytes) {
+    if (bytes <= h->dws_bytes) return SYN_OK;
+    if (h->dws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->dws)); h->dws = nullptr; h->dws_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->dws, bytes));
+    h->dws_bytes = bytes;
+    return SYN_OK;
+}
+int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+}  // namespace
+
+size_t syn_detector_flat_count(void) { return detnet().flat_count; }
+
+int syn_load_detector(syn_handle *h, const float *flat, size_t count) {
+    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_detector: NULL argument");
+    const DetNet &n = detnet();
+    if (count != n.flat_count) return fail(SYN_ERR_INVALID, "syn_load_detector: %zu floats given, %zu expected", count, n.flat_count);
+    std::vector<float> pk(n.packed_count, 0.f);
+    for (const DetConv &c : n.convs) {
+        const float *w = flat + c.src;
+        const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
+        const int cp = round_up(c.cout, 4);
+        std::vector<float> sc(c.cout, 1.f), sh(c.cout, 0.f);
+        if (c.kind == 2) { for (int o = 0; o < c.cout; ++o) sh[o] = w[wn + o]; }
+        else {
+            const float *g = w + wn, *b = g + c.cout, *m = b + c.cout, *v = m + c.cout;
+            for (int o = 0; o < c.cout; ++o) { sc[o] = g[o] * (1.0f / sqrtf(v[o] + 1e-5f)); sh[o] = b[o] - m[o] * sc[o]; }
+        }
+        for (int o = 0; o < c.cout; ++o) {
+            for (int ci = 0; ci < c.cin; ++ci)
+                for (int ky = 0; ky < c.k; ++ky)
+                    for (int kx = 0; kx < c.k; ++kx)
+                        pk[c.w + ((size_t)(ky * c.k + kx) * c.cin + ci) * cp + o] = w[(((size_t)o * c.cin + ci) * c.k + ky) * c.k + kx] * sc[o];
+            pk[c.shift + o] = sh[o];
+        }
+    }
+    DeviceGuard g(h->device);
+    if (!h->d_det) HIP_TRY(hipMalloc((void **)&h->d_det, n.packed_count * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_det, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
+    return SYN_OK;
+}
+
+// Runs the detector on one uint8 BGR frame (device).  scale: 1 or the down-scaling factor FaceBoxes.__call__ computes
+// (FaceBoxes.py:63-80).  dets [keep_top_k,5] device, n_dets: HOST int (the call synchronises the stream to return it).
+// raw_loc / raw_conf / raw_boxes / raw_scores: optional device outputs of the network / decoder (tests).
+static int run_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k,
+                      int keep_top_k, float *dets, int *n_dets, float *raw_loc, float *raw_conf, float *raw_boxes,
+                      float *raw_scores, hipStream_t s) {
+    const DetNet &n = detnet();
+    const int Hn = scale == 1.0f ? H : (int)(scale * H), Wn = scale == 1.0f ? W : (int)(scale * W);
+    if (Hn < 1 || Wn < 1) return fail(SYN_ERR_INVALID, "syn_detect: scaled frame %dx%d", Hn, Wn);
+    const int H1 = cdiv_i(Hn, 4), W1 = cdiv_i(Wn, 4), H2 = cdiv_i(H1, 2), W2 = cdiv_i(W1, 2), H3 = cdiv_i(H2, 2), W3 = cdiv_i(W2, 2);
+    const int H4 = cdiv_i(H3, 2), W4 = cdiv_i(W3, 2), H5 = cdiv_i(H4, 2), W5 = cdiv_i(W4, 2), H6 = cdiv_i(H5, 2), W6 = cdiv_i(W5, 2);
+    const int P = H4 * W4 * 21 + H5 * W5 + H6 * W6;
+    const int max_cand = syn::det_sort_capacity();
+    // scratch carve (floats)
+    size_t off = 0;
+    auto carve = [&](size_t nfl) { const size_t o = off; off += (nfl + 63) & ~(size_t)63; return o; };
+    const size_t o_img = carve((size_t)Hn * Wn * 3), o_c1 = carve((size_t)H1 * W1 * 48), o_p1 = carve((size_t)H2 * W2 * 48);
+    const size_t o_c2 = carve((size_t)H3 * W3 * 128), o_xa = carve((size_t)H4 * W4 * 128), o_xb = carve((size_t)H4 * W4 * 128);
+    const size_t o_pool = carve((size_t)H4 * W4 * 128), o_r1 = carve((size_t)H4 * W4 * 24), o_r2 = carve((size_t)H4 * W4 * 24);
+    const size_t o_t = carve((size_t)H4 * W4 * 32), o_31 = carve((size_t)H4 * W4 * 128), o_32 = carve((size_t)H5 * W5 * 256);
+    const size_t o_41 = carve((size_t)H5 * W5 * 128), o_42 = carve((size_t)H6 * W6 * 256);
+    const size_t o_loc = carve((size_t)P * 4), o_conf = carve((size_t)P * 2), o_cand = carve((size_t)max_cand * 6), o_cnt = carve(64);
+    int rc = ensure_dws(h, off * sizeof(float));
+    if (rc) return rc;
+    float *B0 = (float *)h->dws;
+    const float *Wd = h->d_det;
+    size_t li = 0;
+    auto conv = [&](const float *in, int Hi, int Wi, int cs_in, int ci0, float *out, int Ho, int Wo, int cs_out, int co0) {
+        const DetConv &c = n.convs[li++];
+        syn::launch_det_conv(in, Wd + c.w, Wd + c.shift, out, Hi, Wi, cs_in, ci0, c.cin, Ho, Wo, cs_out, co0, c.cout, c.k, c.stride, c.pad,
+                             c.kind == 0 ? 2 : (c.kind == 1 ? 1 : 0), s);
+    };
+    syn::launch_det_preproc(frame, H, W, B0 + o_img, Hn, Wn, s);
+    conv(B0 + o_img, Hn, Wn, 3, 0, B0 + o_c1, H1, W1, 48, 0);                                   // conv1 (CReLU -> 48)
+    syn::launch_det_pool(B0 + o_c1, B0 + o_p1, H1, W1, 48, H2, W2, 2, 1, s);
+    conv(B0 + o_p1, H2, W2, 48, 0, B0 + o_c2, H3, W3, 128, 0);                                  // conv2 (CReLU -> 128)
+    syn::launch_det_pool(B0 + o_c2, B0 + o_xa, H3, W3, 128, H4, W4, 2, 1, s);
+    float *x = B0 + o_xa, *y = B0 + o_xb;
+    for (int i = 0; i < 3; ++i) {                                                               // Inception: cat[b1, b2, b3, b4]
+        conv(x, H4, W4, 128, 0, y, H4, W4, 128, 0);                                             // branch1x1
+        syn::launch_det_pool(x, B0 + o_pool, H4, W4, 128, H4, W4, 1, 0, s);
+        conv(B0 + o_pool, H4, W4, 128, 0, y, H4, W4, 128, 32);                                  // branch1x1_2(avg_pool)
+        conv(x, H4, W4, 128, 0, B0 + o_r1, H4, W4, 24, 0);                                      // branch3x3_reduce
+        conv(B0 + o_r1, H4, W4, 24, 0, y, H4, W4, 128, 64);                                     // branch3x3
+        conv(x, H4, W4, 128, 0, B0 + o_r2, H4, W4, 24, 0);                                      // branch3x3_reduce_2
+        conv(B0 + o_r2, H4, W4, 24, 0, B0 + o_t, H4, W4, 32, 0);                                // branch3x3_2
+        conv(B0 + o_t, H4, W4, 32, 0, y, H4, W4, 128, 96);                                      // branch3x3_3
+        float *t2 = x; x = y; y = t2;
+    }
+    conv(x, H4, W4, 128, 0, B0 + o_31, H4, W4, 128, 0);
+    conv(B0 + o_31, H4, W4, 128, 0, B0 + o_32, H5, W5, 256, 0);
+    conv(B0 + o_32, H5, W5, 256, 0, B0 + o_41, H5, W5, 128, 0);
+    conv(B0 + o_41, H5, W5, 128, 0, B0 + o_42, H6, W6, 256, 0);
+    // multibox heads: NHWC conv outputs ARE the permuted / flattened loc and conf vectors (faceboxes.py:137-142)
+    float *loc = B0 + o_loc, *conf = B0 + o_conf;
+    const float *srcs[3] = {x, B0 + o_32, B0 + o_42};
+    const int sh_[3] = {H4, H5, H6}, sw_[3] = {W4, W5, W6}, sc_[3] = {128, 256, 256}, sa[3] = {21, 1, 1};
+    size_t lo = 0, co = 0;
+    for (int i = 0; i < 3; ++i) {
+        conv(srcs[i], sh_[i], sw_[i], sc_[i], 0, loc + lo, sh_[i], sw_[i], sa[i] * 4, 0);
+        conv(srcs[i], sh_[i], sw_[i], sc_[i], 0, conf + co, sh_[i], sw_[i], sa[i] * 2, 0);
+        lo += (size_t)sh_[i] * sw_[i] * sa[i] * 4; co += (size_t)sh_[i] * sw_[i] * sa[i] * 2;
+    }
+    int *cnt = (int *)(B0 + o_cnt);
+    syn::launch_det_decode(loc, conf, P, Hn, Wn, H4, W4, H5, W5, H6, W6, scale, conf_thr, B0 + o_cand, cnt, max_cand, raw_boxes, raw_scores, s);
+    syn::launch_det_nms(B0 + o_cand, cnt, max_cand, top_k, nms_thr, keep_top_k, dets, cnt + 1, s);
+    if (raw_loc) HIP_TRY(hipMemcpyAsync(raw_loc, loc, sizeof(float) * 4 * P, hipMemcpyDeviceToDevice, s));
+    if (raw_conf) HIP_TRY(hipMemcpyAsync(raw_conf, conf, sizeof(float) * 2 * P, hipMemcpyDeviceToDevice, s));
+    int host_cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    if (host_cnt[0] > max_cand)
+        return fail(SYN_ERR_INVALID, "syn_detect: %d priors pass the confidence threshold, more than the %d the sorter holds", host_cnt[0], max_cand);
+    *n_dets = host_cnt[1];
+    return SYN_OK;
+}
+
+int syn_detector_prior_count(int H, int W, float scale) {
+    const int Hn = scale == 1.0f ? H : (int)(scale * H), Wn = scale == 1.0f ? W : (int)(scale * W);
+    return cdiv_i(Hn, 32) * cdiv_i(Wn, 32) * 21 + cdiv_i(Hn, 64) * cdiv_i(Wn, 64) + cdiv_i(Hn, 128) * cdiv_i(Wn, 128);
+}
+
+int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k, int keep_top_k,
+               float *dets, int *n_dets, void *stream) {
+    if (!h || !frame || !dets || !n_dets) return fail(SYN_ERR_INVALID, "syn_detect: NULL argument");
+    if (H <= 0 || W <= 0 || !(scale > 0.f) || scale > 1.f || top_k <= 0 || keep_top_k <= 0)
+        return fail(SYN_ERR_INVALID, "syn_detect: H=%d W=%d scale=%g top_k=%d keep_top_k=%d", H, W, (double)scale, top_k, keep_top_k);
+    if (!h->d_det) return fail(SYN_ERR_NOT_LOADED, "syn_detect: detector weights not loaded");
+    DeviceGuard g(h->device);
+    return run_detect(h, frame, H, W, scale, conf_thr, nms_thr, top_k, keep_top_k, dets, n_dets, nullptr, nullptr, nullptr, nullptr,
+                      (hipStream_t)stream);
+}
+
+// Test hook, not part of include/synergy_hip.h: network outputs and decoded boxes / scores of every prior.
+int syn_debug_detect_raw(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float *loc, float *conf, float *boxes,
+                         float *scores, void *stream) {
+    if (!h || !frame || !h->d_det) return fail(SYN_ERR_INVALID, "syn_debug_detect_raw: bad argument");
+    DeviceGuard g(h->device);
+    float *dets = nullptr;
+    HIP_TRY(hipMalloc((void **)&dets, 750 * 5 * sizeof(float)));
+    int nd = 0;
+    int rc = run_detect(h, frame, H, W, scale, 0.05f, 0.3f, 5000, 750, dets, &nd, loc, conf, boxes, scores, (hipStream_t)stream);
+    (void)hipFree(dets);
+    return rc;
 }
 
 int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles, float *t3d, void *stream) {

@@ -379,13 +379,15 @@ class SynergyNet(nn.Module):
 
         All faces of the image go through ONE batched launch chain instead of the reference's
         per-face loop.  `rects` = detections [[xmin,ymin,xmax,ymax,score], ...]; when omitted the
-        pluggable `face_detector(image)` is called (the reference constructs FaceBoxes here,
-        :170-171; that detector is outside this repo's scope)."""
+        `face_detector(image)` is called -- by default the HIP FaceBoxes of synergynet_amd/faceboxes.py (the
+        reference constructs FaceBoxes here, :170-171)."""
         from .inference import lanczos4_tables
         if rects is None:
             if self.face_detector is None:
-                raise RuntimeError('no face detector: pass rects=[[xmin,ymin,xmax,ymax,score],...] or set '
-                                   'model.face_detector (FaceBoxes is outside the scope of this hot-path library)')
+                # the reference builds FaceBoxes() on every call (:170-171); here once, on first use (HIP kernels,
+                # synergynet_amd/faceboxes.py; needs FaceBoxes/weights/FaceBoxesProd.pth or model.face_detector = FaceBoxes(state_dict=...))
+                from .faceboxes import FaceBoxes
+                self.face_detector = FaceBoxes(device=self.device)
             rects = self.face_detector(input)
         pts_res, vertices_lst, poses = [], [], []
         if len(rects) == 0:

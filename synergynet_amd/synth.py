@@ -271,3 +271,60 @@ def make_face_meshes(n_faces: int, rows: int = 231, cols: int = 231, n_vert: int
     if n_vert is not None:
         out = out[:, :, :n_vert]
     return np.ascontiguousarray(out, dtype=np.float32)
+
+
+# ---- FaceBoxes detector: layer table shared by the oracle, the packer and the tests ----
+def faceboxes_convs():
+    """(state_dict prefix, cin, cout, k, stride, pad, kind) for every convolution of FaceBoxesNet in forward order
+    (reference FaceBoxes/models/faceboxes.py:64-150).  kind: 'crelu' (conv+BN, cat[x,-x], ReLU :48-61), 'bn' (conv+BN+ReLU
+    :8-18), 'head' (conv with bias, no activation :104-114)."""
+    L = [('conv1', 3, 24, 7, 4, 3, 'crelu'), ('conv2', 48, 64, 5, 2, 2, 'crelu')]
+    for i in (1, 2, 3):
+        p = f'inception{i}.'
+        L += [(p + 'branch1x1', 128, 32, 1, 1, 0, 'bn'), (p + 'branch1x1_2', 128, 32, 1, 1, 0, 'bn'),
+              (p + 'branch3x3_reduce', 128, 24, 1, 1, 0, 'bn'), (p + 'branch3x3', 24, 32, 3, 1, 1, 'bn'),
+              (p + 'branch3x3_reduce_2', 128, 24, 1, 1, 0, 'bn'), (p + 'branch3x3_2', 24, 32, 3, 1, 1, 'bn'),
+              (p + 'branch3x3_3', 32, 32, 3, 1, 1, 'bn')]
+    L += [('conv3_1', 128, 128, 1, 1, 0, 'bn'), ('conv3_2', 128, 256, 3, 2, 1, 'bn'),
+          ('conv4_1', 256, 128, 1, 1, 0, 'bn'), ('conv4_2', 128, 256, 3, 2, 1, 'bn')]
+    for i, (cin, a) in enumerate(((128, 21), (256, 1), (256, 1))):
+        L += [(f'loc.{i}', cin, a * 4, 3, 1, 1, 'head'), (f'conf.{i}', cin, a * 2, 3, 1, 1, 'head')]
+    return L
+
+
+def make_faceboxes_state(seed: int = 1357) -> dict:
+    """Seeded FaceBoxesNet state_dict (numpy): variance-preserving conv weights, randomised BN statistics, head biases tuned
+    so that a few hundred priors pass the 0.05 confidence threshold and a handful pass 0.5 on noise images."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, cin, cout, k, _, _, kind in faceboxes_convs():
+        fan = cin * k * k
+        w = rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / fan)
+        if name == 'conv1':
+            w /= 60.0                                            # pixels minus mean are O(100): bring activations to O(1)
+        if kind == 'head':
+            sd[name + '.weight'] = (w * (1.2 if name.startswith('conf') else 0.25)).astype(np.float32)
+            b = rng.standard_normal(cout) * 0.1
+            if name.startswith('conf'):
+                b[0::2] += 4.0                                   # background logit ahead: most priors are negatives
+            sd[name + '.bias'] = b.astype(np.float32)
+        else:
+            sd[name + '.conv.weight'] = w.astype(np.float32)
+            sd[name + '.bn.weight'] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            sd[name + '.bn.bias'] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            sd[name + '.bn.running_mean'] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            sd[name + '.bn.running_var'] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+    return sd
+
+
+def make_frame(height: int, width: int, seed: int = 11) -> np.ndarray:
+    """uint8 BGR frame [H,W,3]: low-pass noise with a few bright blobs."""
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0, 255, (height, width, 3)).astype(np.float32)
+    for _ in range(2):
+        f = (f + np.roll(f, 1, 0) + np.roll(f, -1, 0) + np.roll(f, 1, 1) + np.roll(f, -1, 1)) / 5.0
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(4):
+        cy, cx, r = rng.uniform(0.2, 0.8) * height, rng.uniform(0.2, 0.8) * width, rng.uniform(0.05, 0.15) * min(height, width)
+        f += 90.0 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r))[:, :, None]
+    return np.clip(np.rint(f), 0, 255).astype(np.uint8)

@@ -184,7 +184,58 @@ def main_render():
     print('wrote', path, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, 'KB')
 
 
+def main_faceboxes():
+    """the reference's own FaceBoxesNet / PriorBox / decode (torch + numpy only, importable as they are) and
+    its pure-python NMS with the comparison of the Cython variant the wrapper dispatches to, glued exactly like
+    FaceBoxes.__call__ (FaceBoxes.py:60-143) on seeded weights and frames -> tests/golden/faceboxes_golden.npz.
+    Frames stay below 720x1080 here: the down-scaling branch needs cv2.resize, which is absent (restated, unpinned)."""
+    import importlib
+    import types
+    fbroot = os.path.join(ref_loader.REF_ROOT, 'FaceBoxes')
+    # import the sub-modules without running FaceBoxes/__init__.py (which imports cv2 and the Cython NMS)
+    pkg = types.ModuleType('FaceBoxes'); pkg.__path__ = [fbroot]; sys.modules['FaceBoxes'] = pkg
+    for sub in ('models', 'utils'):
+        m = types.ModuleType('FaceBoxes.' + sub); m.__path__ = [os.path.join(fbroot, sub)]; sys.modules['FaceBoxes.' + sub] = m
+    net_mod = importlib.import_module('FaceBoxes.models.faceboxes')
+    prior_mod = importlib.import_module('FaceBoxes.utils.prior_box')
+    box_mod = importlib.import_module('FaceBoxes.utils.box_utils')
+    cfg = importlib.import_module('FaceBoxes.utils.config').cfg
+    sd = synth.make_faceboxes_state()
+    net = net_mod.FaceBoxesNet(phase='test', size=None, num_classes=2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)      # num_batches_tracked stays default
+    net.eval()
+    from oracle import faceboxes_torch as ofb
+    out = {}
+    for tag, (hh, ww) in (('a', (300, 420)), ('b', (97, 131)), ('c', (64, 64))):
+        frame = synth.make_frame(hh, ww, seed=hh)
+        img = np.float32(frame)
+        scale_bbox = torch.Tensor([img.shape[1], img.shape[0], img.shape[1], img.shape[0]])
+        img -= (104, 117, 123)
+        with torch.no_grad():
+            loc, conf = net(torch.from_numpy(img.transpose(2, 0, 1)).unsqueeze(0))
+        priors = prior_mod.PriorBox(image_size=(hh, ww)).forward()
+        boxes = box_mod.decode(loc.data.squeeze(0), priors.data, cfg['variance'])
+        boxes = (boxes * scale_bbox / 1 / 1).cpu().numpy()
+        scores = conf.squeeze(0).data.cpu().numpy()[:, 1]
+        inds = np.where(scores > 0.05)[0]
+        boxes, scores = boxes[inds], scores[inds]
+        order = scores.argsort()[::-1][:5000]
+        dets = np.hstack((boxes[order], scores[order][:, np.newaxis])).astype(np.float32, copy=False)
+        keep = ofb.cpu_nms(dets, 0.3) if dets.shape[0] else []      # cpu_nms.pyx semantics (restated: the Cython module is not built)
+        out[tag + '_loc'] = loc.numpy()[0]
+        out[tag + '_conf'] = conf.numpy()[0]
+        out[tag + '_priors'] = priors.numpy()
+        out[tag + '_dets'] = dets[keep, :][:750]
+        out[tag + '_hw'] = np.array([hh, ww])
+    path = os.path.join(HERE, 'faceboxes_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, 'KB')
+    for k in [k for k in sys.modules if k == 'FaceBoxes' or k.startswith('FaceBoxes.')]:
+        del sys.modules[k]
+
+
 if __name__ == '__main__':
     main()
     main_resnet50()
     main_render()
+    main_faceboxes()

@@ -1,0 +1,110 @@
+"""GPU parity of the FaceBoxes detector through the C ABI (syn_load_detector / syn_detect) against the torch
+oracle and against fixtures produced by the REAL reference modules.  Tolerance: fp32 network outputs 1e-4 relative (different
+summation order than torch's convolutions), box coordinates 1e-2 px, scores 1e-5; the SET of detections must be the same."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def det():
+    from synergynet_amd import synth
+    from synergynet_amd.faceboxes import FaceBoxes
+    return FaceBoxes(state_dict=synth.make_faceboxes_state())
+
+
+@pytest.fixture(scope='module')
+def fgold():
+    return dict(np.load(os.path.join(HERE, 'golden', 'faceboxes_golden.npz')))
+
+
+def _raw(det, frame, scale=1.0):
+    import torch
+    from synergynet_amd import abi
+    h, w = frame.shape[:2]
+    P = det._lib.syn_detector_prior_count(h, w, C.c_float(scale))
+    loc = torch.empty((P, 4), device='cuda'); conf = torch.empty((P, 2), device='cuda')
+    boxes = torch.empty((P, 4), device='cuda'); scores = torch.empty((P,), device='cuda')
+    f = torch.from_numpy(frame).cuda()
+    abi.check(abi.lib().syn_debug_detect_raw(det._h, f.data_ptr(), h, w, C.c_float(scale), loc.data_ptr(), conf.data_ptr(), boxes.data_ptr(),
+                                             scores.data_ptr(), None))
+    return loc.cpu().numpy(), conf.cpu().numpy(), boxes.cpu().numpy(), scores.cpu().numpy()
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_network_priors_and_detections_match_reference_golden(det, fgold, tag):
+    from synergynet_amd import synth
+    hh, ww = [int(v) for v in fgold[tag + '_hw']]
+    frame = synth.make_frame(hh, ww, seed=hh)
+    loc, conf, boxes, scores = _raw(det, frame)
+    assert loc.shape == fgold[tag + '_loc'].shape
+    assert np.abs(loc - fgold[tag + '_loc']).max() / np.abs(fgold[tag + '_loc']).max() < 1e-4
+    np.testing.assert_allclose(scores, fgold[tag + '_conf'][:, 1], rtol=0, atol=1e-5)       # softmax of the logits
+    dets = det.detect_all(frame)
+    want = fgold[tag + '_dets']
+    assert dets.shape == want.shape
+    np.testing.assert_allclose(dets[:, 4], want[:, 4], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(dets[:, :4], want[:, :4], rtol=0, atol=1e-2)
+
+
+def test_decoded_boxes_match_oracle_for_every_prior(det):
+    import torch
+    from oracle import faceboxes_torch as ofb
+    from synergynet_amd import synth
+    sd = synth.make_faceboxes_state()
+    frame = synth.make_frame(200, 333, seed=8)
+    _, _, boxes, scores = _raw(det, frame)
+    img = np.float32(frame) - np.array((104, 117, 123), dtype=np.float32)
+    loc, conf = ofb.net_forward(sd, torch.from_numpy(img.transpose(2, 0, 1)).unsqueeze(0))
+    want = ofb.decode(loc.squeeze(0), ofb.prior_boxes((200, 333)), ofb.CFG['variance']) * torch.Tensor([333, 200, 333, 200])
+    np.testing.assert_allclose(boxes, want.numpy(), rtol=0, atol=2e-2)
+    np.testing.assert_allclose(scores, conf[0, :, 1].numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('hw', [(720, 1080), (800, 1300), (1500, 900), (33, 47)])
+def test_detections_match_oracle_including_downscaled_frames(det, hw):
+    """Frames above 720x1080 take the bilinear down-scaling branch (FaceBoxes.py:63-80); tiny frames have one prior cell."""
+    from oracle import faceboxes_torch as ofb
+    from synergynet_amd import synth
+    sd = synth.make_faceboxes_state()
+    frame = synth.make_frame(*hw, seed=hw[1])
+    want = ofb.detect(sd, frame, return_all=True)
+    got = det.detect_all(frame)
+    assert got.shape == want.shape
+    if want.shape[0]:
+        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=5e-2)
+    rects = det(frame)
+    assert rects == [[b[0], b[1], b[2], b[3], b[4]] for b in got if b[4] > 0.5]
+
+
+def test_reference_package_name_and_errors(det):
+    import FaceBoxes as pkg
+    from synergynet_amd import faceboxes
+    assert pkg.FaceBoxes is faceboxes.FaceBoxes
+    with pytest.raises(ValueError):
+        det.detect_all(np.zeros((10, 10), dtype=np.uint8))
+    with pytest.raises(RuntimeError):
+        faceboxes.FaceBoxes(weights_path='/nonexistent/FaceBoxesProd.pth')
+
+
+def test_image_to_outputs_with_the_device_detector(det):
+    """get_all_outputs with no rects: detector -> crops -> backbone -> landmarks / meshes / poses, all on the device, equals
+    the same call with the detector's boxes passed in (synergy3DMM.py:167-207)."""
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_backbone_state(), face_detector=det)
+    frame = synth.make_frame(300, 420, seed=300)
+    rects = det(frame)
+    assert 0 < len(rects)
+    lmk, mesh, pose = m.get_all_outputs(frame)
+    lmk2, mesh2, pose2 = m.get_all_outputs(frame, rects=[list(r) for r in rects])
+    assert len(lmk) == len(rects) == len(mesh) == len(pose)
+    assert lmk[0].shape == (3, 68) and mesh[0].shape == (3, 640)
+    for a, b in zip(lmk, lmk2):
+        assert np.array_equal(a, b)
