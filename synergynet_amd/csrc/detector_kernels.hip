@@ -173,7 +173,9 @@ __global__ __launch_bounds__(1024) void det_nms_kernel(const float *__restrict__
     n = n < max_cand ? n : max_cand;
     n = n < kSortN ? n : kSortN;
     const int tid = threadIdx.x;
-    for (int i = tid; i < kSortN; i += 1024) {
+    int sn = 1024;                                     // sort network size: next power of two >= n (>= one element per thread)
+    while (sn < n) sn <<= 1;
+    for (int i = tid; i < sn; i += 1024) {
         unsigned long long k = 0ull;
         if (i < n) {
             const unsigned sb = __builtin_bit_cast(unsigned, cand[(size_t)i * 6 + 4]);       // scores are positive: bit order = value order
@@ -184,9 +186,9 @@ __global__ __launch_bounds__(1024) void det_nms_kernel(const float *__restrict__
     }
     if (tid == 0) n_keep = 0;
     __syncthreads();
-    for (int k2 = 2; k2 <= kSortN; k2 <<= 1)
+    for (int k2 = 2; k2 <= sn; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < kSortN; i += 1024) {
+            for (int i = tid; i < sn; i += 1024) {
                 const int l = i ^ j;
                 if (l > i) {
                     const bool desc = (i & k2) == 0;
