@@ -169,6 +169,10 @@ int syn_detector_prior_count(int H, int W, float scale);
 int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k,
                int keep_top_k, float *dets, int *n_dets, void *stream);
 
+/* calc_nme (benchmark_aflw2000.py:107-139): fit [N,2,68] fitted landmarks in 120x120 crop coordinates, gt [N,3,68] ground truth
+ * in image coordinates, roi [N,4] crop boxes (sx, sy, ex, ey) -> nme [N] float32.  All device pointers. */
+int syn_nme(syn_handle *h, const float *fit, const float *gt, const float *roi, float *nme, int N, void *stream);
+
 /* predict_pose (utils/inference.py:146-157 -> parse_pose :86-92 -> P2sRt :33-43 ->
  * matrix2angle_corr :45-62).  angles [B,3] degrees (double, like the reference's python
  * floats), t3d [B,3] fp32 with the ROI affine on x,y; roi may be NULL. */

@@ -48,6 +48,7 @@ _SIGS = {
     'syn_detector_prior_count': (C.c_int, [C.c_int, C.c_int, C.c_float]),
     'syn_detect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
                              C.POINTER(C.c_int), C.c_void_p]),
+    'syn_nme': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'syn_load_triangles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'syn_mesh_shade': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_rasterize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -121,6 +121,9 @@ void launch_rasterize(const float *vertices, const int *tri, const float *colors
 void launch_add_weighted(const unsigned char *a, float alpha, const unsigned char *b, float beta, unsigned char *out, size_t n,
                          hipStream_t s);
 
+// ---- AFLW2000-3D landmark error (eval_kernels.hip) ----
+void launch_nme(const float *fit, const float *gt, const float *roi, float *nme, int N, hipStream_t s);
+
 // ---- FaceBoxes detector (detector_kernels.hip) ----
 void launch_det_preproc(const unsigned char *frame, int H, int W, float *out, int Ho, int Wo, hipStream_t s);
 void launch_det_conv(const float *in, const float *Wt, const float *shift, float *out, int Hi, int Wi, int cs_in, int ci0, int Cin, int Ho,

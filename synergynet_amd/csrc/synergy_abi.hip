@@ -1234,6 +1234,15 @@ int syn_debug_detect_raw(syn_handle *h, const uint8_t *frame, int H, int W, floa
     return rc;
 }
 
+int syn_nme(syn_handle *h, const float *fit, const float *gt, const float *roi, float *nme, int N, void *stream) {
+    if (!h || !fit || !gt || !roi || !nme) return fail(SYN_ERR_INVALID, "syn_nme: NULL argument");
+    if (N <= 0) return fail(SYN_ERR_INVALID, "syn_nme: N=%d", N);
+    DeviceGuard g(h->device);
+    syn::launch_nme(fit, gt, roi, nme, N, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
 int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles, float *t3d, void *stream) {
     if (!h || !param || !angles || !t3d) return fail(SYN_ERR_INVALID, "syn_pose: NULL argument");
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_pose: B=%d", B);

@@ -234,8 +234,54 @@ def main_faceboxes():
         del sys.modules[k]
 
 
+def make_eval_inputs(n=96, seed=2024):
+    """Seeded stand-ins for aflw2000_data/eval/*.npy (absent): ground-truth landmarks, crop boxes, yaws, fitted landmarks."""
+    rng = np.random.default_rng(seed)
+    roi = np.stack([rng.uniform(0, 200, n), rng.uniform(0, 200, n)], 1)
+    side = rng.uniform(80, 400, n)
+    roi = np.concatenate([roi, roi + side[:, None]], 1).astype(np.float32)                      # sx, sy, ex, ey
+    fit = rng.uniform(10, 110, (n, 2, 68)).astype(np.float32)                                   # crop coordinates
+    sx, sy, ex, ey = roi.T
+    gt = np.stack([fit[:, 0] * ((ex - sx) / 120)[:, None] + sx[:, None], fit[:, 1] * ((ey - sy) / 120)[:, None] + sy[:, None],
+                   rng.uniform(-50, 50, (n, 68))], 1)
+    gt[:, :2] += rng.standard_normal((n, 2, 68)) * 3.0
+    yaws = rng.uniform(-90, 90, n).astype(np.float32)
+    return fit, gt.astype(np.float32), roi, yaws
+
+
+def main_evaluate():
+    """SURVEY 8f row 4 (data-gated part): the reference's own benchmark_aflw2000.calc_nme / ana with its `_load` patched to
+    serve seeded synthetic ground truth -> tests/golden/evaluate_golden.npz."""
+    import importlib
+    import types
+    fit, gt, roi, yaws = make_eval_inputs()
+    served = {'AFLW2000-3D.pose.npy': yaws, 'AFLW2000-3D.pts68.npy': gt, 'AFLW2000-3D-Reannotated.pts68.npy': gt[:, :, ::-1].copy(),
+              'AFLW2000-3D_crop.roi_box.npy': roi}
+    io_stub = types.ModuleType('utils.io'); io_stub._load = lambda fp: served[os.path.basename(fp)]
+    utils_stub = types.ModuleType('utils'); utils_stub.__path__ = []; utils_stub.io = io_stub
+    saved = {k: sys.modules.get(k) for k in ('utils', 'utils.io', 'benchmark_aflw2000')}
+    sys.modules['utils'], sys.modules['utils.io'] = utils_stub, io_stub
+    sys.modules.pop('benchmark_aflw2000', None)
+    sys.path.insert(0, ref_loader.REF_ROOT)
+    try:
+        ref = importlib.import_module('benchmark_aflw2000')
+        nme = ref.calc_nme([f.copy() for f in fit], option='ori')
+        import contextlib, io as _io
+        with contextlib.redirect_stdout(_io.StringIO()):
+            stats = ref.ana(nme)
+    finally:
+        sys.path.remove(ref_loader.REF_ROOT)
+        for k, v in saved.items():
+            if v is None: sys.modules.pop(k, None)
+            else: sys.modules[k] = v
+    path = os.path.join(HERE, 'evaluate_golden.npz')
+    np.savez_compressed(path, nme=nme, stats=np.array(stats, dtype=np.float64))
+    print('wrote', path, nme.shape, stats)
+
+
 if __name__ == '__main__':
     main()
     main_resnet50()
     main_render()
     main_faceboxes()
+    main_evaluate()
