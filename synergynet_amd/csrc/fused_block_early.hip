@@ -168,6 +168,19 @@ void fused_block_early_kernel(
         psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
     }
     __syncthreads();
+    // the project weight fragments of this wave's output-channel tiles are the same for every tile: registers, not LDS reads
+    u32x4 pa[C::AN][C::NCH][C::KP][3];
+#pragma unroll
+    for (int i = 0; i < C::AN; ++i) {
+        int nt = wn + i * C::WN;
+        nt = nt < C::NT_O ? nt : 0;
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c)
+#pragma unroll
+            for (int kc = 0; kc < C::KP; ++kc)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pa[i][c][kc][p] = *(const u32x4 *)(Wlp + ((size_t)(nt * C::NCH + c) * C::KP + kc) * 768 + p * 256 + lane * 4);
+    }
     // Two groups run the same barrier-separated stage sequence [project(c-1) expand(c)] | [depthwise(c)] | ... one stage
     // apart: while one group's waves feed the matrix pipe (expand / project), the other group's waves on the same SIMDs
     // run the depthwise stage on the VALU.  (s_barrier only counts arrivals, so the groups may sit at different barriers.)
@@ -207,6 +220,7 @@ void fused_block_early_kernel(
 #pragma unroll
             for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];        // BN shift = accumulator start
 
+#pragma unroll
         for (int c = 0; c < C::NCH; ++c) {
             const int hc0 = c * C::HC;
             // ---- stage 1: expand 1x1 (bf16 x3) + BN shift + ReLU6 -> Es (fp32); operands: LDS weights x registers ----
@@ -330,16 +344,9 @@ void fused_block_early_kernel(
                     for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
                 }
 #pragma unroll
-                for (int i = 0; i < C::AN; ++i) {
-                    int nt = wn + i * C::WN;
-                    nt = nt < C::NT_O ? nt : 0;
-                    u32x4 a[3];
-                    const unsigned *wa = Wlp + ((size_t)(nt * C::NCH + c) * C::KP + kc) * 768 + lane * 4;
+                for (int i = 0; i < C::AN; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[p] = *(const u32x4 *)(wa + p * 256);
-#pragma unroll
-                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6e(a, b[j], acc[i][j]);
-                }
+                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6e(pa[i][c][kc], b[j], acc[i][j]);
             }
             SYNE_LAP(5);
             // no barrier: the next stage 1 only writes Es (its readers finished before the barrier above); the D planes
