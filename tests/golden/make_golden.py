@@ -12,6 +12,13 @@ synthetic inputs:
   * utils.inference.predict_sparseVert / predict_denseVert / predict_pose
                                                  (utils/inference.py:127-157)
 
+  * backbone_nets.resnet_backbone.resnet50        -> resnet50_outputs.npz   (main_resnet50)
+  * Sim3DR.RenderPipeline / get_normal / rasterize: the reference's own Python package driving its own C++ rasteriser
+    (compiled from where it lies by oracle/Makefile)  -> render_golden.npz  (main_render)
+  * FaceBoxes.models.faceboxes.FaceBoxesNet, utils.prior_box.PriorBox, utils.box_utils.decode, glued like
+    FaceBoxes.__call__                              -> faceboxes_golden.npz (main_faceboxes)
+  * benchmark_aflw2000.calc_nme / ana on seeded synthetic ground truth -> evaluate_golden.npz (main_evaluate)
+
 The assets themselves (9 MB of weights, 32 MB of basis) are NOT stored: they are
 regenerated bit-identically from the seeds in synergynet_amd/synth.py.  The dense
 mesh is stored as a strided vertex subset plus float64 per-row sums.
