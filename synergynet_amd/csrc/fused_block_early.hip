@@ -80,6 +80,10 @@ struct EarlyCfg {
     static constexpr int PXT = K16 ? 32 : 16;                  // pixels per expand tile
     static constexpr int PT_X = PINP / PXT;
     static constexpr int PPW = cdive(PT_X, GW);                // input pixel tiles owned by a wave
+    // leftover pixel tiles of the last round (PT_X % GW of them): when few (features.3: 9 tiles on 8 waves) one wave -- and its
+    // SIMD -- would carry a whole extra tile per chunk; instead its hidden-channel tiles are dealt to different waves
+    static constexpr int LEFT = PT_X - (PPW - 1) * GW;
+    static constexpr bool SPLIT = CIN_ != 16 && HC / 16 >= 2 && PPW >= 2 && LEFT * (HC / 16) < GW;
     static constexpr int COUTP = rupe(COUT, 16), NT_O = COUTP / 16, NT_E = HC / 16;
     static constexpr int AN = cdive(NT_O, WN), AP = cdive(PT_O, WP);
     static constexpr int ES = HC + 4, DSD = HCP / 2 + 4, DPL = POUTP * DSD;
@@ -121,6 +125,10 @@ void fused_block_early_kernel(
     const int r16 = lane & 15, g = lane >> 4;
     const int xl = C::K16 ? (lane & 31) : r16, xg = C::K16 ? (lane >> 5) : g;   // expand operand: pixel in tile, channel octet
     const int wn = gw % C::WN, wp = gw / C::WN;
+    // SPLIT: wave gw in [1, LEFT*NT_E] expands hidden tile (gw-1) % NT_E of leftover pixel tile (gw-1) / NT_E
+    const bool xvalid = C::SPLIT && gw >= 1 && gw <= C::LEFT * C::NT_E;
+    const int xq = xvalid ? (gw - 1) / C::NT_E : 0, xnt = xvalid ? (gw - 1) % C::NT_E : -1;
+    auto slot_pt = [&](int i) { return (C::SPLIT && i == C::PPW - 1) ? (C::PPW - 1) * C::GW + xq : gw + i * C::GW; };
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, ntiles_done = 0;
 
@@ -132,10 +140,10 @@ void fused_block_early_kernel(
         const int iy0 = ty * C::TH * C::S - 1, ix0 = tx * C::TW * C::S - 1;
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
-            const int p = (gw + i * C::GW) * C::PXT + xl;
+            const int p = slot_pt(i) * C::PXT + xl;
             const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
             xr[i][0] = z4; xr[i][1] = z4;
-            if (p < C::PIN && 8 * xg < C::CIN && (unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) {
+            if ((!C::SPLIT || i < C::PPW - 1 || xvalid) && p < C::PIN && 8 * xg < C::CIN && (unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) {
                 const float *src = &X[((size_t)(f * C::HIN + iy) * C::HIN + ix) * C::CIN + 8 * xg];
                 xr[i][0] = *(const f32x4 *)src;
                 xr[i][1] = *(const f32x4 *)(src + 4);
@@ -207,7 +215,7 @@ void fused_block_early_kernel(
                 xb[i][1][2 * h] = m0; xb[i][1][2 * h + 1] = m1;
                 xb[i][2][2 * h] = l0; xb[i][2][2 * h + 1] = l1;
             }
-            const int p = (gw + i * C::GW) * C::PXT + xl;
+            const int p = slot_pt(i) * C::PXT + xl;
             const int iy = iy0 + p / C::IW, ix = ix0 + p % C::IW;
             ehi[i] = ((unsigned)iy < (unsigned)C::HIN && (unsigned)ix < (unsigned)C::HIN) ? 6.0f : 0.0f;
         }
@@ -267,8 +275,9 @@ void fused_block_early_kernel(
                 const f32x4 sh = *(const f32x4 *)&Ebn[hc0 + nt * 16 + 4 * g];
 #pragma unroll
                 for (int i = 0; i < C::PPW; ++i) {
-                    const int pt = gw + i * C::GW;
+                    const int pt = slot_pt(i);
                     if (pt >= C::PT_IN || !live) break;                 // wave-uniform
+                    if (C::SPLIT && i == C::PPW - 1 && nt != xnt) continue;     // leftover tile: only this wave's share
                     const f32x4 e = mac6e(a, xb[i], sh);
                     f32x4 ev;
 #pragma unroll
