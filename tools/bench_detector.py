@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from synergynet_amd import synth
 from synergynet_amd.faceboxes import FaceBoxes
-from oracle import faceboxes_torch as ofb
+from oracle import faceboxes_torch as ofb  # CPU-baseline leg only (same role as bench.py's cpu_baseline): timed beside, never inside, the GPU path
 sd = synth.make_faceboxes_state()
 det = FaceBoxes(state_dict=sd)
 for hw in ((300, 420), (720, 1080), (1080, 1920)):

@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from synergynet_amd import synth, sim3dr
 from synergynet_amd.synergy3DMM import SynergyNet
-from oracle import sim3dr as osim
+from oracle import sim3dr as osim          # CPU-baseline leg only (same role as bench.py's cpu_baseline): timed beside, never inside, the GPU path
 
 Fs = [int(a) for a in sys.argv[1:]] or [1, 8, 64]
 m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_backbone_state())
