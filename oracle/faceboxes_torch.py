@@ -14,7 +14,6 @@ main_faceboxes) on seeded weights and frames.
 """
 from __future__ import annotations
 
-from itertools import product
 from math import ceil
 
 import numpy as np
@@ -78,26 +77,26 @@ def net_forward(sd, x):
 
 
 def prior_boxes(image_size):
-    """prior_box.py:10-48: [P,4] float32 (cx, cy, w, h) in image-relative units, python-float arithmetic then float32."""
-    anchors = []
-    fmaps = [[ceil(image_size[0] / s), ceil(image_size[1] / s)] for s in CFG['steps']]
-    for k, f in enumerate(fmaps):
-        for i, j in product(range(f[0]), range(f[1])):
-            for min_size in CFG['min_sizes'][k]:
-                s_kx, s_ky = min_size / image_size[1], min_size / image_size[0]
-                if min_size == 32:
-                    dcx = [x * CFG['steps'][k] / image_size[1] for x in [j + 0, j + 0.25, j + 0.5, j + 0.75]]
-                    dcy = [y * CFG['steps'][k] / image_size[0] for y in [i + 0, i + 0.25, i + 0.5, i + 0.75]]
-                    for cy, cx in product(dcy, dcx):
-                        anchors += [cx, cy, s_kx, s_ky]
-                elif min_size == 64:
-                    dcx = [x * CFG['steps'][k] / image_size[1] for x in [j + 0, j + 0.5]]
-                    dcy = [y * CFG['steps'][k] / image_size[0] for y in [i + 0, i + 0.5]]
-                    for cy, cx in product(dcy, dcx):
-                        anchors += [cx, cy, s_kx, s_ky]
-                else:
-                    anchors += [(j + 0.5) * CFG['steps'][k] / image_size[1], (i + 0.5) * CFG['steps'][k] / image_size[0], s_kx, s_ky]
-    return torch.Tensor(anchors).view(-1, 4)
+    """prior_box.py:10-48: [P,4] float32 (cx, cy, w, h) in image-relative units.  The reference builds the list with python
+    floats cell by cell; the same double-precision expressions evaluated array-wise (then cast to float32, as torch.Tensor
+    does) give bit-identical rows in the same order: per cell 16 anchors of 32 px (4x4 dense, y-major), 4 of 64 px (2x2),
+    1 of 128 px on the stride-32 map, then one 256 px anchor per stride-64 cell and one 512 px anchor per stride-128 cell."""
+    H, W = float(image_size[0]), float(image_size[1])
+    rows = []
+    for step, sizes in zip(CFG['steps'], CFG['min_sizes']):
+        fh, fw = ceil(image_size[0] / step), ceil(image_size[1] / step)
+        ii, jj = np.meshgrid(np.arange(fh, dtype=np.float64), np.arange(fw, dtype=np.float64), indexing='ij')
+        per_cell = []
+        for size in sizes:
+            dens = {32: 4, 64: 2}.get(size, 0)
+            offs = [k / dens for k in range(dens)] if dens else [0.5]
+            for oy in offs:
+                for ox in offs:
+                    cx = (jj + ox) * step / W
+                    cy = (ii + oy) * step / H
+                    per_cell.append(np.stack([cx, cy, np.full_like(cx, size / W), np.full_like(cy, size / H)], -1))
+        rows.append(np.stack(per_cell, 2).reshape(-1, 4))            # [fh, fw, anchors, 4] -> cell-major, anchor-minor
+    return torch.from_numpy(np.concatenate(rows, 0).astype(np.float32))
 
 
 def decode(loc, priors, variances):                   # box_utils.py:177-196

@@ -76,65 +76,67 @@ def rasterize(vertices, triangles, colors, bg=None, height=None, width=None, cha
     return bg
 
 
-_norm = lambda arr: arr / np.sqrt(np.sum(arr ** 2, axis=1))[:, None]       # lighting.py:6
-
-
-def norm_vertices(vertices):                                                 # lighting.py:9-14
-    vertices -= vertices.min(0)[None, :]
-    vertices /= vertices.max()
-    vertices *= 2
-    vertices -= vertices.max(0)[None, :] / 2
-    return vertices
-
-
-def convert_type(obj):                                                       # lighting.py:17-20
-    if isinstance(obj, (tuple, list)):
-        return np.array(obj, dtype=np.float32)[None, :]
-    return obj
-
-
 RENDER_CFG = dict(intensity_ambient=0.75, color_ambient=(1, 1, 1), intensity_directional=0.7, color_directional=(1, 1, 1),
                   intensity_specular=0.2, specular_exp=5, light_pos=(0, 0, 5), view_pos=(0, 0, 5))      # utils/render.py:18-27
 
 
+def _row(v):
+    """lighting.py:17-20 (convert_type): tuples become float32 [1,3] rows, scalars stay python floats."""
+    return np.asarray(v, dtype=np.float32)[None, :] if isinstance(v, (tuple, list)) else v
+
+
+def _unit_rows(a):
+    """lighting.py:6 (_norm): rows divided by their Euclidean length, in float32."""
+    return a / np.sqrt(np.sum(a ** 2, axis=1))[:, None]
+
+
+def vertex_colours(vertices, normal, cfg):
+    """The vertex colours RenderPipeline.__call__ hands to the rasteriser (lighting.py:40-64), same float32 numpy
+    operations in the same order: ambient + clipped Lambert term + (clipped) Phong specular term, on vertices normalised
+    to a [-1, 1]-ish box by lighting.py:9-14."""
+    k_amb, c_amb = cfg['intensity_ambient'], _row(cfg['color_ambient'])
+    k_dir, c_dir = cfg['intensity_directional'], _row(cfg['color_directional'])
+    k_spec, shininess = cfg['intensity_specular'], cfg['specular_exp']
+    lamp, eye = _row(cfg['light_pos']), _row(cfg['view_pos'])
+    colour = np.zeros_like(vertices, dtype=np.float32)
+    if k_amb > 0:
+        colour += k_amb * c_amb
+    box = vertices.copy()                                   # norm_vertices
+    box -= box.min(0)[None, :]
+    box /= box.max()
+    box *= 2
+    box -= box.max(0)[None, :] / 2
+    if k_dir > 0:
+        to_lamp = _unit_rows(lamp - box)
+        lambert = np.sum(normal * to_lamp, axis=1)[:, None]
+        colour += k_dir * (c_dir * np.clip(lambert, 0, 1))
+        if k_spec > 0:
+            to_eye = _unit_rows(eye - box)
+            mirrored = 2 * lambert * normal - to_lamp
+            gloss = np.sum((to_eye * mirrored) ** shininess, axis=1)[:, None]
+            gloss = np.where(lambert != 0, np.clip(gloss, 0, 1), np.zeros_like(gloss))
+            colour += k_spec * c_dir * np.clip(gloss, 0, 1)
+    return np.clip(colour, 0, 1)
+
+
 class RenderPipeline:
-    """Sim3DR/lighting.py:23-71."""
+    """Sim3DR/lighting.py:23-71 (defaults of :25-32)."""
+    DEFAULTS = dict(intensity_ambient=0.3, intensity_directional=0.6, intensity_specular=0.1, specular_exp=5,
+                    color_ambient=(1, 1, 1), color_directional=(1, 1, 1), light_pos=(0, 0, 5), view_pos=(0, 0, 5))
 
     def __init__(self, impl='oracle', **kwargs):
         self.impl = impl
-        self.intensity_ambient = convert_type(kwargs.get('intensity_ambient', 0.3))
-        self.intensity_directional = convert_type(kwargs.get('intensity_directional', 0.6))
-        self.intensity_specular = convert_type(kwargs.get('intensity_specular', 0.1))
-        self.specular_exp = kwargs.get('specular_exp', 5)
-        self.color_ambient = convert_type(kwargs.get('color_ambient', (1, 1, 1)))
-        self.color_directional = convert_type(kwargs.get('color_directional', (1, 1, 1)))
-        self.light_pos = convert_type(kwargs.get('light_pos', (0, 0, 5)))
-        self.view_pos = convert_type(kwargs.get('view_pos', (0, 0, 5)))
+        self.cfg = {k: kwargs.get(k, d) for k, d in self.DEFAULTS.items()}
 
     def light(self, vertices, triangles):
-        normal = get_normal(vertices, triangles, impl=self.impl)
-        light = np.zeros_like(vertices, dtype=np.float32)
-        if self.intensity_ambient > 0:
-            light += self.intensity_ambient * self.color_ambient
-        vertices_n = norm_vertices(vertices.copy())
-        if self.intensity_directional > 0:
-            direction = _norm(self.light_pos - vertices_n)
-            cos = np.sum(normal * direction, axis=1)[:, None]
-            light += self.intensity_directional * (self.color_directional * np.clip(cos, 0, 1))
-            if self.intensity_specular > 0:
-                v2v = _norm(self.view_pos - vertices_n)
-                reflection = 2 * cos * normal - direction
-                spe = np.sum((v2v * reflection) ** self.specular_exp, axis=1)[:, None]
-                spe = np.where(cos != 0, np.clip(spe, 0, 1), np.zeros_like(spe))
-                light += self.intensity_specular * self.color_directional * np.clip(spe, 0, 1)
-        return np.clip(light, 0, 1)
+        return vertex_colours(vertices, get_normal(vertices, triangles, impl=self.impl), self.cfg)
 
     def __call__(self, vertices, triangles, bg, texture=None):
-        light = self.light(vertices, triangles)
-        if texture is None:
-            return rasterize(vertices, triangles, light, bg=bg, impl=self.impl)
-        texture *= light
-        return rasterize(vertices, triangles, texture, bg=bg, impl=self.impl)
+        colours = self.light(vertices, triangles)
+        if texture is not None:
+            texture *= colours
+            colours = texture
+        return rasterize(vertices, triangles, colours, bg=bg, impl=self.impl)
 
 
 def add_weighted(a, alpha, b, beta):
