@@ -95,7 +95,10 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
 // PROF: as in fused_block.hip -- wave 0 accumulates s_memtime deltas per stage into prof[0..7].
 #define SYNB_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
 
-template <class C, bool PROF = false>
+// NS > 1 (small batches only): blockIdx.y selects one of NS slices of the block's OUTPUT channel tiles.  Every slice repeats the
+// expand and depthwise stages (idle compute at small B) but streams only its share of the project weights, and each output
+// element is produced by exactly the same instruction sequence as with NS = 1 -- results do not depend on the batch size.
+template <class C, bool PROF = false, int NS = 1>
 __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_bf3_kernel(
     const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/, const float *__restrict__ e_shift,
     const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][3][64][4]*/,
@@ -114,6 +117,9 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     const int wn = wave % C::WN, wp = wave / C::WN;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int f0 = blockIdx.x * C::NF;
+    static_assert(C::NT_O % NS == 0, "output channel tiles split evenly");
+    constexpr int NTO_S = C::NT_O / NS, AN_S = cdivb(NTO_S, C::WN);            // channel tiles of this slice, per wave column
+    const int nt_base = NS > 1 ? (int)blockIdx.y * NTO_S : 0;
 
     // ---- prefetch: expand weights of chunk 0 and its depthwise filter (registers) ----
     u32x4 a1[C::JPW][C::KE][3];
@@ -141,9 +147,9 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     };
     auto fetch_a3 = [&](int hc0) {
 #pragma unroll
-        for (int i = 0; i < C::AN; ++i) {
+        for (int i = 0; i < AN_S; ++i) {
             int nt = wn + i * C::WN;
-            nt = nt < C::NT_O ? nt : 0;
+            nt = nt_base + (nt < NTO_S ? nt : 0);
             const unsigned *wa = Wp3 + ((size_t)nt * (C::HID / 32) + hc0 / 32) * 768 + lane * 4;
 #pragma unroll
             for (int kc = 0; kc < C::KP; ++kc)
@@ -178,13 +184,13 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         }
     f32x4 psh[C::AN];
 #pragma unroll
-    for (int i = 0; i < C::AN; ++i) {
-        const int n = (wn + i * C::WN) * 16 + 4 * g;
+    for (int i = 0; i < AN_S; ++i) {
+        const int n = (nt_base + wn + i * C::WN) * 16 + 4 * g;
         psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
     }
     f32x4 acc[C::AN][C::AP];
 #pragma unroll
-    for (int i = 0; i < C::AN; ++i)
+    for (int i = 0; i < AN_S; ++i)
 #pragma unroll
         for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];
     __syncthreads();
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             for (int kc = 0; kc < C::KP; ++kc) {
                 if (kc + 1 < C::KP) ldb(kc + 1, bq[(kc + 1) & 1]);
 #pragma unroll
-                for (int i = 0; i < C::AN; ++i)
+                for (int i = 0; i < AN_S; ++i)
 #pragma unroll
                     for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6(a3[i][kc], bq[kc & 1][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -316,10 +322,10 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
 
     // ---- epilogue: (+ residual rebuilt exactly from the three input planes) and NHWC store ----
 #pragma unroll
-    for (int i = 0; i < C::AN; ++i) {
+    for (int i = 0; i < AN_S; ++i) {
         const int nt = wn + i * C::WN;
-        const int n = nt * 16 + 4 * g;
-        if (nt >= C::NT_O || n >= C::COUT) continue;
+        const int n = (nt_base + nt) * 16 + 4 * g;
+        if (nt >= NTO_S || n >= C::COUT) continue;
 #pragma unroll
         for (int j = 0; j < C::AP; ++j) {
             const int pt = wp + j * C::WP;
@@ -349,6 +355,12 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     }
 }
 
+template <class C, int NS>
+static void launch_bf3_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
+    const dim3 grid((B + C::NF - 1) / C::NF, NS);
+    fused_block_bf3_kernel<C, false, NS><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+}
+
 template <class C>
 static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::NF - 1) / C::NF;
@@ -368,6 +380,8 @@ using B14 = Bf3Cfg<  96, 576, 160,  8, 2, false,  1, 64, 4, 4, 4, 1, 2>;    // f
 using B15 = Bf3Cfg< 160, 960, 160,  4, 1, true,   4, 64, 4, 4, 2, 2>;    // features.15,16
 using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // features.17
 
+constexpr int kSliceMaxGrid = 48;      // workgroups (of 4 faces) below which the late blocks are sliced over output channels
+
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.We3 || !a.Wp3) return false;
     switch (feature) {
@@ -377,8 +391,9 @@ bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStre
         case 11: launch_bf3<B11>(a, B, s); return true;
         case 12: case 13: launch_bf3<B12>(a, B, s); return true;
         case 14: launch_bf3<B14>(a, B, s); return true;
-        case 15: case 16: launch_bf3<B15>(a, B, s); return true;
-        case 17: launch_bf3<B17>(a, B, s); return true;
+        // few faces: one workgroup would stream 1.8-2.8 MB of weights through a single CU; slice the output channels over 5
+        case 15: case 16: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_bf3_sliced<B15, 5>(a, B, s); else launch_bf3<B15>(a, B, s); return true;
+        case 17: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_bf3_sliced<B17, 5>(a, B, s); else launch_bf3<B17>(a, B, s); return true;
         default: return false;
     }
 }

@@ -179,6 +179,43 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 }
 }  // namespace
 
+// The 62 head rows of NF faces whose pooled 1280-vectors are in `xv`: wave w computes outputs w + 4 * (rbase + r), r < NR;
+// the next row's weights are fetched while the current one is reduced.  One function for the fused and the sliced tail,
+// so a parameter is produced by the same instruction sequence at every batch size.
+template <int NR>
+__device__ __forceinline__ void fc_rows(const f32x4 (&xv)[NF][N / 256], const float *__restrict__ Wfc, const float *__restrict__ bfc,
+                                        float *__restrict__ param, int f0, int B, int rbase, int wave, int lane) {
+    f32x4 wq[2][N / 256];
+    auto ldw = [&](int o, f32x4(&w)[N / 256]) {
+        const float *wr = Wfc + (size_t)(o < kParam ? o : kParam - 1) * N;
+#pragma unroll
+        for (int i = 0; i < N / 256; ++i) w[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
+    };
+    ldw(wave + 4 * rbase, wq[0]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int o = wave + 4 * (rbase + r);
+        if (r + 1 < NR) ldw(o + 4, wq[(r + 1) & 1]);
+        if (o >= kParam) continue;
+        const f32x4(&wv)[N / 256] = wq[r & 1];
+        const float bo = bfc[o];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i)
+                a += wv[i][0] * xv[j][i][0] + wv[i][1] * xv[j][i][1] + wv[i][2] * xv[j][i][2] + wv[i][3] * xv[j][i][3];
+            const float tot = wave64_sum(a);
+            if (lane == 0 && f0 + j < B) param[(size_t)(f0 + j) * kParam + o] = tot + bo;
+        }
+    }
+}
+
+constexpr int kFcRounds = (kParam + 3) / 4;      // 16 rounds of 4 rows
+
+// NS > 1 (few faces): blockIdx.y owns NTL / NS of the 80 output-channel tiles, the pooled slice goes to `pool` in HBM and
+// head_fc_kernel finishes; NS == 1: the whole tail in this launch.
+template <int NS>
 __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
                                                           const unsigned *__restrict__ Wb3 /*[80][10][3][64][4] dwords*/,
                                                           const float *__restrict__ shift, const float *__restrict__ Wfc,
@@ -189,6 +226,9 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int f0 = blockIdx.x * NF;
+    constexpr int NTS = NTL / NS;
+    static_assert(NTL % NS == 0 && NTS % 4 == 0, "whole rounds of 4 waves per slice");
+    const int nt0 = NS > 1 ? (int)blockIdx.y * NTS : 0, nt_end = nt0 + NTS;
 
     u32x4 ring[5][3];                                   // weight pieces of 5 k-chunks in flight
     auto lda = [&](int nt, int kc, u32x4(&dst)[3]) {
@@ -197,7 +237,7 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
         for (int p = 0; p < 3; ++p) dst[p] = *(const u32x4 *)(w + p * 256);
     };
 #pragma unroll
-    for (int kc = 0; kc < 5; ++kc) lda(wave, kc, ring[kc]);
+    for (int kc = 0; kc < 5; ++kc) lda(nt0 + wave, kc, ring[kc]);
     // input tile -> three bf16 planes in LDS (the split happens exactly once per element)
     for (int it = tid; it < PX * (K / 4); it += 256) {
         const int c4 = it % (K / 4), p = it / (K / 4);
@@ -213,7 +253,7 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     }
     __syncthreads();
 
-    for (int nt = wave; nt < NTL; nt += 4) {
+    for (int nt = nt0 + wave; nt < nt_end; nt += 4) {
         const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g];
         f32x4 acc[NF];
 #pragma unroll
@@ -246,7 +286,7 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
             for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][0], acc[j]);
             // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
             if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
-            else if (nt + 4 < NTL) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
+            else if (nt + 4 < nt_end) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -258,6 +298,13 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
         }
     }
     __syncthreads();
+    if (NS > 1) {                                          // this slice of the pooled vectors -> HBM
+        for (int it = tid; it < NF * (NTS * 4); it += 256) {
+            const int j = it / (NTS * 4), c4 = nt0 * 4 + it % (NTS * 4);
+            if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
+        }
+        return;
+    }
     if (pool) {
         for (int it = tid; it < NF * (N / 4); it += 256) {
             const int j = it / (N / 4), c4 = it % (N / 4);
@@ -269,35 +316,35 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
-    // the 62 head rows, 4 waves x 16 rounds; the next row's weights are fetched while the current one is reduced
-    f32x4 wq[2][N / 256];
-    auto ldw = [&](int o, f32x4(&w)[N / 256]) {
-        const float *wr = Wfc + (size_t)(o < kParam ? o : kParam - 1) * N;
-#pragma unroll
-        for (int i = 0; i < N / 256; ++i) w[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
-    };
-    ldw(wave, wq[0]);
-#pragma unroll
-    for (int r = 0; r < (kParam + 3) / 4; ++r) {
-        const int o = wave + 4 * r;
-        if (r + 1 < (kParam + 3) / 4) ldw(o + 4, wq[(r + 1) & 1]);
-        if (o >= kParam) continue;
-        const f32x4(&wv)[N / 256] = wq[r & 1];
-        const float bo = bfc[o];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < N / 256; ++i)
-                a += wv[i][0] * xv[j][i][0] + wv[i][1] * xv[j][i][1] + wv[i][2] * xv[j][i][2] + wv[i][3] * xv[j][i][3];
-            const float tot = wave64_sum(a);
-            if (lane == 0 && f0 + j < B) param[(size_t)(f0 + j) * kParam + o] = tot + bo;
-        }
-    }
+    fc_rows<kFcRounds>(xv, Wfc, bfc, param, f0, B, 0, wave, lane);
 }
 
+// second half of the sliced tail: blockIdx.y owns 4 of the 16 rounds of head rows
+constexpr int kFcSlices = 4;
+__global__ __launch_bounds__(256) void head_fc_kernel(const float *__restrict__ pool, const float *__restrict__ Wfc,
+                                                      const float *__restrict__ bfc, float *__restrict__ param, int B) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = blockIdx.x * NF;
+    f32x4 xv[NF][N / 256];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int f = f0 + j < B ? f0 + j : B - 1;
+#pragma unroll
+        for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&pool[(size_t)f * N + (i * 64 + lane) * 4];
+    }
+    fc_rows<kFcRounds / kFcSlices>(xv, Wfc, bfc, param, f0, B, blockIdx.y * (kFcRounds / kFcSlices), wave, lane);
+}
+
+// `scratch` ([B,1280] floats) receives the pooled vectors of the sliced schedule when the caller did not ask for them
 void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
-                        float *param, float *pool, int B, hipStream_t s) {
-    head_bf16x3_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
+                        float *param, float *pool, float *scratch, int B, hipStream_t s) {
+    const int grid = (B + NF - 1) / NF;
+    if (grid <= 96) {                                      // few faces: spread the 2.4 MB of weights over 5 workgroups per face pair
+        float *pl = pool ? pool : scratch;
+        head_bf16x3_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
+        head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);
+        return;
+    }
+    head_bf16x3_kernel<1><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
 }
 }  // namespace syn

@@ -67,7 +67,7 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
 
 // same tail with the GEMM on the bf16 matrix pipe via an exact 3-way bf16 split of fp32 operands (head_kernel.hip)
 void launch_head_bf16x3(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
-                        const float *bfc, float *param, float *pool, int B, hipStream_t s);
+                        const float *bfc, float *param, float *pool, float *scratch /*[B,1280]*/, int B, hipStream_t s);
 
 // ---- on-device crop + Lanczos-4 resize (preproc_kernels.hip) ----
 void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, const int *xofs, const short *xcoef,

@@ -410,7 +410,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
         } else if (L.feature == 18 && h->fusion >= 2 && stop_feature != 18) {
             syn::launch_head_bf16x3(X, reinterpret_cast<const unsigned *>(P + n.dst_head_b3), sh, P + n.dst_fc_w, P + n.dst_fc_b,
-                                    param, pool, B, s);
+                                    param, pool, H1, B, s);
             mark(19);
             HIP_TRY(hipGetLastError());
             return SYN_OK;

@@ -182,6 +182,19 @@ def test_full_size_properties_b1024(model, golden):
     assert torch.isfinite(mesh).all()
 
 
+@pytest.mark.parametrize('B', [1, 2, 5, 96, 97, 190, 192, 193, 194, 200])
+def test_small_batch_schedules_are_bitwise_batch_independent(model, B):
+    """Below ~200 faces the late blocks and the tail run in the output-channel-sliced schedule (fused_block_bf3.hip
+    kSliceMaxGrid, head_kernel.hip launch_head_bf16x3); a face's parameters must not depend on which schedule ran."""
+    import torch
+    from synergynet_amd import synth
+    crops = torch.from_numpy(synth.make_crops(8, seed=78)).cuda()
+    ref = model.forward_crops_u8(crops.repeat(64, 1, 1, 1))[:8]          # B = 512: fused schedule
+    idx = torch.arange(B) % 8
+    got = model.forward_crops_u8(crops[idx.cuda()].contiguous())
+    assert torch.equal(got, ref[idx.cuda()])
+
+
 def test_error_behaviour_mirrors_reference(model):
     import torch
     with pytest.raises(RuntimeError, match='length of params mismatch'):     # synergy3DMM.py:126-129
