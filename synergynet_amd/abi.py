@@ -65,7 +65,8 @@ EXPORTED_SYMBOLS = tuple(_SIGS)          # exactly the symbols include/synergy_h
 # test hook exported by the library but deliberately not part of the public header
 _SIGS = dict(_SIGS, syn_debug_feature=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
              syn_debug_profile_block=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-             syn_debug_detect_raw=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5))
+             syn_debug_detect_raw=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5),
+             syn_debug_poison_workspace=(C.c_int, [C.c_void_p, C.c_int, C.c_int]))
 
 
 def lib():

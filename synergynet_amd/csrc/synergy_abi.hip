@@ -941,6 +941,21 @@ int syn_debug_feature(syn_handle *h, const float *img, int B, int feature, float
     return run_backbone(h, img, nullptr, B, nullptr, nullptr, (hipStream_t)stream, feature, out);
 }
 
+// Test hook, not part of include/synergy_hip.h: fill every scratch buffer of the handle with `byte` (0xFF = NaNs), so a test
+// can show that no result depends on what earlier calls (or the allocator) left in the workspace.
+int syn_debug_poison_workspace(syn_handle *h, int B, int byte) {
+    if (!h || B <= 0) return fail(SYN_ERR_INVALID, "syn_debug_poison_workspace: bad argument");
+    DeviceGuard g(h->device);
+    int rc = ensure_ws(h, B);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(h->ws, byte, h->ws_bytes));
+    if (h->rws) HIP_TRY(hipMemset(h->rws, byte, h->rws_bytes));
+    if (h->dws) HIP_TRY(hipMemset(h->dws, byte, h->dws_bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return SYN_OK;
+}
+
 int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int *box, const int *xofs, const int16_t *xcoef,
                     const int *yofs, const int16_t *ycoef, uint8_t *out, int B, void *stream) {
     if (!h || !frame || !box || !xofs || !xcoef || !yofs || !ycoef || !out) return fail(SYN_ERR_INVALID, "syn_crop_resize: NULL argument");

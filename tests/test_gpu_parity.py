@@ -195,6 +195,31 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model, B):
     assert torch.equal(got, ref[idx.cuda()])
 
 
+@pytest.mark.parametrize('B', [1, 5, 37, 300])
+def test_results_do_not_depend_on_workspace_contents(model, B):
+    """Scratch buffers are reused across calls and never cleared: fill them with NaN bytes (test hook) and with zeros, the
+    parameters, landmarks, mesh and pose of a ragged batch must come out bit-identical (padding lanes / over-read
+    records of partially filled tiles must never reach a result)."""
+    import torch
+    from synergynet_amd import abi, synth
+    crops = torch.from_numpy(synth.make_crops(B, seed=79)).cuda()
+    rois = torch.from_numpy(synth.make_rois(B, seed=80)).cuda()
+    outs = []
+    for byte in (0xFF, 0x00, 0x7F):
+        abi.check(abi.lib().syn_debug_poison_workspace(model._h, 512, byte))
+        p = model.forward_crops_u8(crops)
+        lmk = model.reconstruct(p, roi=rois, dense=False)
+        mesh = model.reconstruct(p, roi=rois, dense=True)
+        pose = model.predict_pose_batch(p, rois)
+        pose = [t for t in pose] if isinstance(pose, (tuple, list)) else [pose]
+        torch.cuda.synchronize()
+        outs.append([p, lmk, mesh] + [t for t in pose if torch.is_tensor(t)])
+    for o in outs:
+        assert all(torch.isfinite(t).all() for t in o)
+    for o in outs[1:]:
+        assert len(o) == len(outs[0]) and all(torch.equal(a, b) for a, b in zip(outs[0], o))
+
+
 def test_error_behaviour_mirrors_reference(model):
     import torch
     with pytest.raises(RuntimeError, match='length of params mismatch'):     # synergy3DMM.py:126-129

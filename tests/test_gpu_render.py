@@ -98,6 +98,11 @@ def test_full_size_batch_pipeline_vs_reference_golden_and_oracle(rmodel, rgold):
     d2 = np.abs(overlap.astype(int) - o_ov.astype(int))
     assert d2.max() <= 1 and (d2 > 0).mean() <= 1e-3
     assert np.array_equal(res, osim.add_weighted(img, 1 - 0.6, overlap, 0.6))         # the blend itself is exact
+    # scratch (normals accumulators, z-keys) left full of NaN bytes by a test hook: same image again
+    from synergynet_amd import abi
+    abi.check(abi.lib().syn_debug_poison_workspace(rmodel._h, 4, 0xFF))
+    ov3, res3 = sim3dr.render_batch(rmodel, img, torch.from_numpy(meshes).cuda(), alpha=0.6)
+    assert np.array_equal(ov3.cpu().numpy(), overlap) and np.array_equal(res3.cpu().numpy(), res)
     # the list-of-(3,N)-arrays entry of utils/render.py gives the same image
     res2 = sim3dr.render(img, [meshes[f] for f in range(meshes.shape[0])], alpha=0.6)
     assert np.array_equal(res2, res)
