@@ -11,6 +11,7 @@
 // rows = faces and columns = vertices so that a stored row segment is 32 consecutive vertices of
 // one face (128 B).  The output (638,580 B per face) is the compulsory HBM traffic; the basis is
 // read once per wave and kept in registers while the wave walks its share of the faces.
+#include <cstdio>
 #include <cstdlib>
 
 #include "syn_internal.h"
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
                 const int row = k * 8 + rsub;                 // = face_in_tile * 3 + coord
                 const int f = f0 + row / 3, c = row % 3;
                 const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
-                if (f < B) {
+                if (f < B && !(ablate & 1)) {
                     float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
                     if (vq + 3 < n_vert) *(f32x4 *)o = vv;       // 4-byte aligned 16-byte store (rows are n_vert floats)
                     else {
@@ -289,12 +290,24 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
 // WPG waves per workgroup = WPG consecutive vertex tiles = one WPG*128-byte run per (face, coord) row and iteration.  Rows of
 // the [B,3,53215] output are only 4-byte aligned, so every run shares its first and last cache line with a neighbouring
 // workgroup; longer runs mean fewer such split lines (tools/ubench/store_pattern.hip: 512 B runs 3.5 TB/s, 1 KiB ~4).
-template <int WPG>
+//
+// Vector memory operations retire IN ORDER on this ISA (one vmcnt for loads and stores): a load issued after the 12 stores of
+// a face tile cannot be consumed before those stores are acknowledged (~6k cycles).  So the kernel never waits on memory
+// right after its stores: the operands of the next face tile (alpha pieces + face records, 11 KB, the same for all WPG waves)
+// are fetched cooperatively after the MFMAs, parked in registers during the epilogue and written to the other half of a
+// double-buffered LDS tile before the stage barrier -- by then the previous tile's stores have had a whole MFMA + epilogue
+// phase to drain -- and nothing in the kernel spills (a scratch reload is a vector load too: one `s_waitcnt vmcnt(0)` per
+// store instruction cost 10k cycles per face tile before).
+#define RLAP(i) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+template <int WPG, bool PROF = false>
 __global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
-                     int n_vert, int n_tiles, int n_split, int ftiles_per_split, int n_ftiles, int n_units) {
+                     int n_vert, int n_tiles, int n_split, int ftiles_per_split, int n_ftiles, int n_units,
+                     unsigned long long *prof = nullptr) {
+    unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
-    __shared__ __attribute__((aligned(16))) float smt[WPG][32][16];
+    constexpr int NTH = WPG * 64, TQ = kRecTileB3 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
+    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order) | 32 x 16 fp32 records
     __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
@@ -321,32 +334,49 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     const int ft0 = split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
     ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
-    float(*mt)[16] = smt[wave];
     const int v_base = tg * (WPG * 32);
+    if (ft0 >= ft1) return;                          // (workgroup-uniform)
+
+    u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
+    auto fetch = [&](int ft) {                       // branch-free (index clamped): no control flow around in-flight loads
+        const unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            int q = i * NTH + (int)threadIdx.x;
+            q = q < TQ ? q : TQ - 1;
+            pf[i] = *(const u32x4 *)(rt + 4 * q);
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int q = i * NTH + (int)threadIdx.x;
+            if ((i + 1) * NTH <= TQ || q < TQ) *(u32x4 *)&optile[buf][4 * q] = pf[i];
+        }
+    };
+    fetch(ft0);
+    park(0);                                         // waits for everything issued so far: the loop starts with no load in flight
+    RLAP(0);
+    lds_barrier();
 
     for (int ft = ft0; ft < ft1; ++ft) {
-        const int f0 = ft * 32;
-        const unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
-        u32x4 aa[2][3];                                                      // alpha pieces, one k16 step ahead
-#pragma unroll
-        for (int p = 0; p < 3; ++p) aa[0][p] = *(const u32x4 *)(rt + (p * 64 + lane) * 4);
-        // the 32 face records of this tile -> the wave's private LDS slice (2 KiB: 64 lanes x 2 float4)
-        {
-            const float *rr = reinterpret_cast<const float *>(rt + 9 * 256);
-            *(f32x4 *)&mt[0][lane * 4] = *(const f32x4 *)(rr + lane * 4);
-            *(f32x4 *)&mt[0][256 + lane * 4] = *(const f32x4 *)(rr + 256 + lane * 4);
-        }
+        const int f0 = ft * 32, buf = (ft - ft0) & 1;
+        const unsigned *ot = optile[buf];
+        const float(*mt)[16] = reinterpret_cast<const float(*)[16]>(ot + 9 * 256);      // the 32 face records
         f32x16 acc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = bu[c];                  // mean shape = accumulator start
+        u32x4 aa[2][3];                                                      // alpha pieces, one k16 step ahead (LDS reads)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aa[0][p] = *(const u32x4 *)(ot + (p * 64 + lane) * 4);
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int cur = ks & 1;
             if (ks + 1 < 3)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) aa[cur ^ 1][p] = *(const u32x4 *)(rt + (((ks + 1) * 3 + p) * 64 + lane) * 4);
+                for (int p = 0; p < 3; ++p) aa[cur ^ 1][p] = *(const u32x4 *)(ot + (((ks + 1) * 3 + p) * 64 + lane) * 4);
             // six partial products, smallest first; the three coordinate planes interleave as independent chains
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -354,9 +384,10 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[c] = mfma32(aa[cur][PA[q]], bb[c][ks][PB[q]], acc[c]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        RLAP(1);
+        const bool more = ft + 1 < ft1;
+        if (more) fetch(ft + 1);
+        RLAP(2);
         // columns 48, 49 + pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -372,21 +403,27 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
             st[0] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
             st[SS] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
             st[2 * SS] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);    // keep the record reads of at most two rows in flight (registers)
+            __builtin_amdgcn_sched_barrier(0);               // keep the record reads of one row in flight (registers)
         }
+        RLAP(3);
+        if (more) park(buf ^ 1);                     // last read two barriers ago (previous tile's MFMAs / epilogue)
         lds_barrier();
-        {   // cooperative store: LPR lanes x float4 = one run of one (face, coord) row; WPG*64/LPR rows per instruction
+        RLAP(4);
+        {   // cooperative store: LPR lanes x float4 = one run of one (face, coord) row; WPG*64/LPR rows per instruction.
+            // Output row (f0 + r/3, r%3) is simply row 3*f0 + r of the [3B, n_vert] matrix: one pointer, one constant stride.
             constexpr int LPR = WPG * 8, RPI = WPG * 64 / LPR;
             const int seg = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
             const int vq = v_base + 4 * seg;
+            const int rows_live = 3 * (B - f0);                       // rows of this face tile that exist (ragged last tile)
+            float *o = out + ((size_t)3 * f0 + rsub) * n_vert + vq;
+            const size_t ostep = (size_t)RPI * n_vert;
+            const float *sp = &stage[rsub * SS + 4 * seg];
+            const bool whole = vq + 3 < n_vert;
 #pragma unroll
-            for (int k = 0; k < 96 / RPI; ++k) {
-                const int row = k * RPI + rsub;               // = face_in_tile * 3 + coord
-                const int f = f0 + row / 3, c = row % 3;
-                const f32x4 vv = *(const f32x4 *)&stage[row * SS + 4 * seg];
-                if (f < B) {
-                    float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
-                    if (vq + 3 < n_vert) *(f32x4 *)o = vv;
+            for (int k = 0; k < 96 / RPI; ++k, o += ostep) {
+                const f32x4 vv = *(const f32x4 *)(sp + k * RPI * SS);
+                if (k * RPI + rsub < rows_live) {
+                    if (whole) *(f32x4 *)o = vv;
                     else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) if (vq + t < n_vert) o[t] = vv[t];
@@ -394,7 +431,13 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
                 }
             }
         }
-        lds_barrier();     // stage and the record slices are rewritten by the next face tile
+        RLAP(5);
+        lds_barrier();     // the stage is rewritten by the next face tile
+        RLAP(6);
+    }
+    if (PROF && threadIdx.x == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], 1ull);
     }
 }
 
@@ -406,13 +449,28 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower: 347 vs 305 us
     const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
-    int n_split = (3072 + n_groups - 1) / n_groups;           // >= 3072 workgroups (see launch_reconstruct)
+    static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 3072;
+    int n_split = (wg_target + n_groups - 1) / n_groups;           // >= 3072 workgroups (see launch_reconstruct)
     n_split = n_split < 1 ? 1 : n_split;
     n_split = n_split > n_ftiles ? n_ftiles : n_split;
     const int per = (n_ftiles + n_split - 1) / n_split;
     n_split = (n_ftiles + per - 1) / per;
     const int n_units = n_groups * n_split;
     const int grid = ((n_units + 7) / 8) * 8;
+    static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
+    if (prof3 && n_vert > 1000) {
+        unsigned long long *d = nullptr, hst[8];
+        (void)hipMalloc((void **)&d, sizeof(hst));
+        (void)hipMemsetAsync(d, 0, sizeof(hst), s);
+        recon_b3_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units, d);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        const char *nm[7] = {"basis+first tile", "mfma", "fetch issue", "epilogue", "park+barrier1", "store", "barrier2"};
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "recon prof %-18s %10.0f ticks/wg\n", nm[i], (double)hst[i] / (double)hst[7]);
+        fprintf(stderr, "recon prof workgroups %llu (s_memtime ticks = 100 MHz)\n", hst[7]);
+        return;
+    }
     recon_b3_kernel<WPG><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units);
 }
 

@@ -1,0 +1,15 @@
+"""GPU box: per-stage ticks of recon_b3_kernel (SYN_RECON_PROF=1 makes launch_reconstruct_b3 run the instrumented variant
+and print averages per workgroup to stderr; s_memtime ticks are 10 ns)."""
+import os, sys
+os.environ['SYN_RECON_PROF'] = '1'
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from synergynet_amd import synth
+from synergynet_amd.synergy3DMM import SynergyNet
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(), backbone_state=synth.make_backbone_state())
+p = torch.from_numpy(synth.make_params(B, seed=5)).cuda(); roi = torch.from_numpy(synth.make_rois(B, seed=6)).cuda()
+out = torch.empty((B, 3, 53215), dtype=torch.float32, device='cuda')
+for _ in range(3):
+    m.reconstruct(p, roi, dense=True, out=out)
+    sys.stderr.write('--\n')

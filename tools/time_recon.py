@@ -10,11 +10,14 @@ for f in (1, 2):
     os.environ['SYNERGY_HIP_FUSION'] = str(f)
     m = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd)
     p = torch.from_numpy(synth.make_params(B, seed=5)).cuda(); roi = torch.from_numpy(synth.make_rois(B, seed=6)).cuda()
-    for _ in range(3): m.reconstruct(p, roi, dense=True)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20): out = m.reconstruct(p, roi, dense=True)
-    b.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 20
-    print(f'fusion={f} B={B} nv={NV} dense recon {ms*1e3:.1f} us  -> {B*3*NV*4/ms/1e9:.2f} TB/s of output')
+    out = torch.empty((B, 3, NV), dtype=torch.float32, device='cuda')
+    lmk = torch.empty((B, 3, 68), dtype=torch.float32, device='cuda')
+    for dense, buf, name in ((False, lmk, 'landmarks (host-call floor)'), (True, out, 'dense')):
+        for _ in range(3): m.reconstruct(p, roi, dense=dense, out=buf)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20): m.reconstruct(p, roi, dense=dense, out=buf)
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 20
+        print(f'fusion={f} B={B} nv={NV} {name} recon {ms*1e3:.1f} us  -> {B*3*(NV if dense else 68)*4/ms/1e9:.2f} TB/s of output')

@@ -51,6 +51,43 @@ __global__ __launch_bounds__(256) void k(float *out, int B, int n_vert, int n_gr
         __syncthreads();
     }
 }
+// Line-aligned variant: a workgroup owns 96 vertices per row, shifted per row so that every run is three whole 128-byte
+// lines of the flat [3B * n_vert] array (row r starts at flat offset r * n_vert; aligned columns are v = -r*n_vert mod 32 + 32m).
+__global__ __launch_bounds__(256) void k_aligned(float *out, int B, int n_vert, int n_groups, int n_split, int per, int n_ftiles, int n_units) {
+    const int per_xcd = (n_units + 7) / 8;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
+    const int tg = unit / n_split, split = unit - tg * n_split;
+    const int ft0 = split * per, ft1 = min(ft0 + per, n_ftiles);
+    const int seg = threadIdx.x % 32, rsub = threadIdx.x / 32;
+    const f32x4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (int ft = ft0; ft < ft1; ++ft) {
+        for (int kk = 0; kk < 12; ++kk) {
+            const int row = kk * 8 + rsub;
+            const long r = (long)ft * 96 + row;
+            if (r >= 3L * B || seg >= 24) continue;
+            const size_t rowoff = (size_t)r * n_vert;
+            const int s = (int)((32 - (rowoff & 31)) & 31);
+            const int vq = tg * 96 + s + 4 * seg;
+            if (vq + 3 < n_vert) *(f32x4 *)(out + rowoff + vq) = v;
+        }
+        __syncthreads();
+    }
+}
+void run_aligned(float *d, int B, int nv, int target_wgs) {
+    const int n_groups = (nv + 95) / 96, n_ftiles = (B + 31) / 32;
+    int n_split = (target_wgs + n_groups - 1) / n_groups; n_split = n_split < 1 ? 1 : (n_split > n_ftiles ? n_ftiles : n_split);
+    const int per = (n_ftiles + n_split - 1) / n_split; n_split = (n_ftiles + per - 1) / per;
+    const int n_units = n_groups * n_split, grid = ((n_units + 7) / 8) * 8;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    k_aligned<<<grid, 256>>>(d, B, nv, n_groups, n_split, per, n_ftiles, n_units); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < 10; ++i) k_aligned<<<grid, 256>>>(d, B, nv, n_groups, n_split, per, n_ftiles, n_units);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
+    printf("line-aligned 384 B runs  wgs=%5d (split %2d, %d ftiles each) : %.1f us  %.2f TB/s\n", n_units, n_split, per, ms * 1e3,
+           (double)B * 3 * nv * 4 / ms / 1e9);
+}
 template <int RUNF> void run(float *d, int B, int nv, int target_wgs, int xcd) {
     const int n_groups = (nv + RUNF - 1) / RUNF, n_ftiles = (B + 31) / 32;
     int n_split = (target_wgs + n_groups - 1) / n_groups; n_split = n_split < 1 ? 1 : (n_split > n_ftiles ? n_ftiles : n_split);
@@ -72,6 +109,7 @@ int main(int argc, char **argv) {
     for (int xcd = 0; xcd < 4; ++xcd) {
         run<128>(d, B, nv, 3072, xcd); run<256>(d, B, nv, 3072, xcd); run<512>(d, B, nv, 3072, xcd); run<1024>(d, B, nv, 3072, xcd);
     }
+    run_aligned(d, B, nv, 3072); run_aligned(d, B, nv, 4400); run_aligned(d, B, nv, 1600);
     run<128>(d, B, nv, 512, 2); run<128>(d, B, nv, 1600, 2); run<128>(d, B, nv, 100000, 2); run<256>(d, B, nv, 100000, 2);
     return 0;
 }
