@@ -114,7 +114,7 @@ def main():
     crops = torch.from_numpy(synth.make_crops(B, seed=1000 + rank)).to(dev)      # this rank's shard
     rois = torch.from_numpy(synth.make_rois(B, seed=2000 + rank)).to(dev)
     lmk = torch.empty((B, 3, 68), dtype=torch.float32, device=dev)
-    mesh = torch.empty((B, 3, 53215), dtype=torch.float32, device=dev)
+    mesh = model.empty_vertices(B, dense=True)       # [B,3,53215] view, rows pitched to 128-byte lines (syn_reconstruct_pitched)
 
     def step():
         param = model.forward_crops_u8(crops)

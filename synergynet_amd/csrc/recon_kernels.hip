@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void recon_prep_kernel(const float *__restrict_
 // resident while alpha fragments stream in from the 256-byte per-face records.
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ rec, const float *__restrict__ basis,
-                                                    float *__restrict__ out, int B, int n_vert, int n_tiles,
+                                                    float *__restrict__ out, int B, int n_vert, int pitch, int n_tiles,
                                                     int n_split, int ftiles_per_split, int n_ftiles, int n_units,
                                                     int ablate) {
     __shared__ __attribute__((aligned(16))) float smt[4][32][12];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
                 const int f = f0 + row / 3, c = row % 3;
                 const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
                 if (f < B && !(ablate & 1)) {
-                    float *o = out + ((size_t)f * 3 + c) * n_vert + vq;
+                    float *o = out + ((size_t)f * 3 + c) * pitch + vq;
                     if (vq + 3 < n_vert) *(f32x4 *)o = vv;       // 4-byte aligned 16-byte store (rows are n_vert floats)
                     else {
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
 
 // rec: [B,64] scratch for the per-face records (part of the library workspace)
 void launch_reconstruct(const float *param, const float *mean62, const float *std62, const float *basis, int n_vert,
-                        int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec) {
+                        int nvp, const float *roi, int transform, float *out, int pitch, int B, hipStream_t s, float *rec) {
     recon_prep_kernel<<<B, 64, 0, s>>>(param, mean62, std62, roi, transform, rec, B);
     const int n_tiles = nvp / 32;
     const int n_groups = (n_tiles + 3) / 4;                   // a workgroup = 4 consecutive vertex tiles
@@ -203,7 +203,7 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
     const int n_units = n_groups * n_split;
     const int grid = ((n_units + 7) / 8) * 8;
     static const int ablate = getenv("SYN_ABLATE_RECON") ? atoi(getenv("SYN_ABLATE_RECON")) : 0;   // profiling only
-    recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units, ablate);
+    recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, pitch, n_tiles, n_split, per, n_ftiles, n_units, ablate);
 }
 
 // =====================================================================================
@@ -235,7 +235,7 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 
 // Prologue: one workgroup (64 lanes) per 32-face tile.  Lane (i = l&31, hh = l>>5) is face f0+i: it de-whitens the 24
 // shape/expression coefficients k = 16*step + 8*hh + e it feeds to the MFMA, splits them and writes them in operand
-// order; lanes hh = 0 also write the face's 16-float record M[9] | T[3] | alpha48 | alpha49 | 0 | 0.
+// order (plus the fourth-step fragment, see below); lanes hh = 0 also write the face's 16-float record M[9] | T[3] | 0 x 4.
 __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restrict__ param, const float *__restrict__ mean,
                                                            const float *__restrict__ stdv, const float *__restrict__ roi,
                                                            int transform, unsigned *__restrict__ rec3, int B) {
@@ -258,6 +258,22 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
 #pragma unroll
         for (int p = 0; p < 3; ++p) *(u32x4 *)&rt[((ks * 3 + p) * 64 + l) * 4] = pc[p];
     }
+    // fourth k16 step: the two expression columns 48, 49 and the mean shape ride on ONE more MFMA -- its 16 k slots carry the
+    // six split partial products of column 48 (k0-5), of column 49 (k6-11) and the three pieces of the mean times 1.0 (k12-14):
+    //   basis side   [b48h b48h b48m b48m b48h b48l | b49h b49h b49m b49m b49h b49l | uh um ul 0]
+    //   alpha side   [a48h a48m a48h a48m a48l a48h | a49h a49m a49h a49m a49l a49h |  1  1  1 0]
+    {
+        const float a48 = ok ? pp[12 + 48] * stdv[12 + 48] + mean[12 + 48] : 0.f;
+        const float a49 = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
+        unsigned h, m, lo;
+        split2r(a48, a49, h, m, lo);                      // low half = piece of a48, high half = piece of a49
+        const unsigned h8 = h & 0xffffu, m8 = m & 0xffffu, l8 = lo & 0xffffu, h9 = h >> 16, m9 = m >> 16, l9 = lo >> 16;
+        const unsigned one = ok ? 0x3f80u : 0u;
+        u32x4 fx;
+        if (hh == 0) fx = (u32x4){h8 | (m8 << 16), h8 | (m8 << 16), l8 | (h8 << 16), h9 | (m9 << 16)};
+        else         fx = (u32x4){h9 | (m9 << 16), l9 | (h9 << 16), one | (one << 16), one};
+        *(u32x4 *)&rt[(9 * 64 + l) * 4] = fx;
+    }
     if (hh == 0) {
         float r[16];
         float p12[12];
@@ -278,10 +294,8 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
             r[3 * c + 0] = m0 * sc; r[3 * c + 1] = m1 * sc; r[3 * c + 2] = m2 * sc;
             r[9 + c] = t * sc + of;
         }
-        r[12] = ok ? pp[12 + 48] * stdv[12 + 48] + mean[12 + 48] : 0.f;
-        r[13] = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
-        r[14] = 0.f; r[15] = 0.f;
-        float *rr = reinterpret_cast<float *>(rt + 9 * 256) + i * 16;
+        r[12] = 0.f; r[13] = 0.f; r[14] = 0.f; r[15] = 0.f;
+        float *rr = reinterpret_cast<float *>(rt + 10 * 256) + i * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4 *)&rr[4 * q] = (f32x4){r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
     }
@@ -299,28 +313,31 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
 // phase to drain -- and nothing in the kernel spills (a scratch reload is a vector load too: one `s_waitcnt vmcnt(0)` per
 // store instruction cost 10k cycles per face tile before).
 #define RLAP(i) do { if (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
-template <int WPG, bool PROF = false>
+// FAST: every face tile in [ft_lo, ft_hi) is whole (32 faces) and the padded tile columns fit in the pitch -> the stores are 12
+// unconditional instructions in straight-line code, the only shape for which the compiler's wait-count bookkeeping stays exact
+// (see the store phase).  The launcher runs the ragged last face tile / packed outputs through the guarded instantiation.
+template <int WPG, bool FAST, bool PROF = false>
 __global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
-                     int n_vert, int n_tiles, int n_split, int ftiles_per_split, int n_ftiles, int n_units,
+                     int n_vert, int pitch, int n_tiles, int n_split, int ftiles_per_split, int ft_lo, int ft_hi, int n_units,
                      unsigned long long *prof = nullptr) {
     unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
     constexpr int NTH = WPG * 64, TQ = kRecTileB3 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
-    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order) | 32 x 16 fp32 records
+    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order, 10 fragments) | 32 x 16 fp32 records
     __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
     const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
     const int tg = unit / n_split, split = unit - tg * n_split;
+    constexpr int RUN = WPG * 32;                                             // vertices per row and workgroup
     int T = tg * WPG + wave;
     T = T < n_tiles ? T : n_tiles - 1;
     const int j = lane & 31, h = lane >> 5;
 
-    // resident basis fragments of this vertex tile: 3 coords x 3 k16 steps x 3 pieces, plus columns 48, 49 and the mean
-    u32x4 bb[3][3][3];
-    float b48[3], b49[3], bu[3];
+    // resident basis fragments of this vertex tile: 3 coords x (3 k16 steps x 3 pieces + the fourth-step fragment)
+    u32x4 bb[3][3][3], bx[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned *bc = basis3 + ((size_t)T * 3 + c) * kBasisB3;
@@ -328,13 +345,12 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bb[c][ks][p] = *(const u32x4 *)(bc + ((ks * 3 + p) * 64 + lane) * 4);
-        const float *bx = reinterpret_cast<const float *>(bc + 9 * 256);
-        b48[c] = bx[j]; b49[c] = bx[32 + j]; bu[c] = bx[64 + j];
+        bx[c] = *(const u32x4 *)(bc + (9 * 64 + lane) * 4);
     }
-    const int ft0 = split * ftiles_per_split;
+    const int ft0 = ft_lo + split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
-    ft1 = ft1 < n_ftiles ? ft1 : n_ftiles;
-    const int v_base = tg * (WPG * 32);
+    ft1 = ft1 < ft_hi ? ft1 : ft_hi;
+    const int v_base = tg * RUN;
     if (ft0 >= ft1) return;                          // (workgroup-uniform)
 
     u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
@@ -356,80 +372,101 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     };
     fetch(ft0);
     park(0);                                         // waits for everything issued so far: the loop starts with no load in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), visible to the compiler: no wait on the basis loads is left inside the loop
     RLAP(0);
     lds_barrier();
 
     for (int ft = ft0; ft < ft1; ++ft) {
         const int f0 = ft * 32, buf = (ft - ft0) & 1;
         const unsigned *ot = optile[buf];
-        const float(*mt)[16] = reinterpret_cast<const float(*)[16]>(ot + 9 * 256);      // the 32 face records
+        // MFMA orientation: A = basis (rows = the tile's 32 vertices), B = alpha (columns = the 32 faces), so lane (j, h) ends
+        // up with face f0 + j and vertices i = (r&3) + 8(r>>2) + 4h: the per-face pose record is a per-LANE constant
+        // (12 registers, no LDS reads in the epilogue) and four consecutive registers are four consecutive vertices (one
+        // ds_write_b128 per coordinate into the stage).
         f32x16 acc[3];
+        {
+            const u32x4 ax = *(const u32x4 *)(ot + (9 * 64 + lane) * 4);
+            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = bu[c];                  // mean shape = accumulator start
-        u32x4 aa[2][3];                                                      // alpha pieces, one k16 step ahead (LDS reads)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) aa[0][p] = *(const u32x4 *)(ot + (p * 64 + lane) * 4);
+            for (int c = 0; c < 3; ++c) acc[c] = mfma32(bx[c], ax, z16);     // mean + columns 48, 49
+        }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < 3)
+            u32x4 aa[3];                                                     // alpha pieces of this k16 step (LDS; the SIMD's other wave covers the latency)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) aa[cur ^ 1][p] = *(const u32x4 *)(ot + (((ks + 1) * 3 + p) * 64 + lane) * 4);
+            for (int p = 0; p < 3; ++p) aa[p] = *(const u32x4 *)(ot + ((ks * 3 + p) * 64 + lane) * 4);
             // six partial products, smallest first; the three coordinate planes interleave as independent chains
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = mfma32(aa[cur][PA[q]], bb[c][ks][PB[q]], acc[c]);
+                for (int c = 0; c < 3; ++c) acc[c] = mfma32(bb[c][ks][PB[q]], aa[PA[q]], acc[c]);
         }
         RLAP(1);
-        const bool more = ft + 1 < ft1;
-        if (more) fetch(ft + 1);
+        fetch(ft + 1 < ft1 ? ft + 1 : ft);           // unconditional (the last tile is fetched twice): no control flow for the
+                                                     // compiler's wait-count bookkeeping to be conservative about
         RLAP(2);
-        // columns 48, 49 + pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
+        {   // pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
+            const float *rec = reinterpret_cast<const float *>(ot + 10 * 256) + j * 16;
+            const f32x4 q0 = *(const f32x4 *)&rec[0], q1 = *(const f32x4 *)&rec[4], q2 = *(const f32x4 *)&rec[8];
+            float *st = stage + (j * 3) * SS + wave * 32 + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const f32x4 q0 = *(const f32x4 *)&mt[i][0];
-            const f32x4 q1 = *(const f32x4 *)&mt[i][4];
-            const f32x4 q2 = *(const f32x4 *)&mt[i][8];
-            const f32x4 q3 = *(const f32x4 *)&mt[i][12];
-            const float sx = acc[0][r] + q3[0] * b48[0] + q3[1] * b49[0];
-            const float sy = acc[1][r] + q3[0] * b48[1] + q3[1] * b49[1];
-            const float sz = acc[2][r] + q3[0] * b48[2] + q3[1] * b49[2];
-            float *st = stage + (i * 3) * SS + wave * 32 + j;
-            st[0] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
-            st[SS] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
-            st[2 * SS] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
-            __builtin_amdgcn_sched_barrier(0);               // keep the record reads of one row in flight (registers)
+            for (int t = 0; t < 4; ++t) {
+                f32x4 ox, oy, oz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sx = acc[0][4 * t + e], sy = acc[1][4 * t + e], sz = acc[2][4 * t + e];
+                    ox[e] = q0[0] * sx + q0[1] * sy + q0[2] * sz + q2[1];
+                    oy[e] = q0[3] * sx + q1[0] * sy + q1[1] * sz + q2[2];
+                    oz[e] = q1[2] * sx + q1[3] * sy + q2[0] * sz + q2[3];
+                }
+                *(f32x4 *)&st[8 * t] = ox;
+                *(f32x4 *)&st[SS + 8 * t] = oy;
+                *(f32x4 *)&st[2 * SS + 8 * t] = oz;
+            }
         }
         RLAP(3);
-        if (more) park(buf ^ 1);                     // last read two barriers ago (previous tile's MFMAs / epilogue)
         lds_barrier();
         RLAP(4);
-        {   // cooperative store: LPR lanes x float4 = one run of one (face, coord) row; WPG*64/LPR rows per instruction.
-            // Output row (f0 + r/3, r%3) is simply row 3*f0 + r of the [3B, n_vert] matrix: one pointer, one constant stride.
-            constexpr int LPR = WPG * 8, RPI = WPG * 64 / LPR;
-            const int seg = threadIdx.x % LPR, rsub = threadIdx.x / LPR;
+        {   // cooperative store: LPR lanes x float4 = one RUN*4-byte run of one (face, coord) row; WPG*64/LPR rows per
+            // instruction.  Output row (f0 + r/3, r%3) is row 3*f0 + r of a [3B, pitch] matrix: one pointer, one constant
+            // stride.  With pitch = n_vert (dense [B,3,53215]) rows are only 4-byte aligned and every run shares its first and
+            // last 128-byte line with the neighbouring workgroups (3.3 TB/s of HBM writes in tools/ubench/store_pattern.hip);
+            // with a pitch that is a multiple of 32 floats every run is four whole lines (5.2 TB/s) -- the host API
+            // allocates dense outputs with such a pitch unless the caller brings a packed buffer.
+            // Nothing of this addressing may stay live across the tile loop (the compiler once hoisted 12 offsets, spilled
+            // them, and every scratch reload's s_waitcnt vmcnt(0) waited for all stores in flight): hence the opaque thread id.
+            constexpr int LPR = RUN / 4, RPI = WPG * 64 / LPR;
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));
+            const int seg = tid_ % LPR, rsub = tid_ / LPR;
             const int vq = v_base + 4 * seg;
             const int rows_live = 3 * (B - f0);                       // rows of this face tile that exist (ragged last tile)
-            float *o = out + ((size_t)3 * f0 + rsub) * n_vert + vq;
-            const size_t ostep = (size_t)RPI * n_vert;
+            float *o = out + ((size_t)3 * f0 + rsub) * pitch + vq;
+            const size_t ostep = (size_t)RPI * pitch;
             const float *sp = &stage[rsub * SS + 4 * seg];
-            const bool whole = vq + 3 < n_vert;
+            if (FAST) {
+                // 12 unconditional stores: the compiler knows exactly how many stores follow the fetch, so park's wait for
+                // the fetched operands is s_waitcnt vmcnt(12) -- these stores stay in flight across the barrier and into the
+                // next tile's MFMAs (with any branch around a store the wait degrades to vmcnt(0))
 #pragma unroll
-            for (int k = 0; k < 96 / RPI; ++k, o += ostep) {
-                const f32x4 vv = *(const f32x4 *)(sp + k * RPI * SS);
-                if (k * RPI + rsub < rows_live) {
-                    if (whole) *(f32x4 *)o = vv;
-                    else {
+                for (int k = 0; k < 96 / RPI; ++k, o += ostep) *(f32x4 *)o = *(const f32x4 *)(sp + k * RPI * SS);
+            } else {
+                const bool whole = vq + 3 < n_vert;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) if (vq + t < n_vert) o[t] = vv[t];
+                for (int k = 0; k < 96 / RPI; ++k, o += ostep) {
+                    const f32x4 vv = *(const f32x4 *)(sp + k * RPI * SS);
+                    if (k * RPI + rsub < rows_live) {
+                        if (whole) *(f32x4 *)o = vv;
+                        else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) if (vq + t < n_vert) o[t] = vv[t];
+                        }
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);       // park() must stay BELOW the stores (its wait counts them)
+            park(buf ^ 1);
         }
         RLAP(5);
         lds_barrier();     // the stage is rewritten by the next face tile
@@ -442,36 +479,48 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
 }
 
 void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
-                           int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec3f) {
+                           int nvp, const float *roi, int transform, float *out, int pitch, int B, hipStream_t s, float *rec3f) {
     unsigned *rec3 = reinterpret_cast<unsigned *>(rec3f);
     const int n_ftiles = (B + 31) / 32;
     recon_prep_b3_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
     const int n_tiles = nvp / 32;
-    constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower: 347 vs 305 us
+    constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
     static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 3072;
-    int n_split = (wg_target + n_groups - 1) / n_groups;           // >= 3072 workgroups (see launch_reconstruct)
-    n_split = n_split < 1 ? 1 : n_split;
-    n_split = n_split > n_ftiles ? n_ftiles : n_split;
-    const int per = (n_ftiles + n_split - 1) / n_split;
-    n_split = (n_ftiles + per - 1) / per;
-    const int n_units = n_groups * n_split;
-    const int grid = ((n_units + 7) / 8) * 8;
     static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
-    if (prof3 && n_vert > 1000) {
-        unsigned long long *d = nullptr, hst[8];
-        (void)hipMalloc((void **)&d, sizeof(hst));
-        (void)hipMemsetAsync(d, 0, sizeof(hst), s);
-        recon_b3_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units, d);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
-        (void)hipFree(d);
-        const char *nm[7] = {"basis+first tile", "mfma", "fetch issue", "epilogue", "park+barrier1", "store", "barrier2"};
-        for (int i = 0; i < 7; ++i) fprintf(stderr, "recon prof %-18s %10.0f ticks/wg\n", nm[i], (double)hst[i] / (double)hst[7]);
-        fprintf(stderr, "recon prof workgroups %llu (s_memtime ticks = 100 MHz)\n", hst[7]);
-        return;
-    }
-    recon_b3_kernel<WPG><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, n_tiles, n_split, per, n_ftiles, n_units);
+    // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
+    auto run = [&](int lo, int hi, bool fast) {
+        const int nft = hi - lo;
+        if (nft <= 0) return;
+        int n_split = (wg_target + n_groups - 1) / n_groups;
+        n_split = n_split < 1 ? 1 : n_split;
+        n_split = n_split > nft ? nft : n_split;
+        const int per = (nft + n_split - 1) / n_split;
+        n_split = (nft + per - 1) / per;
+        const int n_units = n_groups * n_split;
+        const int grid = ((n_units + 7) / 8) * 8;
+        if (prof3 && fast && n_vert > 1000) {
+            unsigned long long *d = nullptr, hst[8];
+            (void)hipMalloc((void **)&d, sizeof(hst));
+            (void)hipMemsetAsync(d, 0, sizeof(hst), s);
+            recon_b3_kernel<WPG, true, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units, d);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            const char *nm[7] = {"basis+first tile", "mfma", "fetch issue", "epilogue", "barrier1", "store+park", "barrier2"};
+            for (int i = 0; i < 7; ++i) fprintf(stderr, "recon prof %-18s %10.0f ticks/wg\n", nm[i], (double)hst[i] / (double)hst[7]);
+            fprintf(stderr, "recon prof workgroups %llu\n", hst[7]);
+        } else if (fast)
+            recon_b3_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+        else
+            recon_b3_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+    };
+    if (pitch >= n_groups * WPG * 32) {   // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
+                                          // store path (columns [n_vert, pitch) receive padding values), the ragged last one guarded
+        run(0, B / 32, true);
+        run(B / 32, n_ftiles, false);
+    } else
+        run(0, n_ftiles, false);
 }
 
 // -------------------------------------------------------------------------------------

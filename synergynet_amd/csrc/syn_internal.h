@@ -94,19 +94,20 @@ void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bi
 // rec: [B,64] float scratch for the per-face records (alpha[52] | M[9] | T[3]).
 void launch_reconstruct(const float *param, const float *mean62, const float *std62,
                         const float *basis, int n_vert, int nvp, const float *roi,
-                        int transform, float *out, int B, hipStream_t s, float *rec);
+                        int transform, float *out, int pitch /*floats between rows of out, >= n_vert*/, int B, hipStream_t s, float *rec);
 
 // Same contraction on the bf16 matrix pipe (exact 3-way split of both operands, v_mfma_f32_32x32x16_bf16).
 //   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 3][lane 64][4 dwords] for k = 0..47
-//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), then fp32 [3][32]: column 48, column 49, mean u.
-//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces in the same lane order (rows = faces), then 32 x 16 fp32
-//           records M[9] | T[3] | alpha48 | alpha49 | 0 | 0.
-constexpr int kBasisB3 = 3 * 3 * 256 + 96;
-constexpr int kRecTileB3 = 3 * 3 * 256 + 32 * 16;
+//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), then one more [lane 64][4] fragment: a fourth k16
+//           step whose slots carry the split partial products of columns 48, 49 and the mean (recon_prep_b3_kernel).
+//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces in the same lane order (faces), the matching fourth-step
+//           fragment, then 32 x 16 fp32 records M[9] | T[3] | 0 x 4.
+constexpr int kBasisB3 = (3 * 3 + 1) * 256;
+constexpr int kRecTileB3 = (3 * 3 + 1) * 256 + 32 * 16;
 constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)
 constexpr int kRecSlack = 4096;
 void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
-                           int nvp, const float *roi, int transform, float *out, int B, hipStream_t s, float *rec3);
+                           int nvp, const float *roi, int transform, float *out, int pitch, int B, hipStream_t s, float *rec3);
 
 // ---- mesh consumers (render_kernels.hip): Sim3DR.get_normal / RenderPipeline / Sim3DR.rasterize / cv2.addWeighted ----
 // vertices: F meshes, planar = 1 -> [F,3,nver] (the layout syn_reconstruct writes), 0 -> [F,nver,3] (the reference's)

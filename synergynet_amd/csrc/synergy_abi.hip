@@ -332,11 +332,18 @@ void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const flo
                         split(wfull(32 * t + (lane & 31), c, k0 + 1), hi);
                         for (int pc = 0; pc < 3; ++pc) d[((ks * 3 + pc) * 64 + lane) * 4 + dd] = lo[pc] | (hi[pc] << 16);
                     }
-            float *x = reinterpret_cast<float *>(d + 9 * 256);
-            for (int j = 0; j < 32; ++j) {
-                x[j] = wfull(32 * t + j, c, 48);
-                x[32 + j] = wfull(32 * t + j, c, 49);
-                x[64 + j] = wfull(32 * t + j, c, 50);
+            // fourth k16 step (recon_prep_b3_kernel writes the matching alpha side): columns 48, 49 and the mean as split products
+            for (int lane = 0; lane < 64; ++lane) {
+                unsigned b8[3], b9[3], uu[3];
+                split(wfull(32 * t + (lane & 31), c, 48), b8);
+                split(wfull(32 * t + (lane & 31), c, 49), b9);
+                split(wfull(32 * t + (lane & 31), c, 50), uu);
+                unsigned *x = d + (9 * 64 + lane) * 4;
+                if ((lane >> 5) == 0) {
+                    x[0] = b8[0] | (b8[0] << 16); x[1] = b8[1] | (b8[1] << 16); x[2] = b8[0] | (b8[2] << 16); x[3] = b9[0] | (b9[0] << 16);
+                } else {
+                    x[0] = b9[1] | (b9[1] << 16); x[1] = b9[0] | (b9[2] << 16); x[2] = uu[0] | (uu[1] << 16); x[3] = uu[2];
+                }
             }
         }
 }
@@ -966,24 +973,33 @@ int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int
     return SYN_OK;
 }
 
-int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
-                    float *out, void *stream) {
+int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
+                            float *out, int row_pitch, void *stream) {
     if (!h || !param || !out) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
     if (param_len != SYN_PARAM_DIM) return fail(SYN_ERR_PARAM_LEN, "length of params mismatch");
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_reconstruct: B=%d", B);
     if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_reconstruct: 3DMM basis not loaded");
+    const int n = dense ? h->n_vert : h->n_lmk;
+    if (row_pitch < n) return fail(SYN_ERR_INVALID, "syn_reconstruct: row_pitch=%d < %d columns", row_pitch, n);
     DeviceGuard g(h->device);
     int rc = ensure_ws(h, B);
     if (rc) return rc;
     float *rec = h->ws + (size_t)B * (ws_floats_per_face() - syn::kRecFloatsPerFace);
-    if (h->fusion >= 2) {
-        if (dense) syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), basis3_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
-        else       syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), basis3_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
-    }
-    else if (dense) syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_dense(h), h->n_vert, h->nvp, roi, transform, out, B, (hipStream_t)stream, rec);
-    else       syn::launch_reconstruct(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, out, B, (hipStream_t)stream, rec);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->fusion >= 2)
+        syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
+                                   roi, transform, out, row_pitch, B, s, rec);
+    else
+        syn::launch_reconstruct(param, basis_mean(h), basis_std(h), dense ? basis_dense(h) : basis_lmk(h), n, dense ? h->nvp : h->nlp,
+                                roi, transform, out, row_pitch, B, s, rec);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
+}
+
+int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
+                    float *out, void *stream) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
+    return syn_reconstruct_pitched(h, param, B, param_len, dense, transform, roi, out, dense ? h->n_vert : h->n_lmk, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -302,16 +302,30 @@ class SynergyNet(nn.Module):
                 raise RuntimeError('roi must be [B,5] (sx,sy,ex,ey,score)')
         with torch.cuda.device(self.device):
             if out is None:
-                out = torch.empty((B, 3, n), dtype=torch.float32, device=self.device)
+                out = self.empty_vertices(B, dense)
+            if tuple(out.shape) != (B, 3, n) or out.dtype != torch.float32 or out.device != self.device:
+                raise RuntimeError(f'out must be a float32 [B,3,{n}] tensor on {self.device}')
+            pitch = out.stride(1)
+            if out.stride(2) != 1 or pitch < n or (B > 1 and out.stride(0) != 3 * pitch):
+                raise RuntimeError('out must have unit column stride and equally pitched rows (a [B,3,pitch][..., :n] view)')
             try:
-                abi.check(self._lib.syn_reconstruct(self._h, p.data_ptr(), B, p.shape[1], int(dense), int(transform),
-                                                    r.data_ptr() if r is not None else None, out.data_ptr(),
-                                                    self._stream()))
+                abi.check(self._lib.syn_reconstruct_pitched(self._h, p.data_ptr(), B, p.shape[1], int(dense), int(transform),
+                                                            r.data_ptr() if r is not None else None, out.data_ptr(), int(pitch),
+                                                            self._stream()))
             except abi.SynergyHipError as e:
                 if e.code == abi.SYN_ERR_PARAM_LEN:
                     raise RuntimeError('length of params mismatch') from None
                 raise
         return out
+
+    def empty_vertices(self, B, dense=True):
+        """Output buffer for `reconstruct`: a [B,3,n] float32 view whose rows are 512-byte aligned (row pitch rounded up to 128
+        floats: 53215 -> 53248, +0.06 % memory; the pad columns receive unspecified values).  Same shape and values as the reference's packed tensor
+        (synergy3DMM.py:131-147), but every store of the kernel is a whole HBM line (include/synergy_hip.h,
+        syn_reconstruct_pitched); `.contiguous()` gives the packed copy where a consumer needs one."""
+        n = self._n_vert if dense else self._n_lmk
+        pitch = (n + 127) // 128 * 128 if n >= 1024 else n          # whole 128-vertex store runs (csrc/recon_kernels.hip)
+        return torch.empty((B, 3, pitch), dtype=torch.float32, device=self.device)[:, :, :n]
 
     def reconstruct_vertex_62(self, param, whitening=True, dense=False, transform=True, lmk_pts=68):
         """reference synergy3DMM.py:116-149.  [B,62] whitened -> [B,3,68] or [B,3,53215] in 120x120 crop

@@ -195,6 +195,32 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model, B):
     assert torch.equal(got, ref[idx.cuda()])
 
 
+@pytest.mark.parametrize('B', [1, 31, 32, 33, 64, 100])
+def test_pitched_and_packed_outputs_are_identical(model, B):
+    """reconstruct() writes into a row-pitched [B,3,n] view by default (whole-line stores, syn_reconstruct_pitched) and into
+    the reference's packed layout when the caller brings such a buffer; whole face tiles take the branch-free store path, the
+    ragged last tile and packed outputs the guarded one.  Same bits either way, and nothing outside the view is touched
+    except the pad columns of the pitched rows."""
+    import torch
+    from synergynet_amd import synth
+    p = torch.from_numpy(synth.make_params(B, seed=81)).cuda()
+    roi = torch.from_numpy(synth.make_rois(B, seed=82)).cuda()
+    n = model._n_vert
+    pitched = model.reconstruct(p, roi=roi, dense=True)
+    assert pitched.shape == (B, 3, n) and pitched.stride(1) % 128 == 0 and pitched.stride(1) >= n
+    guard = torch.full((B * 3 * n + 64,), 7.0, device='cuda')
+    packed = guard[32:32 + B * 3 * n].view(B, 3, n)
+    model.reconstruct(p, roi=roi, dense=True, out=packed)
+    assert torch.equal(packed, pitched)
+    assert torch.all(guard[:32] == 7.0) and torch.all(guard[-32:] == 7.0)
+    # odd pitch (not a multiple of 128 floats): guarded path, pad columns untouched
+    store = torch.full((B, 3, n + 5), 7.0, device='cuda')
+    model.reconstruct(p, roi=roi, dense=True, out=store[:, :, :n])
+    assert torch.equal(store[:, :, :n], pitched) and torch.all(store[:, :, n:] == 7.0)
+    with pytest.raises(RuntimeError, match='pitched rows'):
+        model.reconstruct(p, roi=roi, dense=True, out=torch.empty((B, n, 3), device='cuda').permute(0, 2, 1))
+
+
 @pytest.mark.parametrize('B', [1, 5, 37, 300])
 def test_results_do_not_depend_on_workspace_contents(model, B):
     """Scratch buffers are reused across calls and never cleared: fill them with NaN bytes (test hook) and with zeros, the

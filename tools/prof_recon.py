@@ -9,7 +9,7 @@ from synergynet_amd.synergy3DMM import SynergyNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(), backbone_state=synth.make_backbone_state())
 p = torch.from_numpy(synth.make_params(B, seed=5)).cuda(); roi = torch.from_numpy(synth.make_rois(B, seed=6)).cuda()
-out = torch.empty((B, 3, 53215), dtype=torch.float32, device='cuda')
+out = m.empty_vertices(B)
 for _ in range(3):
     m.reconstruct(p, roi, dense=True, out=out)
     sys.stderr.write('--\n')

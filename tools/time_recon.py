@@ -10,7 +10,7 @@ for f in (1, 2):
     os.environ['SYNERGY_HIP_FUSION'] = str(f)
     m = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd)
     p = torch.from_numpy(synth.make_params(B, seed=5)).cuda(); roi = torch.from_numpy(synth.make_rois(B, seed=6)).cuda()
-    out = torch.empty((B, 3, NV), dtype=torch.float32, device='cuda')
+    out = m.empty_vertices(B) if os.environ.get('PACKED') != '1' else torch.empty((B, 3, NV), dtype=torch.float32, device='cuda')
     lmk = torch.empty((B, 3, 68), dtype=torch.float32, device='cuda')
     for dense, buf, name in ((False, lmk, 'landmarks (host-call floor)'), (True, out, 'dense')):
         for _ in range(3): m.reconstruct(p, roi, dense=dense, out=buf)
