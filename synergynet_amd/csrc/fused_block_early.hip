@@ -227,6 +227,7 @@ void fused_block_early_kernel(
         for (int i = 0; i < C::AN; ++i)
 #pragma unroll
             for (int j = 0; j < C::AP; ++j) acc[i][j] = psh[i];        // BN shift = accumulator start
+        f32x4 resv[C::RES ? C::AN : 1][C::RES ? C::AP : 1];
 
 #pragma unroll
         for (int c = 0; c < C::NCH; ++c) {
@@ -340,6 +341,22 @@ void fused_block_early_kernel(
             SYNE_LAP(3);
             __syncthreads();
             SYNE_LAP(4);
+            // residual: fetched (L2-hot block input) while the last project stage runs, and before any store of this tile --
+            // vector memory retires in order, a load issued between two stores would wait for the first store's acknowledgement
+            if (C::RES && c == C::NCH - 1) {
+#pragma unroll
+                for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::AP; ++j) {
+                        // branch-free (indices clamped into the tile; the epilogue skips what is not real): with control flow
+                        // around a load the compiler's wait for it degrades to vmcnt(0), i.e. to waiting for the stores too
+                        int n = (wn + i * C::WN) * 16 + 4 * g, po = (wp + j * C::WP) * 16 + r16;
+                        n = n + 3 < C::COUT ? n : 0;
+                        po = po < C::POUT ? po : 0;
+                        const int fc = live ? f : 0;
+                        resv[i][j] = *(const f32x4 *)&X[((size_t)(fc * C::HOUT + oy0 + po / C::TW) * C::HOUT + ox0 + po % C::TW) * C::COUT + n];
+                    }
+            }
             // ---- stage 3: project 1x1 (bf16 x3), K = this hidden chunk (zero padded to k32 steps) ----
             if (live)
 #pragma unroll
@@ -362,7 +379,16 @@ void fused_block_early_kernel(
             // are rewritten only after the next barrier, which every wave reaches after this stage
         }
 
-        // ---- epilogue: (+ residual, re-read from global: the block input is L2-hot) and NHWC store ----
+        // ---- epilogue: (+ residual) and NHWC store ----
+        if (C::RES) {                   // all residual adds first: every load is consumed before the first store is issued
+#pragma unroll
+            for (int i = 0; i < C::AN; ++i)
+#pragma unroll
+                for (int j = 0; j < C::AP; ++j) {
+                    acc[i][j] += resv[i][j];                                // x + conv(x): same shape, same index
+                    asm volatile("" : "+v"(acc[i][j]));                      // (keeps the add from being sunk into the store's branch)
+                }
+        }
 #pragma unroll
         for (int i = 0; i < C::AN; ++i) {
             const int nt = wn + i * C::WN;
@@ -376,7 +402,6 @@ void fused_block_early_kernel(
                 const int oy = oy0 + po / C::TW, ox = ox0 + po % C::TW;
                 f32x4 v = acc[i][j];
                 const size_t o = ((size_t)(f * C::HOUT + oy) * C::HOUT + ox) * C::COUT + n;
-                if (C::RES) v += *(const f32x4 *)&X[o];                 // x + conv(x): same shape, same index
                 *(f32x4 *)&Y[o] = v;
             }
         }

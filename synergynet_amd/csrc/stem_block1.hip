@@ -118,10 +118,12 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                 const int ly = it / ROWDW, d = it % ROWDW;
                 const int iy = iy0 + ly;
                 const int byte0 = ix0 * 3 - 3 + 4 * d;                   // byte offset inside the image row
-                unsigned v = 0x80808080u;                                 // never used un-masked
-                if (it < IT * ROWDW && iy >= 0 && iy < kImg && byte0 >= 0 && byte0 + 3 < kImg * 3)
-                    v = *(const unsigned *)(img8 + ((size_t)(f * kImg + iy) * kImg) * 3 + byte0);
-                xr8[ii] = v;
+                // Branch-free: rows / dwords outside the image are clamped into it (store_patch masks them, the value is
+                // never used).  A conditional load would make the compiler guard the register's default value with
+                // s_waitcnt vmcnt(0) -- which, vector memory being in order, also waits for the previous tile's stores.
+                const int iyc = iy < 0 ? 0 : (iy >= kImg ? kImg - 1 : iy);
+                const int bc = byte0 < 0 ? 0 : (byte0 + 3 < kImg * 3 ? byte0 : kImg * 3 - 4);
+                xr8[ii] = *(const unsigned *)(img8 + ((size_t)(f * kImg + iyc) * kImg) * 3 + bc);
             }
         } else {
 #pragma unroll
@@ -169,18 +171,22 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     };
 
     int tile = blockIdx.x;
-    if (tile < total_tiles) load_patch(tile);
+    if (tile < total_tiles) { load_patch(tile); if (!(ablate & 1)) store_patch(tile); }
     // de-phase the co-resident persistent workgroups of a CU (they start together and would otherwise hit the
     // same MFMA / VALU / LDS stage at the same time): workgroup "layer" k waits k * ~1/3 tile time once
     if (ablate & 16)
         for (int i = 0; i < (int)(blockIdx.x >> 8) * 3; ++i) __builtin_amdgcn_s_sleep(32);
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0), visible to the compiler: the filter / BN constants are in; no wait
+                                                     // for them is left inside the tile loop
     for (; tile < total_tiles; tile += gridDim.x) {
         int f, oy0, ox0;
         tile_origin(tile, f, oy0, ox0);
         const int fy0 = oy0 - 1, fx0 = ox0 - 1;      // stem-output coords of Es pixel (0,0)
-        if (!(ablate & 1)) store_patch(tile);
-        __syncthreads();
-        if (!(ablate & 1) && tile + (int)gridDim.x < total_tiles) load_patch(tile + gridDim.x);     // in flight during the whole tile
+        __syncthreads();                              // the patch planes `im` of this tile are complete
+        // unconditional (the last iteration fetches its own tile again): with control flow around the prefetch the compiler
+        // protects the reuse of its registers with s_waitcnt vmcnt(0) at the loop top, right behind the previous tile's stores
+        const int next = tile + (int)gridDim.x < total_tiles ? tile + (int)gridDim.x : tile;
+        load_patch(next);                             // in flight during the stem conv and the depthwise stage
 
         // ---- stem conv on the MFMA: im2col GEMM  E[144 px][32] = patch[px][27(+5 zero)] . W0^T ----
         // MFMA "B" = patches gathered straight from the LDS image planes: lane (pixel r16, k-slot g) reads
@@ -265,6 +271,11 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
             }
         }
         __syncthreads();
+        // The next tile's patch goes to LDS HERE, before this tile's output stores are issued (`im` is free since the barrier
+        // after the stem conv): vector memory retires in order, so consuming the prefetched registers after the stores -- at
+        // the top of the next iteration -- meant waiting for every store's acknowledgement once per tile.
+        store_patch(next);
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) the compiler can see: no load is pending once the stores start
         // ---- linear 1x1 32 -> 16 on the MFMA: 7 pixel tiles over 4 waves ----
         if (!(ablate & 8))
         for (int pt = wave; pt < POUTP / 16; pt += 4) {
@@ -281,8 +292,8 @@ __global__ __launch_bounds__(NTH) void stem_block1_kernel(
                 *(f32x4 *)&Y[((size_t)(f * 60 + oy) * 60 + ox) * 16 + 4 * g] = acc;
             }
         }
-        // the next iteration rewrites `im` (read in the stem stage, two barriers ago) and then barriers before
-        // Es is rewritten; Ds is rewritten only after two more barriers -> no extra barrier needed here
+        // the next iteration barriers before `im` is read and before Es is rewritten; Ds is rewritten only after two more
+        // barriers -> no extra barrier needed here
     }
 }
 
