@@ -74,9 +74,10 @@ def lib():
     """The loaded library; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.isfile(LIB):
-            raise SynergyHipError(-100, f'{LIB} not built; run `python -c "import __graft_entry__ as g; g.build()"`')
-        l = C.CDLL(LIB)
+        path = os.environ.get('SYNERGY_HIP_LIB', LIB)      # A/B of two builds on one box (tools/ab_bench.sh); default: the in-tree build
+        if not os.path.isfile(path):
+            raise SynergyHipError(-100, f'{path} not built; run `python -c "import __graft_entry__ as g; g.build()"`')
+        l = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args

@@ -160,22 +160,36 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     fetch_a1(0);
 
     // ---- stage 0: input tile -> three bf16 planes (exact split), zero beyond the batch / tile ----
+    // All loads first, branch-free (indices clamped, the value zeroed afterwards): with a branch around each load the compiler
+    // waited for every load before issuing the next one -- X_IPT serialised L2 round trips at the start of every workgroup.
+    {
+        f32x4 xv[C::X_IPT];
 #pragma unroll
-    for (int ii = 0; ii < C::X_IPT; ++ii) {
-        const int it = tid + ii * NT;
-        if (it >= C::X_ITEMS) break;
-        const int c4 = it % (C::CIN / 4), p = it / (C::CIN / 4);
-        f32x4 v = z4;
-        if (p < C::PIN) {
-            const int f = f0 + p / (C::IH * C::IW);
-            if (f < B) v = *(const f32x4 *)&X[((size_t)f * C::IH * C::IW + p % (C::IH * C::IW)) * C::CIN + 4 * c4];
+        for (int ii = 0; ii < C::X_IPT; ++ii) {
+            const int it = tid + ii * NT;
+            const int c4 = it % (C::CIN / 4);
+            int p = it / (C::CIN / 4);
+            p = p < C::PIN ? p : C::PIN - 1;
+            int f = f0 + p / (C::IH * C::IW);
+            f = f < B ? f : B - 1;
+            xv[ii] = *(const f32x4 *)&X[((size_t)f * C::IH * C::IW + p % (C::IH * C::IW)) * C::CIN + 4 * c4];
         }
-        unsigned h0, m0, l0, h1, m1, l1;
-        split2b(v[0], v[1], h0, m0, l0);
-        split2b(v[2], v[3], h1, m1, l1);
-        *(u32x2 *)&Xb[0 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){h0, h1};
-        *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){m0, m1};
-        *(u32x2 *)&Xb[2 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){l0, l1};
+#pragma unroll
+        for (int ii = 0; ii < C::X_IPT; ++ii) asm volatile("" : "+v"(xv[ii]));     // (keeps the loads from being sunk to their uses)
+#pragma unroll
+        for (int ii = 0; ii < C::X_IPT; ++ii) {
+            const int it = tid + ii * NT;
+            if (it >= C::X_ITEMS) break;
+            const int c4 = it % (C::CIN / 4), p = it / (C::CIN / 4);
+            const bool real = p < C::PIN && f0 + p / (C::IH * C::IW) < B;
+            const f32x4 v = real ? xv[ii] : z4;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2b(v[0], v[1], h0, m0, l0);
+            split2b(v[2], v[3], h1, m1, l1);
+            *(u32x2 *)&Xb[0 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){h0, h1};
+            *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){m0, m1};
+            *(u32x2 *)&Xb[2 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){l0, l1};
+        }
     }
     if (C::POUTP > C::POUT)
         for (int it = tid; it < 3 * (C::POUTP - C::POUT) * C::DSD; it += NT) {

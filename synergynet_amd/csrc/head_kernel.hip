@@ -238,18 +238,33 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     };
 #pragma unroll
     for (int kc = 0; kc < 5; ++kc) lda(nt0 + wave, kc, ring[kc]);
-    // input tile -> three bf16 planes in LDS (the split happens exactly once per element)
-    for (int it = tid; it < PX * (K / 4); it += 256) {
-        const int c4 = it % (K / 4), p = it / (K / 4);
-        const int f = f0 + (p >> 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (f < B) v = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
-        unsigned h0, m0, l0, h1, m1, l1;
-        split2(v[0], v[1], h0, m0, l0);
-        split2(v[2], v[3], h1, m1, l1);
-        *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){h0, h1};
-        *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){m0, m1};
-        *(u32x2 *)&Xb[2 * PLANE + p * XSD + 2 * c4] = (u32x2){l0, l1};
+    // input tile -> three bf16 planes in LDS (the split happens exactly once per element).  All ten loads of a thread are
+    // issued before the first is consumed, branch-free (face index clamped, value zeroed afterwards): as a plain loop with
+    // `if (f < B)` around the load it compiled to ten serialised load -> s_waitcnt vmcnt(0) -> split round trips.
+    {
+        constexpr int XI = PX * (K / 4) / 256;
+        static_assert(PX * (K / 4) % 256 == 0, "whole rounds");
+        f32x4 xv[XI];
+#pragma unroll
+        for (int ii = 0; ii < XI; ++ii) {
+            const int it = tid + ii * 256, c4 = it % (K / 4), p = it / (K / 4);
+            int f = f0 + (p >> 4);
+            f = f < B ? f : B - 1;
+            xv[ii] = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
+        }
+#pragma unroll
+        for (int ii = 0; ii < XI; ++ii) asm volatile("" : "+v"(xv[ii]));        // (keeps the loads from being sunk to their uses)
+#pragma unroll
+        for (int ii = 0; ii < XI; ++ii) {
+            const int it = tid + ii * 256, c4 = it % (K / 4), p = it / (K / 4);
+            const f32x4 v = f0 + (p >> 4) < B ? xv[ii] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            unsigned h0, m0, l0, h1, m1, l1;
+            split2(v[0], v[1], h0, m0, l0);
+            split2(v[2], v[3], h1, m1, l1);
+            *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){h0, h1};
+            *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){m0, m1};
+            *(u32x2 *)&Xb[2 * PLANE + p * XSD + 2 * c4] = (u32x2){l0, l1};
+        }
     }
     __syncthreads();
 
