@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=1024, help='faces per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--overlap', type=int, default=1, help='1 (default): reconstruction of batch i on a second stream beside the backbone of batch i+1; 0: one stream')
     ap.add_argument('--arch', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet50'],
                     help='resnet50 = BASELINE configs[4] (use --batch 512); the default bench line is mobilenet_v2')
     args = ap.parse_args()
@@ -116,11 +117,13 @@ def main():
     lmk = torch.empty((B, 3, 68), dtype=torch.float32, device=dev)
     mesh = model.empty_vertices(B, dense=True)       # [B,3,53215] view, rows pitched to 128-byte lines (syn_reconstruct_pitched)
 
+    # Two HIP streams (synergynet_amd/streams.py): the reconstruction of batch i (HBM-write bound) runs beside the backbone of
+    # batch i+1 (issue bound); every step still does the whole pass, the final barrier waits for both streams.
+    from synergynet_amd.streams import OverlappedPipeline
+    pipe = OverlappedPipeline(model, overlap=bool(args.overlap))
+
     def step():
-        param = model.forward_crops_u8(crops)
-        model.reconstruct(param, roi=rois, dense=False, out=lmk)
-        model.reconstruct(param, roi=rois, dense=True, out=mesh)
-        model.predict_pose_batch(param, rois)
+        pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh)
 
     for _ in range(args.warmup):
         step()
@@ -208,7 +211,8 @@ def main():
                                         ' 120x120 uint8 crops -> 62 params -> 68 landmarks + 53215-vertex mesh '
                                         '+ pose, ROI affine, all on device' + ('' if args.arch == 'resnet50' else ' (BASELINE configs[2]/[3])'),
                                faces_per_gpu_per_step=B, global_batch=B * world, parallelism=f'face-shard x{world}',
-                               collectives='one RCCL broadcast of packed constants at init, none in the timed region'),
+                               collectives='one RCCL broadcast of packed constants at init, none in the timed region',
+                               streams=('2: reconstruction of batch i beside the backbone of batch i+1' if args.overlap else '1')),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1 and args.arch == 'mobilenet_v2':
             out['cpu_baseline'] = cpu_baseline(sd, pack)

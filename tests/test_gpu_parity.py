@@ -195,6 +195,28 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model, B):
     assert torch.equal(got, ref[idx.cuda()])
 
 
+def test_two_stream_pipeline_equals_sequential_calls(model):
+    """synergynet_amd/streams.py: reconstruction of batch i beside the backbone of batch i+1 -- same bits as the calls in
+    sequence, for every batch of a stream of different batches (buffers of a batch stay alive while it is in flight)."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.streams import OverlappedPipeline
+    B, nb = 96, 5
+    crops = [torch.from_numpy(synth.make_crops(B, seed=90 + i)).cuda() for i in range(nb)]
+    rois = [torch.from_numpy(synth.make_rois(B, seed=190 + i)).cuda() for i in range(nb)]
+    want = []
+    for c, r in zip(crops, rois):
+        p = model.forward_crops_u8(c)
+        want.append((p, model.reconstruct(p, roi=r, dense=False), model.reconstruct(p, roi=r, dense=True), model.predict_pose_batch(p, r)))
+    torch.cuda.synchronize()
+    pipe = OverlappedPipeline(model)
+    got = [pipe.submit(c, r) for c, r in zip(crops, rois)]
+    pipe.wait()
+    torch.cuda.synchronize()
+    for (p, l, m, (a, t)), (p2, l2, m2, (a2, t2)) in zip(want, got):
+        assert torch.equal(p, p2) and torch.equal(l, l2) and torch.equal(m, m2) and torch.equal(a, a2) and torch.equal(t, t2)
+
+
 @pytest.mark.parametrize('B', [1, 31, 32, 33, 64, 100])
 def test_pitched_and_packed_outputs_are_identical(model, B):
     """reconstruct() writes into a row-pitched [B,3,n] view by default (whole-line stores, syn_reconstruct_pitched) and into
