@@ -129,7 +129,7 @@ int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int
 
 /* Same contraction into a PITCHED output: the rows of out (one per face and coordinate) start row_pitch floats apart,
  * row_pitch >= n (n = n_vert or n_lmk); syn_reconstruct is row_pitch = n.  Columns [n, row_pitch) may be overwritten with
- * unspecified (finite) values.
+ * unspecified (finite) values, so out must be B*3*row_pitch floats long (the last row included).
  * Why: the reference's result is a [B,3,53215] tensor (synergy3DMM.py:131-147) whose rows are 212860 bytes, so packed rows
  * are only 4-byte aligned and every store run shares HBM lines with its neighbours (measured 3.3 TB/s of writes).  With
  * row_pitch = n rounded up to a multiple of 128 floats (53248) and a 128-byte aligned out every run is whole lines
