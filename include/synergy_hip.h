@@ -128,15 +128,16 @@ int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int
                     int transform, const float *roi, float *out, void *stream);
 
 /* Same contraction into a PITCHED output: the rows of out (one per face and coordinate) start row_pitch floats apart,
- * row_pitch >= n (n = n_vert or n_lmk); syn_reconstruct is row_pitch = n.  Columns [n, row_pitch) may be overwritten with
- * unspecified (finite) values, so out must be B*3*row_pitch floats long (the last row included).
+ * row_pitch >= n (n = n_vert or n_lmk); syn_reconstruct is row_pitch = n.
+ * pad_writable != 0: the caller owns columns [n, row_pitch) of every row too (out is B*3*row_pitch floats long, the last
+ * row included) and allows them to be overwritten with unspecified finite values; 0: they are left untouched.
  * Why: the reference's result is a [B,3,53215] tensor (synergy3DMM.py:131-147) whose rows are 212860 bytes, so packed rows
  * are only 4-byte aligned and every store run shares HBM lines with its neighbours (measured 3.3 TB/s of writes).  With
- * row_pitch = n rounded up to a multiple of 128 floats (53248) and a 128-byte aligned out every run is whole lines
- * (5.2 TB/s) and the kernel takes its branch-free store path.  A torch view `storage[:, :, :n]` of a [B,3,row_pitch]
- * allocation has the reference's shape and values. */
+ * row_pitch = n rounded up to a multiple of 128 floats (53248), a 128-byte aligned out and writable pad columns every run
+ * is whole lines (5.2 TB/s) and the kernel takes its branch-free store path.  A torch view `storage[:, :, :n]` of a
+ * [B,3,row_pitch] allocation has the reference's shape and values. */
 int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_len, int dense,
-                            int transform, const float *roi, float *out, int row_pitch, void *stream);
+                            int transform, const float *roi, float *out, int row_pitch, int pad_writable, void *stream);
 
 /* ---- mesh consumers: what the reference's demo does with the meshes (utils/render.py:31-50) ----
  * syn_load_triangles: the mesh topology (param_pack `tri`, 0-based, [ntri,3] int32 host pointer), once per handle;

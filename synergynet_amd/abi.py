@@ -54,7 +54,7 @@ _SIGS = {
     'syn_rasterize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'syn_add_weighted': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     'syn_reconstruct': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'syn_reconstruct_pitched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'syn_reconstruct_pitched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'syn_pose': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_backbone_launch_count': (C.c_int, [C.c_void_p]),
     'syn_backbone_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

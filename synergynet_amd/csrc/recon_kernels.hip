@@ -479,7 +479,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
 }
 
 void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
-                           int nvp, const float *roi, int transform, float *out, int pitch, int B, hipStream_t s, float *rec3f) {
+                           int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3f) {
     unsigned *rec3 = reinterpret_cast<unsigned *>(rec3f);
     const int n_ftiles = (B + 31) / 32;
     recon_prep_b3_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
@@ -515,7 +515,7 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
         else
             recon_b3_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
     };
-    if (pitch >= n_groups * WPG * 32) {   // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
+    if (pad_writable && pitch >= n_groups * WPG * 32) {   // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
                                           // store path (columns [n_vert, pitch) receive padding values), the ragged last one guarded
         run(0, B / 32, true);
         run(B / 32, n_ftiles, false);

@@ -974,7 +974,7 @@ int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int
 }
 
 int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
-                            float *out, int row_pitch, void *stream) {
+                            float *out, int row_pitch, int pad_writable, void *stream) {
     if (!h || !param || !out) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
     if (param_len != SYN_PARAM_DIM) return fail(SYN_ERR_PARAM_LEN, "length of params mismatch");
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_reconstruct: B=%d", B);
@@ -988,7 +988,7 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
     hipStream_t s = (hipStream_t)stream;
     if (h->fusion >= 2)
         syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
-                                   roi, transform, out, row_pitch, B, s, rec);
+                                   roi, transform, out, row_pitch, pad_writable, B, s, rec);
     else
         syn::launch_reconstruct(param, basis_mean(h), basis_std(h), dense ? basis_dense(h) : basis_lmk(h), n, dense ? h->nvp : h->nlp,
                                 roi, transform, out, row_pitch, B, s, rec);
@@ -999,7 +999,7 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
 int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
                     float *out, void *stream) {
     if (!h) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
-    return syn_reconstruct_pitched(h, param, B, param_len, dense, transform, roi, out, dense ? h->n_vert : h->n_lmk, stream);
+    return syn_reconstruct_pitched(h, param, B, param_len, dense, transform, roi, out, dense ? h->n_vert : h->n_lmk, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -311,7 +311,7 @@ class SynergyNet(nn.Module):
             try:
                 abi.check(self._lib.syn_reconstruct_pitched(self._h, p.data_ptr(), B, p.shape[1], int(dense), int(transform),
                                                             r.data_ptr() if r is not None else None, out.data_ptr(), int(pitch),
-                                                            self._stream()))
+                                                            int(getattr(out, '_syn_pad_writable', False)), self._stream()))
             except abi.SynergyHipError as e:
                 if e.code == abi.SYN_ERR_PARAM_LEN:
                     raise RuntimeError('length of params mismatch') from None
@@ -325,7 +325,9 @@ class SynergyNet(nn.Module):
         syn_reconstruct_pitched); `.contiguous()` gives the packed copy where a consumer needs one."""
         n = self._n_vert if dense else self._n_lmk
         pitch = (n + 127) // 128 * 128 if n >= 1024 else n          # whole 128-vertex store runs (csrc/recon_kernels.hip)
-        return torch.empty((B, 3, pitch), dtype=torch.float32, device=self.device)[:, :, :n]
+        out = torch.empty((B, 3, pitch), dtype=torch.float32, device=self.device)[:, :, :n]
+        out._syn_pad_writable = pitch > n        # this very tensor object owns its pad columns (views / slices of it do not inherit the mark)
+        return out
 
     def reconstruct_vertex_62(self, param, whitening=True, dense=False, transform=True, lmk_pts=68):
         """reference synergy3DMM.py:116-149.  [B,62] whitened -> [B,3,68] or [B,3,53215] in 120x120 crop

@@ -239,6 +239,10 @@ def test_pitched_and_packed_outputs_are_identical(model, B):
     store = torch.full((B, 3, n + 5), 7.0, device='cuda')
     model.reconstruct(p, roi=roi, dense=True, out=store[:, :, :n])
     assert torch.equal(store[:, :, :n], pitched) and torch.all(store[:, :, n:] == 7.0)
+    # a caller's own wide buffer: pitch large enough for the branch-free path, but its pad columns are not ours to write
+    wide = torch.full((B, 3, pitched.stride(1) + 128), 7.0, device='cuda')
+    model.reconstruct(p, roi=roi, dense=True, out=wide[:, :, :n])
+    assert torch.equal(wide[:, :, :n], pitched) and torch.all(wide[:, :, n:] == 7.0)
     with pytest.raises(RuntimeError, match='pitched rows'):
         model.reconstruct(p, roi=roi, dense=True, out=torch.empty((B, n, 3), device='cuda').permute(0, 2, 1))
 
