@@ -232,23 +232,45 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
 #pragma unroll
         for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
     }
+    // Epilogue in two passes: every load (BN scale / shift, residual) first and branch-free (indices clamped into the matrix),
+    // then the arithmetic and the stores.  Interleaved, each residual load sat between two stores and its wait (vmcnt is in
+    // order, and conservative around the `if`) covered the previous store's acknowledgement: 8 serialised round trips per tile.
+    f32x4 scv[NT], shv[NT], rsv[MT][NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int n = n0 + i * 16 + 4 * g;
-        if (n >= N) continue;
-        const f32x4 sc = *(const f32x4 *)&scale[n];
-        const f32x4 sh = *(const f32x4 *)&shift[n];
+        int n = n0 + i * 16 + 4 * g;
+        n = n < N ? n : 0;
+        scv[i] = *(const f32x4 *)&scale[n];
+        shv[i] = *(const f32x4 *)&shift[n];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const int m = m0 + j * 16 + r16;
-            if (m >= M) continue;
-            f32x4 v = acc[j][i] * sc + sh;
-            if (residual) v += *(const f32x4 *)&residual[(size_t)m * N + n];
+            int m = m0 + j * 16 + r16;
+            m = m < M ? m : 0;
+            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v = acc[j][i] * scv[i] + shv[i];
+            if (residual) v += rsv[j][i];
             if (act) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
             }
-            *(f32x4 *)&out[(size_t)m * N + n] = v;
+            acc[j][i] = v;
+            asm volatile("" : "+v"(acc[j][i]));         // (keeps the arithmetic from being sunk into the store's branch)
+        }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + i * 16 + 4 * g;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + j * 16 + r16;
+            if (m >= M) continue;
+            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
         }
     }
 }
