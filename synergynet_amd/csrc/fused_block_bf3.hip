@@ -58,11 +58,12 @@ __device__ __forceinline__ f32x4 mac6(const u32x4 (&a)[3], const u32x4 (&b)[3], 
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int NF_, int HC_, int NW_, int EPB_, int WN_, int WP_, int OCC_ = 1>
+template <int CIN_, int HID_, int COUT_, int HIN_, int S_, bool RES_, int NF_, int HC_, int NW_, int EPB_, int WN_, int WP_, int OCC_ = 1, bool PERSIST_ = false>
 struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, HIN = HIN_, S = S_, NF = NF_, HC = HC_, NW = NW_,
                          EPB = EPB_, WN = WN_, WP = WP_;
-    static constexpr bool RES = RES_;
+    static constexpr bool RES = RES_, PERSIST = PERSIST_;
+    static constexpr int SLOTS = 256 * OCC_;      // resident workgroups of the device (256 CUs)
     static constexpr int NT = NW * 64;
     static constexpr int WPE = OCC_ * NW / 4;     // waves per SIMD the register budget is sized for (OCC workgroups per CU)
     static constexpr int HOUT = S == 2 ? (HIN + 1) / 2 : HIN;
@@ -98,7 +99,11 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
 // NS > 1 (small batches only): blockIdx.y selects one of NS slices of the block's OUTPUT channel tiles.  Every slice repeats the
 // expand and depthwise stages (idle compute at small B) but streams only its share of the project weights, and each output
 // element is produced by exactly the same instruction sequence as with NS = 1 -- results do not depend on the batch size.
-template <class C, bool PROF = false, int NS = 1>
+// PERSIST: the grid is the number of resident workgroups and a workgroup walks face groups blockIdx.x, + gridDim.x, ...; the input
+// tile of the next group is fetched into registers while the current one computes (the staging -- 10-19 % of a workgroup's life at
+// one group per workgroup -- shrinks to the split and the LDS writes), and the expand weights of chunk 0 arrive through the
+// wrap-around of the per-chunk prefetch.
+template <class C, bool PROF = false, int NS = 1, bool PERSIST = false>
 __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_bf3_kernel(
     const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/, const float *__restrict__ e_shift,
     const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][3][64][4]*/,
@@ -116,7 +121,8 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     const int r16 = lane & 15, g = lane >> 4;
     const int wn = wave % C::WN, wp = wave / C::WN;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int f0 = blockIdx.x * C::NF;
+    int f0 = blockIdx.x * C::NF;
+    static_assert(!PERSIST || (NS == 1 && !PROF), "the persistent schedule is the plain large-batch one");
     static_assert(C::NT_O % NS == 0, "output channel tiles split evenly");
     constexpr int NTO_S = C::NT_O / NS, AN_S = cdivb(NTO_S, C::WN);            // channel tiles of this slice, per wave column
     const int nt_base = NS > 1 ? (int)blockIdx.y * NTO_S : 0;
@@ -162,18 +168,20 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     // ---- stage 0: input tile -> three bf16 planes (exact split), zero beyond the batch / tile ----
     // All loads first, branch-free (indices clamped, the value zeroed afterwards): with a branch around each load the compiler
     // waited for every load before issuing the next one -- X_IPT serialised L2 round trips at the start of every workgroup.
-    {
-        f32x4 xv[C::X_IPT];
+    f32x4 xv[C::X_IPT];
+    auto load_x = [&](int fb) {
 #pragma unroll
         for (int ii = 0; ii < C::X_IPT; ++ii) {
             const int it = tid + ii * NT;
             const int c4 = it % (C::CIN / 4);
             int p = it / (C::CIN / 4);
             p = p < C::PIN ? p : C::PIN - 1;
-            int f = f0 + p / (C::IH * C::IW);
+            int f = fb + p / (C::IH * C::IW);
             f = f < B ? f : B - 1;
             xv[ii] = *(const f32x4 *)&X[((size_t)f * C::IH * C::IW + p % (C::IH * C::IW)) * C::CIN + 4 * c4];
         }
+    };
+    auto park_x = [&](int fb) {
 #pragma unroll
         for (int ii = 0; ii < C::X_IPT; ++ii) asm volatile("" : "+v"(xv[ii]));     // (keeps the loads from being sunk to their uses)
 #pragma unroll
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             const int it = tid + ii * NT;
             if (it >= C::X_ITEMS) break;
             const int c4 = it % (C::CIN / 4), p = it / (C::CIN / 4);
-            const bool real = p < C::PIN && f0 + p / (C::IH * C::IW) < B;
+            const bool real = p < C::PIN && fb + p / (C::IH * C::IW) < B;
             const f32x4 v = real ? xv[ii] : z4;
             unsigned h0, m0, l0, h1, m1, l1;
             split2b(v[0], v[1], h0, m0, l0);
@@ -190,7 +198,8 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){m0, m1};
             *(u32x2 *)&Xb[2 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){l0, l1};
         }
-    }
+    };
+    load_x(f0);
     if (C::POUTP > C::POUT)
         for (int it = tid; it < 3 * (C::POUTP - C::POUT) * C::DSD; it += NT) {
             const int p = it / ((C::POUTP - C::POUT) * C::DSD), r = it % ((C::POUTP - C::POUT) * C::DSD);
@@ -202,6 +211,12 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         const int n = (nt_base + wn + i * C::WN) * 16 + 4 * g;
         psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
     }
+    const int gstep = (int)gridDim.x * C::NF;
+    for (;;) {                                  // face groups of this workgroup (exactly one unless PERSIST)
+    park_x(f0);
+    const int f0n = f0 + gstep;
+    const bool more = PERSIST && f0n < B;
+    if (PERSIST) load_x(more ? f0n : f0);       // unconditional: in flight during all the chunks of this group
     f32x4 acc[C::AN][C::AP];
 #pragma unroll
     for (int i = 0; i < AN_S; ++i)
@@ -334,6 +349,9 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         SYNB_LAP(5);
     }
 
+    // the prefetched tile (and the wrapped-around weight fetch) are waited for BEFORE the output stores: vector memory retires in
+    // order, a wait placed after them would also wait for their acknowledgements
+    if (PERSIST) __builtin_amdgcn_s_waitcnt(0x0F70);
     // ---- epilogue: (+ residual rebuilt exactly from the three input planes) and NHWC store ----
 #pragma unroll
     for (int i = 0; i < AN_S; ++i) {
@@ -363,6 +381,10 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         }
     }
     SYNB_LAP(6);
+    if (!more) break;
+    f0 = f0n;
+    __syncthreads();                            // the planes of this group (residual reads) are done before the next tile is written
+    }
     if (PROF && tid == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
         atomicAdd(&prof[7], 1ull);
@@ -380,13 +402,21 @@ static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::NF - 1) / C::NF;
     if (a.prof)
         fused_block_bf3_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.prof);
-    else
+    else {
+        if constexpr (C::PERSIST) {
+            if (grid > C::SLOTS) {
+                fused_block_bf3_kernel<C, false, 1, true><<<C::SLOTS, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+                return;
+            }
+        }
         fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+    }
 }
 
-//                      CIN  HID COUT HIN S  RES   NF  HC NW EPB WN WP
-using B5 = Bf3Cfg<   32, 192,  32, 15, 1, true,   1, 32, 8, 4, 2, 4>;    // features.5,6
-using B7 = Bf3Cfg<   32, 192,  64, 15, 2, false,  1, 32, 8, 4, 4, 2>;    // features.7
+//                      CIN  HID COUT HIN S  RES   NF  HC NW EPB WN WP [OCC [PERSIST]]
+// PERSIST where measured faster (features.5-7: -6...8 %; features.8-10 neutral; .11-.14 would spill: +44 registers)
+using B5 = Bf3Cfg<   32, 192,  32, 15, 1, true,   1, 32, 8, 4, 2, 4, 1, true>;    // features.5,6
+using B7 = Bf3Cfg<   32, 192,  64, 15, 2, false,  1, 32, 8, 4, 4, 2, 1, true>;    // features.7
 using B8 = Bf3Cfg<   64, 384,  64,  8, 1, true,   1, 64, 4, 4, 4, 1, 2>;    // features.8-10
 using B11 = Bf3Cfg<  64, 384,  96,  8, 1, false,  1, 64, 4, 4, 2, 2, 2>;    // features.11
 using B12 = Bf3Cfg<  96, 576,  96,  8, 1, true,   1, 32, 4, 2, 2, 2, 2>;    // features.12,13
