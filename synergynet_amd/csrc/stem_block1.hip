@@ -47,13 +47,16 @@ __device__ __forceinline__ f32x4 r6(f32x4 v) {
 // BF: (uint8 crops only) the stem GEMM runs on the bf16 matrix pipe.  A normalised uint8 pixel (2x - 255) / 256 has 8
 // significant bits, i.e. it IS a bf16 number, so only the filter needs the exact 3-way split (w0b3): 3 MFMAs of K = 32
 // per (16 pixels x 16 channels) instead of 8 fp32-input MFMAs of K = 4, products exact, fp32 accumulation.
-template <bool U8, bool BF>
+// ABL: stage ablation for profiling (SYN_ABLATE_STEM) is a separate instantiation -- runtime flags around the MFMA loops cost the
+// production kernel scheduling freedom.
+template <bool U8, bool BF, bool ABL = false>
 __global__ __launch_bounds__(NTH) void stem_block1_kernel(
     const float *__restrict__ img, const uint8_t *__restrict__ img8, const float *__restrict__ w0 /*[27][32]*/,
     const unsigned *__restrict__ w0b3 /*[2][3][64][4]*/,
     const float *__restrict__ s0, const float *__restrict__ b0, const float *__restrict__ wd /*[9][32]*/,
     const float *__restrict__ sd, const float *__restrict__ bd, const float *__restrict__ wp /*Wpk[1][2][64][4]*/,
-    const float *__restrict__ sp, const float *__restrict__ bp, float *__restrict__ Y, int total_tiles, int ablate) {
+    const float *__restrict__ sp, const float *__restrict__ bp, float *__restrict__ Y, int total_tiles, int ablate_) {
+    const int ablate = ABL ? ablate_ : 0;
     __shared__ __attribute__((aligned(16))) float im[3 * IT * ITS];
     __shared__ __attribute__((aligned(16))) float Es[PIN * ES];
     __shared__ __attribute__((aligned(16))) float Ds[POUTP * ES];
@@ -305,7 +308,8 @@ void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, 
     // layer would only start when the first two finish (measured 361 -> 322 us at B = 1024 going from 3 to 2)
     const int grid = total < 256 * 2 ? total : 256 * 2;
     static const int ablate = getenv("SYN_ABLATE_STEM") ? atoi(getenv("SYN_ABLATE_STEM")) : 0;   // profiling only: skip stages
-    if (img8 && w0b3) stem_block1_kernel<true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    if (img8 && w0b3 && ablate) stem_block1_kernel<true, true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
+    else if (img8 && w0b3) stem_block1_kernel<true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, 0);
     else if (img8)    stem_block1_kernel<true, false><<<grid, NTH, 0, s>>>(nullptr, img8, w0, nullptr, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
     else              stem_block1_kernel<false, false><<<grid, NTH, 0, s>>>(img, nullptr, w0, nullptr, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
 }
