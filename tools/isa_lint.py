@@ -9,6 +9,7 @@ import os
 import re
 import subprocess
 import sys
+import shutil
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,7 @@ def main():
             if src == 'synergy_abi.hip':
                 continue
             out = os.path.join(td, src + '.s')
-            r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w',
+            r = subprocess.run([shutil.which('hipcc') or '/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w',
                                 '-I' + os.path.join(ROOT, 'include'), '-o', out, os.path.join(CSRC, src)],
                                capture_output=True, text=True)
             if r.returncode:
