@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='faces per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--overlap', type=int, default=1, help='1 (default): reconstruction of batch i on a second stream beside the backbone of batch i+1; 0: one stream')
+    ap.add_argument('--rec-priority', type=int, default=-1, help='HIP priority of the reconstruction stream (-1 high = default, 0 normal)')
     ap.add_argument('--arch', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet50'],
                     help='resnet50 = BASELINE configs[4] (use --batch 512); the default bench line is mobilenet_v2')
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main():
     # Two HIP streams (synergynet_amd/streams.py): the reconstruction of batch i (HBM-write bound) runs beside the backbone of
     # batch i+1 (issue bound); every step still does the whole pass, the final barrier waits for both streams.
     from synergynet_amd.streams import OverlappedPipeline
-    pipe = OverlappedPipeline(model, overlap=bool(args.overlap))
+    pipe = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
 
     def step():
         pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh)
