@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Throughput bench of the SynergyNet inference hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W           (N=1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+  python bench.py --gpus N --steps K --warmup W
+      N = 1: runs in this process.  N > 1 without a torchrun environment: spawns N ranks of itself (one process per GPU,
+      RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set here, rendezvous on 127.0.0.1) and relays rank 0's JSON line.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's N > 1 launch)
 
 One "step" = one pass of the hot path over one batch of synthetic crops per GPU:
 uint8 crops [B,120,120,3] already resident in HBM -> MobileNetV2 -> 62 params ->
@@ -12,12 +14,20 @@ faces per GPU, i.e. configs[3]'s 8192 faces over 8 GPUs).  Weak scaling: every r
 processes its own shard of B faces; the only collective is the one-time RCCL broadcast
 of the packed constants from rank 0 (outside the timed region).
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+`--lmk-only` times BASELINE configs[1] instead (B = 128 by default, 68 landmarks + pose, no mesh).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline`, `cpu_baseline` and `extra`
+(the other BASELINE configs and the reference-API variants of the headline step, each timed briefly on the same box:
+configs[1] B = 128 landmarks only, fp32 NCHW ingest through forward_test, the reference's packed [B,3,53215] output,
+one stream, ResNet-50 B = 512 = configs[4]).
 """
 import argparse
 import ctypes
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,74 +40,210 @@ sys.path.insert(0, ROOT)
 from synergynet_amd import synth                      # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the exact 3-way split issues 6 bf16 MFMAs per fp32 block product
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sd, pack, budget_s=24.0):
-    """The reference's CPU path restated with the same torch-CPU / numpy ops (oracle/ = "port"), batched
-    best case (BASELINE.md variant ii): forward(B=64) + batched 68-lmk and 53215-vertex reconstruction + pose.
-    torch intra-op thread counts {8, 16, 32, all cores} are each timed for a slice of the budget and the best is
-    reported (the reference leaves threading at torch's default; oversubscribing a big host hurts small convs)."""
-    from oracle import backbone_torch, recon_numpy
-    cores = os.cpu_count() or 1
+# ------------------------------------------------------------------------------------------------ CPU baseline (checker leg)
+def _cpu_info():
+    model, phys = platform.processor() or 'unknown', None
+    try:
+        txt = open('/proc/cpuinfo').read()
+        for line in txt.splitlines():
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+        cores = set()
+        pid = cid = None
+        for line in txt.splitlines() + ['']:
+            if line.startswith('physical id'):
+                pid = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':')[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys
+
+
+def cpu_baseline(sd, pack, budget_s=26.0):
+    """BASELINE.md section 2 on this box's host cores, on a bounded sample.
+
+    kind "reference": /root/reference is importable (authoring container) -> the reference's OWN module is the timed code
+    (oracle/ref_loader.py imports it from where it lies).  kind "port": the GPU box has no /root/reference -> the oracle's
+    restatement of the same torch-CPU / numpy calls (oracle/backbone_torch.py, oracle/recon_numpy.py).
+    Two variants: (i) the loop body of get_all_outputs per face (B = 1 forward_test + numpy sparse / dense vertices + pose,
+    synergy3DMM.py:194-201) and (ii) best-case batched (forward_test(B = 64) + reconstruct_vertex_62 sparse and dense).
+    Protocol: fp32, no_grad, eval; per thread count 2 warm-up iterations, then the median of >= 10 timed iterations
+    (fewer only if the time slice runs out -- the count is reported); thread counts tried: all physical cores (BASELINE.md's
+    protocol) and 32 / 16 / 8 (small convolutions do not scale to 128 threads); `value` = the best batched rate."""
+    from oracle import backbone_torch, recon_numpy, ref_loader
+    logical = os.cpu_count() or 1
+    model_name, phys = _cpu_info()
+    phys = phys or logical
     b = recon_numpy.Basis(pack)
     Bc = 64
-    x = synth.normalize_crops(synth.make_crops(Bc, seed=1))
+    x = torch.from_numpy(synth.normalize_crops(synth.make_crops(Bc, seed=1)))
+    roi = [0.0, 0.0, 120.0, 120.0, 1.0]
+    kind = 'port'
+    if ref_loader.available():
+        try:
+            _, ref_model = ref_loader.build_reference_model(pack, sd)
+            inf = ref_loader._REF_MODULES['utils.inference']
+            kind = 'reference'
+        except Exception as e:                      # pragma: no cover - container quirks must not kill the bench line
+            print('cpu_baseline: reference import failed, timing the port:', e, file=sys.stderr)
 
-    def one():
-        p, _ = backbone_torch.mobilenet_v2_forward(sd, x)
-        recon_numpy.reconstruct_vertex_62(b, p.numpy(), dense=False)
-        recon_numpy.reconstruct_vertex_62(b, p.numpy(), dense=True)
-        for i in range(Bc):
-            recon_numpy.predict_pose(b, p.numpy()[i], [0, 0, 120, 120, 1])
+    if kind == 'reference':
+        def batched():
+            with torch.no_grad():
+                p = ref_model.forward_test(x)
+                ref_model.reconstruct_vertex_62(p, dense=False)
+                ref_model.reconstruct_vertex_62(p, dense=True)
 
-    cands = sorted({t for t in (8, 16, 32, cores) if t <= cores})
-    best = None
+        def per_face(i):
+            with torch.no_grad():
+                p = ref_model.forward_test(x[i:i + 1]).numpy()[0]
+            inf.predict_sparseVert(p, roi, transform=True)
+            inf.predict_denseVert(p, roi, transform=True)
+            inf.predict_pose(p, roi)
+    else:
+        def batched():
+            p, _ = backbone_torch.mobilenet_v2_forward(sd, x.numpy())
+            recon_numpy.reconstruct_vertex_62(b, p.numpy(), dense=False)
+            recon_numpy.reconstruct_vertex_62(b, p.numpy(), dense=True)
+
+        def per_face(i):
+            p, _ = backbone_torch.mobilenet_v2_forward(sd, x[i:i + 1].numpy())
+            p = p.numpy()[0]
+            recon_numpy.predict_vertices(b, p, roi, dense=False)
+            recon_numpy.predict_vertices(b, p, roi, dense=True)
+            recon_numpy.predict_pose(b, p, roi)
+
+    cands = sorted({t for t in (8, 16, 32, phys) if t <= logical})
+    slice_s = budget_s / (2 * len(cands))
+
+    def timed(fn, unit_faces):
+        fn(); fn()
+        ts, t_end = [], time.perf_counter() + slice_s
+        while len(ts) < 10 or (len(ts) < 15 and time.perf_counter() < t_end):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() > t_end and len(ts) >= 3:
+                break
+        return unit_faces / float(np.median(ts)), len(ts)
+
+    rows = []
     for t in cands:
         torch.set_num_threads(t)
-        one()                                   # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < budget_s / len(cands) / 1.5:
-            one()
-            n += Bc
-        el = time.perf_counter() - t0
-        if n and (best is None or n / el > best[0]):
-            best = (n / el, t, n, el)
-    rate, t, n, el = best
-    return dict(value=round(rate, 2), unit='faces/s', cores=t, kind='port',
-                sample=f'{n} faces in batches of {Bc} on {t} of {cores} host threads ({el:.1f} s): oracle torch-CPU '
-                       f'MobileNetV2 forward + numpy 68-landmark and 53215-vertex reconstruction + pose; '
-                       f'thread counts tried: {cands}')
+        r2, n2 = timed(batched, Bc)
+        k = [0]
+
+        def one():
+            per_face(k[0] % Bc)
+            k[0] += 1
+        r1, n1 = timed(one, 1)
+        rows.append(dict(threads=t, batched_faces_s=round(r2, 2), batched_iters=n2, per_face_faces_s=round(r1, 2), per_face_iters=n1))
+    best = max(rows, key=lambda r: r['batched_faces_s'])
+    best1 = max(rows, key=lambda r: r['per_face_faces_s'])
+    allc = next(r for r in rows if r['threads'] == max(cands))
+    return dict(value=best['batched_faces_s'], unit='faces/s', cores=best['threads'], kind=kind,
+                sample=f'median of {best["batched_iters"]} iterations of forward_test(B={Bc}) + reconstruct_vertex_62 (68 landmarks and '
+                       f'53215 vertices), fp32, on {best["threads"]} torch threads of {phys} physical / {logical} logical cores '
+                       f'({"the reference module itself" if kind == "reference" else "oracle restatement of the reference calls"}); '
+                       f'per-face loop and the other thread counts in `variants`',
+                cpu_model=model_name, physical_cores=phys, logical_cores=logical, torch=torch.__version__, numpy=np.__version__,
+                protocol='2 warm-up + median of >= 10 timed iterations per variant and thread count (BASELINE.md section 2)',
+                per_face_loop=dict(value=best1['per_face_faces_s'], threads=best1['threads'],
+                                   what='B=1 forward_test + predict_sparseVert + predict_denseVert + predict_pose per face '
+                                        '(synergy3DMM.py:194-201)'),
+                all_physical_cores=dict(threads=allc['threads'], batched_faces_s=allc['batched_faces_s'],
+                                        per_face_faces_s=allc['per_face_faces_s']),
+                variants=rows)
+
+
+# ------------------------------------------------------------------------------------------------ multi-process launch
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: one child process per GPU, same argv; rank 0 inherits stdout (its ONE
+    JSON line is this command's output), every rank inherits stderr."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:
+        for p in procs:                 # a failed rank must not leave the others waiting in a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ timing helpers
+def time_steps(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
 
 
 def main():
-    # native libraries (RCCL, HIP) print banners on fd 1: keep the real stdout for the ONE JSON line only
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=1024, help='faces per GPU per step')
+    ap.add_argument('--batch', type=int, default=None, help='faces per GPU per step (default 1024; 128 with --lmk-only; 512 with --arch resnet50)')
+    ap.add_argument('--lmk-only', action='store_true', help='BASELINE configs[1]: 68 landmarks + pose only, no 53215-vertex mesh')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the `extra` measurements (other configs / API variants)')
     ap.add_argument('--overlap', type=int, default=1, help='1 (default): reconstruction of batch i on a second stream beside the backbone of batch i+1; 0: one stream')
     ap.add_argument('--rec-priority', type=int, default=-1, help='HIP priority of the reconstruction stream (-1 high = default, 0 normal)')
     ap.add_argument('--arch', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet50'],
-                    help='resnet50 = BASELINE configs[4] (use --batch 512); the default bench line is mobilenet_v2')
+                    help='resnet50 = BASELINE configs[4]; the default bench line is mobilenet_v2')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    # native libraries (RCCL, HIP) print banners on fd 1: keep the real stdout for the ONE JSON line only
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    assert local < torch.cuda.device_count(), f'rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPUs are visible'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
+    dist_info = None
     if world > 1 or os.environ.get('SYN_BENCH_FORCE_DIST') == '1':      # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from synergynet_amd.synergy3DMM import SynergyNet
@@ -110,13 +256,26 @@ def main():
     else:
         model = SynergyNet(device=dev, load_constants=False, arch=args.arch)
     if dist is not None:
-        broadcast_constants(model, src=0)          # one RCCL broadcast over xGMI, then no collectives
+        t0 = time.perf_counter()
+        nbytes = broadcast_constants(model, src=0)          # one RCCL broadcast over xGMI, then no collectives
+        torch.cuda.synchronize()
+        dist_info = dict(backend=dist.get_backend(), world=world, constants_bytes=nbytes, broadcast_s=round(time.perf_counter() - t0, 4))
+        print(f'[rank {rank}] RCCL broadcast of {nbytes} constant bytes done in {dist_info["broadcast_s"]} s', file=sys.stderr)
+        if os.environ.get('SYN_BENCH_FORCE_DIST') == '1' and world == 1:
+            # single-rank exercise of the receive side too: a second handle that never saw host assets imports the blob
+            twin = SynergyNet(device=dev, load_constants=False, arch=args.arch)
+            twin.import_constants(model.export_constants())
+            c8 = torch.from_numpy(synth.make_crops(8, seed=5)).to(dev)
+            same = torch.equal(twin.forward_crops_u8(c8), model.forward_crops_u8(c8))
+            dist_info['import_twin_bitwise_equal'] = bool(same)
+            assert same, 'imported constants give different parameters'
+            del twin
 
-    B = args.batch
+    B = args.batch or (128 if args.lmk_only else 512 if args.arch == 'resnet50' else 1024)
     crops = torch.from_numpy(synth.make_crops(B, seed=1000 + rank)).to(dev)      # this rank's shard
     rois = torch.from_numpy(synth.make_rois(B, seed=2000 + rank)).to(dev)
     lmk = torch.empty((B, 3, 68), dtype=torch.float32, device=dev)
-    mesh = model.empty_vertices(B, dense=True)       # [B,3,53215] view, rows pitched to 128-byte lines (syn_reconstruct_pitched)
+    mesh = None if args.lmk_only else model.empty_vertices(B, dense=True)   # [B,3,53215] view, rows pitched to 128-byte lines
 
     # Two HIP streams (synergynet_amd/streams.py): the reconstruction of batch i (HBM-write bound) runs beside the backbone of
     # batch i+1 (issue bound); every step still does the whole pass, the final barrier waits for both streams.
@@ -124,7 +283,7 @@ def main():
     pipe = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
 
     def step():
-        pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh)
+        pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh, dense=not args.lmk_only)
 
     for _ in range(args.warmup):
         step()
@@ -149,9 +308,10 @@ def main():
     # --- roofline of the dominant kernel family, measured live with HIP events on the launch stream:
     # syn_backbone_profile records an event after every launch of one forward (C ABI, include/synergy_hip.h)
     roof = None
+    from synergynet_amd import abi
+    lib = abi.lib()
     if rank == 0 and args.arch == 'resnet50':
-        from synergynet_amd import abi
-        fl = abi.lib().syn_resnet50_flops_per_face() * B
+        fl = lib.syn_resnet50_flops_per_face() * B
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
@@ -160,13 +320,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         bb_ms = e0.elapsed_time(e1) / 5
-        roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (53 syn::conv_kernel implicit-GEMM launches + stem + max-pool + heads); fp32 v_mfma_f32_16x16x4_f32',
+        roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (syn::conv_bf3_kernel implicit-GEMM launches + stem + max-pool + heads); '
+                                         'fp32-accurate results on v_mfma_f32_16x16x32_bf16 with the exact 3-way operand split',
                     achieved=round(fl / (bb_ms * 1e-3) / 1e12, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(fl / (bb_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
                     flops_per_launch=fl, ms_per_launch=round(bb_ms, 4))
     elif rank == 0:
-        from synergynet_amd import abi
-        lib = abi.lib()
         nmax = 64
         feat = (ctypes.c_int * nmax)()
         ms = (ctypes.c_float * nmax)()
@@ -183,13 +342,18 @@ def main():
         fam = [i for i, f in enumerate(feats) if 2 <= f <= 17]            # fused inverted-residual block launches
         fam_ms, fam_fl = float(avg_ms[fam].sum()), float(flops[fam].sum())
         achieved = fam_fl / (fam_ms * 1e-3) / 1e12
-        traffic = None
-        tfp = os.path.join(ROOT, 'profiles', 'traffic_r1.json')          # HBM bytes from rocprofv3 --pmc (separate run)
-        if os.path.isfile(tfp):
-            try:
-                traffic = json.load(open(tfp)).get('fused_block_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic = pipe_busy = None
+        for name in ('traffic_r2.json', 'traffic_r1.json'):               # HBM bytes / MFMA-busy from rocprofv3 --pmc (separate runs)
+            tfp = os.path.join(ROOT, 'profiles', name)
+            if os.path.isfile(tfp) and B == 1024:
+                try:
+                    tj = json.load(open(tfp))
+                    traffic = tj.get('fused_block_bytes_per_launch')
+                    pipe_busy = tj.get('fused_block_mfma_pipe_busy')
+                    break
+                except Exception:
+                    pass
+        ceiling = PEAK_BF16_MFMA_TFLOPS / 6.0
         roof = dict(bound='mfma',
                     kernel=f'syn::fused_block_{{early,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
                            f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs); fp32-accurate results on '
@@ -197,24 +361,117 @@ def main():
                            f'algorithmic fp32 FLOPs priced against the fp32 (f32-input) MFMA peak',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                    # the pipe these kernels actually issue on: 6 bf16 MFMAs per fp32 block product -> ceiling 2500 / 6 TFLOP/s of
+                    # fp32-equivalent work; frac_of_bf16x3_ceiling is the honest "share of the pipe in use" figure and
+                    # mfma_pipe_busy the same thing from SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (profiles/, separate PMC run)
+                    bf16x3_ceiling=round(ceiling, 1), frac_of_bf16x3_ceiling=round(achieved / ceiling, 4), mfma_pipe_busy=pipe_busy,
                     flops_per_launch=round(fam_fl / len(fam)), ms_per_launch=round(fam_ms / len(fam), 5),
                     backbone=dict(ms=round(float(avg_ms.sum()), 4), launches=n,
                                   tflops=round(float(flops.sum()) / (float(avg_ms.sum()) * 1e-3) / 1e12, 3)),
                     per_launch=[dict(feature=int(f), ms=round(float(m), 4), tflops=round(float(x) / (float(m) * 1e-3) / 1e12, 2))
                                 for f, m, x in zip(feats, avg_ms, flops)])
 
+    # --- the other BASELINE configs and the reference-API variants of the headline step, briefly, on this box
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extras and args.arch == 'mobilenet_v2' and not args.lmk_only:
+        extra = {}
+        sync = torch.cuda.synchronize
+
+        def rate(Bx, fn, steps=20, warmup=3):
+            ms_ = time_steps(fn, steps, warmup, sync) * 1e3
+            return dict(faces_s=round(Bx / ms_ * 1e3, 1), ms_per_step=round(ms_, 4), faces_per_step=Bx, steps=steps)
+
+        # configs[1]: B = 128, 68 landmarks (+ pose) only
+        c128, r128 = crops[:128].contiguous(), rois[:128].contiguous()
+        l128 = torch.empty((128, 3, 68), dtype=torch.float32, device=dev)
+        p128 = OverlappedPipeline(model, overlap=True, rec_priority=args.rec_priority)
+        extra['b128_lmk_only'] = dict(rate(128, lambda: p128.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10),
+                                      what='BASELINE configs[1]: uint8 crops -> MobileNetV2 -> 68 landmarks + pose, no mesh')
+        p1 = OverlappedPipeline(model, overlap=False)
+        extra['b128_lmk_only_one_stream'] = rate(128, lambda: p1.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10)
+        extra['b1_lmk_only_latency_ms'] = round(time_steps(lambda: p1.submit(crops[:1], rois[:1], dense=False), 200, 20, sync) * 1e3, 4)
+        # the headline step through the reference's own entry points: fp32 NCHW crops into forward_test, packed [B,3,53215] output
+        xf = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=1000))).to(dev)
+        packed = torch.empty((B, 3, model._n_vert), dtype=torch.float32, device=dev)
+
+        def ref_api_step():
+            p = model.forward_test(xf)
+            model.reconstruct(p, roi=rois, dense=False, out=lmk)
+            model.reconstruct(p, roi=rois, dense=True, out=packed)
+            model.predict_pose_batch(p, rois)
+        extra['fp32_ingest_packed_output_one_stream'] = dict(rate(B, ref_api_step, steps=10, warmup=2),
+                                                             what='forward_test(fp32 [B,3,120,120]) + reconstruct into the packed [B,3,53215] layout '
+                                                                  '(synergy3DMM.py:131-147), one stream: the step exactly as the reference API shapes it')
+        pk = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
+        extra['packed_output'] = rate(B, lambda: pk.submit(crops, rois, lmk_out=lmk, mesh_out=packed), steps=10, warmup=2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def ev_ms(fn, reps=10):
+            fn(); sync(); e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); sync()
+            return e0.elapsed_time(e1) / reps
+        pp = model.forward_crops_u8(crops)
+        mesh_bytes = B * 3 * model._n_vert * 4
+        t_pitch = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=mesh))
+        t_pack = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=packed))
+        extra['reconstruction_alone'] = dict(pitched_ms=round(t_pitch, 4), pitched_tb_s=round(mesh_bytes / t_pitch / 1e9, 3),
+                                             packed_ms=round(t_pack, 4), packed_tb_s=round(mesh_bytes / t_pack / 1e9, 3),
+                                             mesh_bytes=mesh_bytes, peak_tb_s=PEAK_HBM_GBS / 1e3)
+        extra['fp32_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_test(xf), 5), 4)
+        extra['u8_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_crops_u8(crops), 5), 4)
+        del xf, packed
+        if args.overlap:
+            one = OverlappedPipeline(model, overlap=False)
+            extra['one_stream'] = rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=10, warmup=2)
+        # sustained clocks: the same headline step for ~2 s
+        extra['sustained_2s'] = rate(B, step, steps=max(args.steps, int(2.0 / max(el / args.steps, 1e-4))), warmup=0)
+        # configs[4]: ResNet-50 B = 512 + full mesh
+        try:
+            rmodel = SynergyNet(device=dev, pack=pack, backbone_state=synth.make_resnet50_state(), arch='resnet50')
+            Br = 512
+            rc, rr = crops[:Br].contiguous(), rois[:Br].contiguous()
+            rl, rm = torch.empty((Br, 3, 68), dtype=torch.float32, device=dev), rmodel.empty_vertices(Br, dense=True)
+            rp = OverlappedPipeline(rmodel, overlap=bool(args.overlap), rec_priority=args.rec_priority)
+            r = rate(Br, lambda: rp.submit(rc, rr, lmk_out=rl, mesh_out=rm), steps=5, warmup=2)
+            bb = ev_ms(lambda: rmodel.forward_crops_u8(rc), 3)
+            fl = lib.syn_resnet50_flops_per_face() * Br
+            r.update(backbone_ms=round(bb, 4), backbone_tflops=round(fl / (bb * 1e-3) / 1e12, 2),
+                     frac_of_fp32_mfma_peak=round(fl / (bb * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     what='BASELINE configs[4]: ResNet-50 120x120 B=512 -> 62 params -> 68 landmarks + 53215-vertex mesh + pose')
+            extra['resnet50_b512'] = r
+            del rmodel, rm
+        except Exception as e:                                  # an extra must never cost the headline line
+            extra['resnet50_b512'] = dict(error=str(e)[:200])
+
     if rank == 0:
         faces = B * world * args.steps
-        out = dict(metric='faces/sec (120x120, 68-lmk + 53215-vert)', value=round(faces / el, 1), unit='faces/s',
+        if args.lmk_only:
+            metric = 'faces/sec (120x120, 68-lmk only)'
+            what = 'MobileNetV2 120x120 uint8 crops -> 62 params -> 68 landmarks + pose, ROI affine, all on device (BASELINE configs[1])'
+        else:
+            metric = 'faces/sec (120x120, 68-lmk + 53215-vert)'
+            what = (('ResNet-50 (BASELINE configs[4])' if args.arch == 'resnet50' else 'MobileNetV2') +
+                    ' 120x120 uint8 crops -> 62 params -> 68 landmarks + 53215-vertex mesh + pose, ROI affine, all on device' +
+                    ('' if args.arch == 'resnet50' else ' (BASELINE configs[2]/[3])'))
+        out = dict(metric=metric, value=round(faces / el, 1), unit='faces/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 4),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=('ResNet-50 (BASELINE configs[4])' if args.arch == 'resnet50' else 'MobileNetV2') +
-                                        ' 120x120 uint8 crops -> 62 params -> 68 landmarks + 53215-vertex mesh '
-                                        '+ pose, ROI affine, all on device' + ('' if args.arch == 'resnet50' else ' (BASELINE configs[2]/[3])'),
+                   config=dict(workload=what,
                                faces_per_gpu_per_step=B, global_batch=B * world, parallelism=f'face-shard x{world}',
                                collectives='one RCCL broadcast of packed constants at init, none in the timed region',
-                               streams=('2: reconstruction of batch i beside the backbone of batch i+1' if args.overlap else '1')),
+                               streams=('2: reconstruction of batch i beside the backbone of batch i+1' if args.overlap else '1'),
+                               ingest='uint8 NHWC crops resident in HBM (what cv2.resize hands over, synergy3DMM.py:188); the fp32 NCHW '
+                                      'forward_test ingest is timed in extra.fp32_ingest_*',
+                               mesh_layout=None if args.lmk_only else 'row-pitched [B,3,53248][:, :, :53215] view written in place (same shape / values '
+                                           'as the reference tensor, rows 128-byte aligned; the in-repo renderer consumes it without a '
+                                           'packed copy); the packed [B,3,53215] layout is timed in extra.packed_output'),
                    roofline=roof)
+        if dist_info:
+            out['distributed'] = dist_info
+        if extra:
+            out['extra'] = extra
         if not args.no_cpu_baseline and world == 1 and args.arch == 'mobilenet_v2':
             out['cpu_baseline'] = cpu_baseline(sd, pack)
         sys.stdout.flush()

@@ -92,6 +92,17 @@ size_t syn_constants_bytes(syn_handle *h);
 int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream);
 int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void *stream);
 
+/* Device-free twins of the hand-off: neither makes a HIP call, so a loader process (or a test) without a GPU can produce and
+ * vet the blob.  syn_pack_constants_host writes, from HOST arrays (same meaning as syn_load_backbone / _resnet50 / syn_load_basis;
+ * backbone_flat or the whole basis group may be NULL), exactly the bytes syn_export_constants produces after the same loads;
+ * arch 0 = mobilenet_v2, 1 = resnet50.  syn_check_constants_host applies syn_import_constants' acceptance checks (magic, version,
+ * sizes vs this library's network tables, payload within the buffer) to a host copy of a blob. */
+size_t syn_pack_constants_host_bytes(int arch, int have_backbone, int n_vert, int n_lmk);
+int syn_pack_constants_host(int arch, const float *backbone_flat, size_t n_floats, const float *w_shp, const float *w_exp,
+                            const float *u, const float *param_mean, const float *param_std, const int64_t *keypoints,
+                            int n_lmk, int n_vert, void *host_dst, size_t bytes);
+int syn_check_constants_host(const void *host_blob, size_t bytes);
+
 /* ---- compute ------------------------------------------------------------------------ */
 
 /* Bytes of activation workspace the library keeps for a batch of B faces. */
@@ -146,7 +157,9 @@ int syn_load_triangles(syn_handle *h, const int32_t *tri, int ntri, int nver);
 
 /* Sim3DR.get_normal (Sim3DR/Sim3DR.py:8-11 -> lib/rasterize_kernel.cpp:158-215) and, when light != NULL, the vertex
  * colours of RenderPipeline.__call__ (Sim3DR/lighting.py:37-64) for F meshes in one launch chain.
- * vertices: device, planar = 1 -> [F,3,nver] (what syn_reconstruct writes), 0 -> [F,nver,3] (the reference's layout);
+ * vertices: device, planar = 1 -> [F,3,nver] (what syn_reconstruct writes), 0 -> [F,nver,3] (the reference's layout),
+ *           planar = p >= nver (p > 1) -> [F,3,p][:, :, :nver], rows p floats apart: the pitched tensor syn_reconstruct_pitched
+ *           writes, consumed in place (no packed copy anywhere between reconstruction and rendering);
  * normal, light: device [F,nver,3] (light may be NULL);
  * cfg16: HOST pointer to 16 floats: intensity_ambient, color_ambient[3], intensity_directional, color_directional[3],
  *        intensity_specular, specular_exp, light_pos[3], view_pos[3] (lighting.py:24-32). */
@@ -171,15 +184,17 @@ int syn_add_weighted(syn_handle *h, const uint8_t *a, float alpha, const uint8_t
  * running_var;  then loc.i, conf.i (i = 0..2): weight | bias.  Host pointer. */
 size_t syn_detector_flat_count(void);
 int syn_load_detector(syn_handle *h, const float *flat, size_t count);
-/* number of priors for a frame (FaceBoxes/utils/prior_box.py:20) after the optional down-scaling */
-int syn_detector_prior_count(int H, int W, float scale);
+/* number of priors for a network input of Hs x Ws pixels (FaceBoxes/utils/prior_box.py:20) */
+int syn_detector_prior_count(int Hs, int Ws);
 /* FaceBoxes.__call__ (FaceBoxes/FaceBoxes.py:60-127) on one uint8 BGR frame [H,W,3] (device): optional bilinear down-scaling
- * by `scale` (the caller computes it like :63-70; 1 = none), mean subtraction, network, priors, decoding, score > conf_thr,
- * top_k by score, NMS (cpu_nms.pyx semantics, IoU >= nms_thr suppresses), first keep_top_k rows.
+ * to Hs x Ws = int(scale*H) x int(scale*W), which the CALLER evaluates in double precision exactly like :63-75 (a float32
+ * product lands one pixel off on ~8 % of frame sizes); Hs = H, Ws = W, scale = 1 for no scaling.  Then mean subtraction,
+ * network, priors, decoding (boxes * (Ws,Hs,Ws,Hs) / scale, :101-104), score > conf_thr, top_k by score (any number of
+ * candidates; top_k <= 8192), NMS (cpu_nms.pyx semantics, IoU >= nms_thr suppresses), first keep_top_k rows.
  * dets: device [keep_top_k,5] (x1, y1, x2, y2, score) in original-frame pixels, score-descending; n_dets: HOST int, rows
  * valid (the call synchronises `stream`).  The vis_thres filter (:133-140) is the caller's. */
-int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k,
-               int keep_top_k, float *dets, int *n_dets, void *stream);
+int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, int Hs, int Ws, float scale, float conf_thr, float nms_thr,
+               int top_k, int keep_top_k, float *dets, int *n_dets, void *stream);
 
 /* calc_nme (benchmark_aflw2000.py:107-139): fit [N,2,68] fitted landmarks in 120x120 crop coordinates, gt [N,3,68] ground truth
  * in image coordinates, roi [N,4] crop boxes (sx, sy, ex, ey) -> nme [N] float32.  All device pointers. */
@@ -190,6 +205,11 @@ int syn_nme(syn_handle *h, const float *fit, const float *gt, const float *roi, 
  * floats), t3d [B,3] fp32 with the ROI affine on x,y; roi may be NULL. */
 int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles,
              float *t3d, void *stream);
+
+/* predict_pose(..., ret_mat=True) (utils/inference.py:146-157): parse_pose's P = [R | t3d] "without scale" (:86-92),
+ * pmat [B,3,4] fp32 row-major; R = normalised rows 0,1 of the de-whitened camera matrix and their cross product, column 3 =
+ * the de-whitened translation WITHOUT the ROI affine (the reference concatenates P before predict_pose rescales t3d). */
+int syn_pose_matrix(syn_handle *h, const float *param, int B, float *pmat, void *stream);
 
 /* ---- introspection (bench / profiling) --------------------------------------------- */
 

@@ -137,9 +137,9 @@ def resize_linear_u8(img, out_h, out_w):
 
     def taps(n_dst, n_src):
         scale = n_src / n_dst
-        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5
-        s = np.floor(f).astype(np.int64)
-        f = (f - s).astype(np.float32)
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)     # fx = (float)((dx+0.5)*scale_x - 0.5)
+        s = np.floor(f).astype(np.int64)                                                      # sx = cvFloor(fx)
+        f = f - s.astype(np.float32)                                                          # fx -= sx
         lo = s < 0
         f[lo] = 0.0; s[lo] = 0
         hi = s >= n_src - 1

@@ -120,6 +120,16 @@ def predict_pose(b: Basis, param, roi_bbox):
     return pose, t3d
 
 
+def pose_matrix(b: Basis, param):
+    """reference utils/inference.py:86-92 + :155-156: predict_pose(..., ret_mat=True) returns parse_pose's
+    P = concatenate(R, t3d) -- a copy made BEFORE predict_pose applies the ROI affine to t3d, so the translation column is
+    the de-whitened one."""
+    param = param * b.param_std[:62] + b.param_mean[:62]
+    Ps = param[:12].reshape(3, -1)
+    _, R, t3d = P2sRt(Ps)
+    return np.concatenate((R, t3d.reshape(3, -1)), axis=1)
+
+
 def reconstruct_vertex_62(b: Basis, param, dense=False, transform=True):
     """reference synergy3DMM.py:116-149 (batched; [B,62] -> [B,3,68|N]); no ROI affine.
 

@@ -39,15 +39,18 @@ _SIGS = {
     'syn_constants_bytes': (C.c_size_t, [C.c_void_p]),
     'syn_export_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'syn_import_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'syn_pack_constants_host_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'syn_pack_constants_host': (C.c_int, [C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    'syn_check_constants_host': (C.c_int, [C.c_void_p, C.c_size_t]),
     'syn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'syn_backbone_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_backbone_forward_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_crop_resize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
     'syn_detector_flat_count': (C.c_size_t, []),
     'syn_load_detector': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
-    'syn_detector_prior_count': (C.c_int, [C.c_int, C.c_int, C.c_float]),
-    'syn_detect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
-                             C.POINTER(C.c_int), C.c_void_p]),
+    'syn_detector_prior_count': (C.c_int, [C.c_int, C.c_int]),
+    'syn_detect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                             C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     'syn_nme': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'syn_load_triangles': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'syn_mesh_shade': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -56,6 +59,7 @@ _SIGS = {
     'syn_reconstruct': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_reconstruct_pitched': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'syn_pose': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'syn_pose_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'syn_backbone_launch_count': (C.c_int, [C.c_void_p]),
     'syn_backbone_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_backbone_flops_per_face': (C.c_double, []),
@@ -66,7 +70,7 @@ EXPORTED_SYMBOLS = tuple(_SIGS)          # exactly the symbols include/synergy_h
 # test hook exported by the library but deliberately not part of the public header
 _SIGS = dict(_SIGS, syn_debug_feature=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
              syn_debug_profile_block=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-             syn_debug_detect_raw=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5),
+             syn_debug_detect_raw=(C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5),
              syn_debug_poison_workspace=(C.c_int, [C.c_void_p, C.c_int, C.c_int]))
 
 

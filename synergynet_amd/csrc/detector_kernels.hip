@@ -29,9 +29,9 @@ __global__ __launch_bounds__(256) void det_preproc_kernel(const unsigned char *_
     }
     auto taps = [](int d, int n_dst, int n_src, int &s0, int &s1, int &c0, int &c1) {
         const double scale = (double)n_src / n_dst;
-        double fd = ((double)d + 0.5) * scale - 0.5;
-        long s = (long)floor(fd);
-        float f = (float)(fd - (double)s);
+        const float fd = (float)(((double)d + 0.5) * scale - 0.5);      // fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx
+        long s = (long)floorf(fd);
+        float f = fd - (float)s;
         if (s < 0) { f = 0.f; s = 0; }
         if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
         c1 = (int)rintf(f * 2048.0f);
@@ -161,29 +161,77 @@ __global__ __launch_bounds__(256) void det_decode_kernel(const float *__restrict
 }
 
 // ---- sort by score (descending; equal scores: lower prior index first) + greedy NMS, one workgroup (FaceBoxes.py:114-127) ----
-// keys: [score bits : 32 | ~prior index : 32] sorted descending with an in-LDS bitonic network over kSortN slots.
+// keys: [score bits : 32 | ~prior index : 32] sorted descending with an in-LDS bitonic network over kSortN slots.  The reference
+// sorts ALL candidates and keeps the first top_k (FaceBoxes.py:115); when more candidates than the network holds pass the
+// threshold, the top_k largest keys are first selected exactly (8-bit radix select on the unique 64-bit keys, most significant
+// digit first) and only those enter the network -- the same set in the same order as sorting everything.
 constexpr int kSortN = 8192;
 __global__ __launch_bounds__(1024) void det_nms_kernel(const float *__restrict__ cand, const int *__restrict__ n_cand, int max_cand, int top_k,
                                                        float nms_thr, int keep_top_k, float *__restrict__ dets /*[keep_top_k,5]*/,
                                                        int *__restrict__ n_out) {
     __shared__ unsigned long long key[kSortN];
-    __shared__ unsigned short slot[kSortN];            // candidate slot of each key
+    __shared__ unsigned slot[kSortN];                  // candidate slot of each key
     __shared__ unsigned char dead[kSortN];
-    __shared__ int n_keep;
-    int n = *n_cand;
-    n = n < max_cand ? n : max_cand;
-    n = n < kSortN ? n : kSortN;
+    __shared__ int n_keep, n_sel;
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel_prefix;
+    __shared__ int sel_want;
+    int n_all = *n_cand;
+    n_all = n_all < max_cand ? n_all : max_cand;
     const int tid = threadIdx.x;
+    auto key_of = [&](int i) {
+        const unsigned sb = __builtin_bit_cast(unsigned, cand[(size_t)i * 6 + 4]);       // scores are positive: bit order = value order
+        const unsigned idx = __builtin_bit_cast(unsigned, cand[(size_t)i * 6 + 5]);
+        return ((unsigned long long)sb << 32) | (unsigned long long)(~idx);
+    };
+    int n = n_all;
+    if (n_all > kSortN) {
+        // threshold key T = the K-th largest key, K = min(top_k, kSortN) (host guarantees top_k <= kSortN)
+        const int K = top_k < kSortN ? top_k : kSortN;
+        if (tid == 0) { sel_prefix = 0ull; sel_want = K; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long pre = sel_prefix;
+            const unsigned long long mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+            for (int i = tid; i < n_all; i += 1024) {
+                const unsigned long long k = key_of(i);
+                if ((k & mask) == pre) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int want = sel_want, d = 255;
+                for (; d > 0; --d) {                   // digits from the top: skip whole bins while they fit
+                    if ((int)hist[d] >= want) break;
+                    want -= (int)hist[d];
+                }
+                sel_prefix = pre | ((unsigned long long)d << shift);
+                sel_want = want;
+            }
+            __syncthreads();
+        }
+        const unsigned long long T = sel_prefix;       // exactly K keys are >= T (keys are unique)
+        if (tid == 0) n_sel = 0;
+        for (int i = tid; i < kSortN; i += 1024) { key[i] = 0ull; slot[i] = 0; dead[i] = 0; }
+        __syncthreads();
+        for (int i = tid; i < n_all; i += 1024) {
+            const unsigned long long k = key_of(i);
+            if (k >= T) {
+                const int q = atomicAdd(&n_sel, 1);
+                if (q < kSortN) { key[q] = k; slot[q] = (unsigned)i; }
+            }
+        }
+        __syncthreads();
+        n = n_sel < kSortN ? n_sel : kSortN;
+    }
     int sn = 1024;                                     // sort network size: next power of two >= n (>= one element per thread)
     while (sn < n) sn <<= 1;
-    for (int i = tid; i < sn; i += 1024) {
-        unsigned long long k = 0ull;
-        if (i < n) {
-            const unsigned sb = __builtin_bit_cast(unsigned, cand[(size_t)i * 6 + 4]);       // scores are positive: bit order = value order
-            const unsigned idx = __builtin_bit_cast(unsigned, cand[(size_t)i * 6 + 5]);
-            k = ((unsigned long long)sb << 32) | (unsigned long long)(~idx);
+    if (n_all <= kSortN) {
+        for (int i = tid; i < sn; i += 1024) {
+            key[i] = i < n ? key_of(i) : 0ull;
+            slot[i] = (unsigned)i; dead[i] = 0;
         }
-        key[i] = k; slot[i] = (unsigned short)i; dead[i] = 0;
     }
     if (tid == 0) n_keep = 0;
     __syncthreads();
@@ -196,7 +244,7 @@ __global__ __launch_bounds__(1024) void det_nms_kernel(const float *__restrict__
                     const unsigned long long a = key[i], b = key[l];
                     if (desc ? (a < b) : (a > b)) {
                         key[i] = b; key[l] = a;
-                        const unsigned short s = slot[i]; slot[i] = slot[l]; slot[l] = s;
+                        const unsigned s = slot[i]; slot[i] = slot[l]; slot[l] = s;
                     }
                 }
             }

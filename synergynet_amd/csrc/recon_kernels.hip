@@ -529,7 +529,8 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ param, const float *__restrict__ mean,
                                                   const float *__restrict__ stdv, const float *__restrict__ roi,
-                                                  double *__restrict__ angles, float *__restrict__ t3d, int B) {
+                                                  double *__restrict__ angles, float *__restrict__ t3d,
+                                                  float *__restrict__ pmat /*nullable [B,3,4]*/, int B) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     float p[12];
@@ -553,6 +554,13 @@ __global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ para
         if (r3[0] == -1.0f) { x = PI / 2; y = z + atan2((double)r1[1], (double)r1[2]); }
         else                { x = -PI / 2; y = -z + atan2(-(double)r1[1], -(double)r1[2]); }
     }
+    if (pmat) {           // parse_pose's P = [R | t3d] "without scale" (:90), built BEFORE predict_pose's ROI affine touches t3d
+        float *m = pmat + (size_t)b * 12;
+        m[0] = r1[0]; m[1] = r1[1]; m[2] = r1[2]; m[3] = p[3];
+        m[4] = r2[0]; m[5] = r2[1]; m[6] = r2[2]; m[7] = p[7];
+        m[8] = r3[0]; m[9] = r3[1]; m[10] = r3[2]; m[11] = p[11];
+    }
+    if (!angles) return;
     angles[(size_t)b * 3 + 0] = x * 180.0 / PI;
     angles[(size_t)b * 3 + 1] = y * 180.0 / PI;
     angles[(size_t)b * 3 + 2] = z * 180.0 / PI;
@@ -568,8 +576,8 @@ __global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ para
 }
 
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi, double *angles,
-                 float *t3d, int B, hipStream_t s) {
-    pose_kernel<<<(B + 63) / 64, 64, 0, s>>>(param, mean62, std62, roi, angles, t3d, B);
+                 float *t3d, float *pmat, int B, hipStream_t s) {
+    pose_kernel<<<(B + 63) / 64, 64, 0, s>>>(param, mean62, std62, roi, angles, t3d, pmat, B);
 }
 
 }  // namespace syn

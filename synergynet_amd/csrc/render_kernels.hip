@@ -22,8 +22,12 @@
 namespace syn {
 
 namespace {
+// `planar`: 0 -> [nver,3] interleaved (the reference's layout); >= nver -> planar rows `planar` floats apart ([3,pitch][:, :nver],
+// what syn_reconstruct_pitched writes; pitch == nver is the packed [3,nver]).  The launchers map the ABI's planar = 1 to nver.
 __device__ __forceinline__ float vtx(const float *v, int planar, int nver, int i, int c) {
-    return planar ? v[(size_t)c * nver + i] : v[(size_t)i * 3 + c];
+    return planar ? v[(size_t)c * planar + i] : v[(size_t)i * 3 + c];
+}
+__device__ __forceinline__ size_t face_stride(int planar, int nver) { return planar ? (size_t)3 * planar : (size_t)3 * nver;
 }
 }  // namespace
 
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void tri_normal_kernel(const float *__restrict
                                                          float *__restrict__ tri_normal, int nver, int ntri, int planar) {
     const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (i >= ntri) return;
-    const float *v = vertices + (size_t)f * nver * 3;
+    const float *v = vertices + (size_t)f * face_stride(planar, nver);
     const int p0 = tri[3 * i], p1 = tri[3 * i + 1], p2 = tri[3 * i + 2];
     const float v1x = vtx(v, planar, nver, p1, 0) - vtx(v, planar, nver, p0, 0);
     const float v1y = vtx(v, planar, nver, p1, 1) - vtx(v, planar, nver, p0, 1);
@@ -70,7 +74,7 @@ constexpr int kMinMaxBlocks = 8;
 __global__ __launch_bounds__(1024) void minmax_kernel(const float *__restrict__ vertices, unsigned *__restrict__ mm, int nver, int planar) {
     __shared__ unsigned red[16][6];
     const int f = blockIdx.y;
-    const float *v = vertices + (size_t)f * nver * 3;
+    const float *v = vertices + (size_t)f * face_stride(planar, nver);
     auto key = [](float a) { const unsigned u = __builtin_bit_cast(unsigned, a); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     unsigned k[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     for (int i = blockIdx.x * 1024 + threadIdx.x; i < nver; i += kMinMaxBlocks * 1024)
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void lighting_kernel(const float *__restrict__
     if (i >= nver) return;
     auto unkey = [](unsigned k) { const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; return __builtin_bit_cast(float, u); };
     const unsigned *m = mm + f * 6;
-    const float *v = vertices + (size_t)f * nver * 3;
+    const float *v = vertices + (size_t)f * face_stride(planar, nver);
     // norm_vertices: v -= min(0); v /= v.max(); v *= 2; v -= v.max(0) / 2   (all monotone: the extrema map to the extrema)
     float mn[3], mx[3], vn[3];
     for (int c = 0; c < 3; ++c) { mn[c] = unkey(m[c]); mx[c] = unkey(m[3 + c]) - mn[c]; }
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void raster_depth_kernel(const float *__restri
                                                            int w, int planar) {
     const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (i >= ntri) return;
-    const float *v = vertices + (size_t)f * nver * 3;
+    const float *v = vertices + (size_t)f * face_stride(planar, nver);
     const int t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
     const float p0x = vtx(v, planar, nver, t0, 0), p0y = vtx(v, planar, nver, t0, 1), d0 = vtx(v, planar, nver, t0, 2);
     const float p1x = vtx(v, planar, nver, t1, 0), p1y = vtx(v, planar, nver, t1, 1), d1 = vtx(v, planar, nver, t1, 2);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(const float *__restri
     // (memory fault on tri[3*i]); an opaque copy keeps the masked value
     asm volatile("" : "+v"(i));
     const int y = px / w, x = px % w;
-    const float *v = vertices + (size_t)f * nver * 3;
+    const float *v = vertices + (size_t)f * face_stride(planar, nver);
     const float *col = colors + (size_t)f * nver * c;
     const int t0 = tri[3 * i], t1 = tri[3 * i + 1], t2 = tri[3 * i + 2];
     const Bary b = bary((float)x, (float)y, vtx(v, planar, nver, t0, 0), vtx(v, planar, nver, t0, 1), vtx(v, planar, nver, t1, 0),

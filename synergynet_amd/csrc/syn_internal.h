@@ -138,6 +138,6 @@ void launch_det_nms(const float *cand, const int *n_cand, int max_cand, int top_
 int det_sort_capacity();
 
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
-                 double *angles, float *t3d, int B, hipStream_t s);
+                 double *angles /*nullable together with t3d*/, float *t3d, float *pmat /*nullable [B,3,4]*/, int B, hipStream_t s);
 
 }  // namespace syn

@@ -236,8 +236,10 @@ struct syn_handle {
     float *d_basis = nullptr;      // dense tiles | landmark tiles | mean[64] | std[64]
     size_t basis_floats = 0;
     int n_vert = 0, n_lmk = 0, nvp = 0, nlp = 0;
-    float *ws = nullptr;
+    float *ws = nullptr;           // backbone activations (used on the stream of syn_backbone_forward*)
     size_t ws_bytes = 0;
+    float *rec = nullptr;          // reconstruction records (used on the stream of syn_reconstruct*): an allocation of its
+    size_t rec_bytes = 0;          // own, so that a backbone call of ANY batch size never overlaps records still in flight
     // mesh topology + render scratch (syn_load_triangles / syn_mesh_* / syn_rasterize)
     int *d_tri = nullptr, *d_adj_off = nullptr, *d_adj_tri = nullptr;
     int ntri = 0, tri_nver = 0;
@@ -265,16 +267,26 @@ const unsigned *basis3_lmk(const syn_handle *h) { return basis3_dense(h) + (size
 
 size_t ws_floats_per_face() {
     const size_t mb = 2 * net().max_io + 2 * net().max_hidden, rn = 4 * resnet50().buf_big + 2 * resnet50().buf_mid;
-    return (mb > rn ? mb : rn) + syn::kRecFloatsPerFace;   // one workspace serves either backbone; the tail = reconstruction records
+    return mb > rn ? mb : rn;      // one activation workspace serves either backbone
 }
 size_t backbone_floats(int arch) { return arch == 1 ? resnet50().packed_count : net().packed_count; }
 
+// Both scratch regions only ever grow; growing synchronises the whole device first, so work in flight on another stream
+// (synergynet_amd/streams.py runs the reconstruction of batch i beside the backbone of batch i+1) never loses its buffer.
 int ensure_ws(syn_handle *h, int B) {
-    const size_t need = ((size_t)B * ws_floats_per_face() + syn::kRecSlack) * sizeof(float);
+    const size_t need = ((size_t)B * ws_floats_per_face() + 1024) * sizeof(float);
     if (need <= h->ws_bytes) return SYN_OK;
     if (h->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->ws)); h->ws = nullptr; h->ws_bytes = 0; }
     HIP_TRY(hipMalloc((void **)&h->ws, need));
     h->ws_bytes = need;
+    return SYN_OK;
+}
+int ensure_rec(syn_handle *h, int B) {
+    const size_t need = ((size_t)B * syn::kRecFloatsPerFace + syn::kRecSlack) * sizeof(float);
+    if (need <= h->rec_bytes) return SYN_OK;
+    if (h->rec) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->rec)); h->rec = nullptr; h->rec_bytes = 0; }
+    HIP_TRY(hipMalloc((void **)&h->rec, need));
+    h->rec_bytes = need;
     return SYN_OK;
 }
 
@@ -507,6 +519,7 @@ int syn_destroy(syn_handle *h) {
     if (h->d_backbone) (void)hipFree(h->d_backbone);
     if (h->d_basis) (void)hipFree(h->d_basis);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->rec) (void)hipFree(h->rec);
     if (h->d_tri) (void)hipFree(h->d_tri);
     if (h->d_adj_off) (void)hipFree(h->d_adj_off);
     if (h->d_adj_tri) (void)hipFree(h->d_adj_tri);
@@ -522,12 +535,11 @@ double syn_backbone_flops_per_face(void) { return net().flops; }
 double syn_pointwise_flops_per_face(void) { return net().pw_flops; }
 int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 1; }
 
-int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
-    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone: NULL argument");
+// Host-only packing of the MobileNetV2 state (BN folding, MFMA lane order, bf16 x3 split): shared by syn_load_backbone and
+// syn_pack_constants_host, so a blob packed without a device is byte-identical to what a handle exports.
+static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
     const Net &n = net();
-    if (n_floats != n.flat_count)
-        return fail(SYN_ERR_INVALID, "syn_load_backbone: got %zu floats, the MobileNetV2 backbone has %zu", n_floats, n.flat_count);
-    std::vector<float> pk(n.packed_count, 0.f);
+    pk.assign(n.packed_count, 0.f);
     for (const Layer &L : n.layers) {
         const float *w = flat + L.src_w;
         size_t wn = L.kind == STEM ? 32 * 27 : L.kind == DW ? (size_t)L.cout * 9 : (size_t)L.cout * L.cin;
@@ -673,6 +685,15 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
             row += hn[k];
         }
     }
+}
+
+int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
+    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone: NULL argument");
+    const Net &n = net();
+    if (n_floats != n.flat_count)
+        return fail(SYN_ERR_INVALID, "syn_load_backbone: got %zu floats, the MobileNetV2 backbone has %zu", n_floats, n.flat_count);
+    std::vector<float> pk;
+    pack_backbone_mbv2(flat, pk);
     DeviceGuard g(h->device);
     if (h->d_backbone && h->arch != 0) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
     if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
@@ -684,12 +705,9 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
 size_t syn_resnet50_flat_count(void) { return resnet50().flat_count; }
 double syn_resnet50_flops_per_face(void) { return resnet50().flops; }
 
-int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats) {
-    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: NULL argument");
+static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
     const ResNet50 &n = resnet50();
-    if (n_floats != n.flat_count)
-        return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: got %zu floats, ResNet-50 has %zu", n_floats, n.flat_count);
-    std::vector<float> pk(n.packed_count, 0.f);
+    pk.assign(n.packed_count, 0.f);
     for (const RConv &c : n.convs) {
         const float *w = flat + c.src_w;
         const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
@@ -746,12 +764,37 @@ int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats
             src += hn[k];
         }
     }
+}
+
+int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats) {
+    if (!h || !flat) return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: NULL argument");
+    const ResNet50 &n = resnet50();
+    if (n_floats != n.flat_count)
+        return fail(SYN_ERR_INVALID, "syn_load_backbone_resnet50: got %zu floats, ResNet-50 has %zu", n_floats, n.flat_count);
+    std::vector<float> pk;
+    pack_backbone_resnet50(flat, pk);
     DeviceGuard g(h->device);
     if (h->d_backbone) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
     HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
     h->arch = 1;
     return SYN_OK;
+}
+
+static void pack_basis(const float *w_shp, const float *w_exp, const float *u, const float *param_mean, const float *param_std,
+                       const int64_t *keypoints, int n_lmk, int n_vert, std::vector<float> &pk) {
+    const int nvp = round_up(n_vert, 32), nlp = round_up(n_lmk, 32);
+    const size_t total = basis_float_count(nvp, nlp);
+    pk.assign(total, 0.f);
+    pack_basis_tiles(pk.data(), n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
+    // landmark sub-basis: w_*_base = w_*[keypoints], u_base = u[keypoints] (utils/params.py:31-33)
+    pack_basis_tiles(pk.data() + (size_t)nvp * 3 * syn::kBasisK, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
+    float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
+    memcpy(ms, param_mean, sizeof(float) * 62);
+    memcpy(ms + 64, param_std, sizeof(float) * 62);
+    unsigned *b3 = reinterpret_cast<unsigned *>(ms + 128);
+    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
+    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
 }
 
 int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u, const float *param_mean,
@@ -764,22 +807,84 @@ int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const 
             return fail(SYN_ERR_INVALID, "syn_load_basis: keypoints[%d]=%lld out of range", i, (long long)keypoints[i]);
     const int nvp = round_up(n_vert, 32), nlp = round_up(n_lmk, 32);
     const size_t total = basis_float_count(nvp, nlp);
-    std::vector<float> pk(total, 0.f);
-    pack_basis_tiles(pk.data(), n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
-    // landmark sub-basis: w_*_base = w_*[keypoints], u_base = u[keypoints] (utils/params.py:31-33)
-    pack_basis_tiles(pk.data() + (size_t)nvp * 3 * syn::kBasisK, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
-    float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
-    memcpy(ms, param_mean, sizeof(float) * 62);
-    memcpy(ms + 64, param_std, sizeof(float) * 62);
-    unsigned *b3 = reinterpret_cast<unsigned *>(ms + 128);
-    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
-    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
+    std::vector<float> pk;
+    pack_basis(w_shp, w_exp, u, param_mean, param_std, keypoints, n_lmk, n_vert, pk);
     DeviceGuard g(h->device);
     if (h->d_basis && h->basis_floats != total) { HIP_TRY(hipFree(h->d_basis)); h->d_basis = nullptr; }
     if (!h->d_basis) HIP_TRY(hipMalloc((void **)&h->d_basis, total * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_basis, pk.data(), total * sizeof(float), hipMemcpyHostToDevice));
     h->basis_floats = total; h->n_vert = n_vert; h->n_lmk = n_lmk; h->nvp = nvp; h->nlp = nlp;
     return SYN_OK;
+}
+
+// Device-free twins of the constant hand-off: pack the blob syn_export_constants would produce straight from host
+// arrays, and run the checks syn_import_constants makes on a host copy of a blob.  No HIP call is made: usable on a machine
+// without a GPU (a loader process, or tests/test_dist_cpu.py's gloo ranks).
+size_t syn_pack_constants_host_bytes(int arch, int have_backbone, int n_vert, int n_lmk) {
+    if (arch < 0 || arch > 1) return 0;
+    size_t fl = have_backbone ? backbone_floats(arch) : 0;
+    if (n_vert > 0 && n_lmk > 0) fl += basis_float_count(round_up(n_vert, 32), round_up(n_lmk, 32));
+    return sizeof(ConstHeader) + fl * sizeof(float);
+}
+
+int syn_pack_constants_host(int arch, const float *backbone_flat, size_t n_floats, const float *w_shp, const float *w_exp, const float *u,
+                            const float *param_mean, const float *param_std, const int64_t *keypoints, int n_lmk, int n_vert,
+                            void *host_dst, size_t bytes) {
+    if (!host_dst) return fail(SYN_ERR_INVALID, "syn_pack_constants_host: NULL destination");
+    if (arch < 0 || arch > 1) return fail(SYN_ERR_INVALID, "syn_pack_constants_host: arch=%d", arch);
+    const bool has_bb = backbone_flat != nullptr, has_basis = w_shp != nullptr;
+    if (has_bb && n_floats != (arch == 1 ? resnet50().flat_count : net().flat_count))
+        return fail(SYN_ERR_INVALID, "syn_pack_constants_host: got %zu backbone floats", n_floats);
+    if (has_basis) {
+        if (!w_exp || !u || !param_mean || !param_std || !keypoints || n_vert <= 0 || n_lmk <= 0)
+            return fail(SYN_ERR_INVALID, "syn_pack_constants_host: incomplete basis arguments");
+        for (int i = 0; i < 3 * n_lmk; ++i)
+            if (keypoints[i] < 0 || keypoints[i] >= (int64_t)3 * n_vert)
+                return fail(SYN_ERR_INVALID, "syn_pack_constants_host: keypoints[%d]=%lld out of range", i, (long long)keypoints[i]);
+    }
+    const size_t need = syn_pack_constants_host_bytes(arch, has_bb, has_basis ? n_vert : 0, has_basis ? n_lmk : 0);
+    if (bytes < need) return fail(SYN_ERR_INVALID, "syn_pack_constants_host: buffer %zu < %zu bytes", bytes, need);
+    std::vector<float> bb, bs;
+    if (has_bb) { if (arch == 1) pack_backbone_resnet50(backbone_flat, bb); else pack_backbone_mbv2(backbone_flat, bb); }
+    if (has_basis) pack_basis(w_shp, w_exp, u, param_mean, param_std, keypoints, n_lmk, n_vert, bs);
+    ConstHeader hd{};
+    hd.magic = kMagic; hd.version = 1;
+    hd.has_backbone = has_bb; hd.has_basis = has_basis;
+    if (has_basis) { hd.n_vert = n_vert; hd.n_lmk = n_lmk; hd.nvp = round_up(n_vert, 32); hd.nlp = round_up(n_lmk, 32); }
+    hd.arch = has_bb ? arch : 0;
+    hd.backbone_floats = bb.size(); hd.basis_floats = bs.size();
+    hd.total_bytes = need;
+    char *d = (char *)host_dst;
+    memcpy(d, &hd, sizeof hd); d += sizeof hd;
+    if (has_bb) { memcpy(d, bb.data(), bb.size() * sizeof(float)); d += bb.size() * sizeof(float); }
+    if (has_basis) memcpy(d, bs.data(), bs.size() * sizeof(float));
+    return SYN_OK;
+}
+
+namespace {
+// the acceptance checks of a constants blob, on a host copy of its header; shared by the device import and the host twin
+int check_const_header(const ConstHeader &hd, size_t bytes, const char *who) {
+    if (hd.magic != kMagic || hd.version != 1) return fail(SYN_ERR_INVALID, "%s: bad magic/version", who);
+    if (hd.total_bytes > bytes) return fail(SYN_ERR_INVALID, "%s: header says %llu bytes, buffer has %zu", who,
+                                            (unsigned long long)hd.total_bytes, bytes);
+    if (hd.has_backbone && (hd.arch > 1 || hd.backbone_floats != backbone_floats((int)hd.arch)))
+        return fail(SYN_ERR_INVALID, "%s: backbone size mismatch", who);
+    if (hd.has_basis && (hd.nvp % 32 || hd.nlp % 32 || hd.n_vert == 0 || hd.n_lmk == 0 || hd.n_vert > hd.nvp || hd.n_lmk > hd.nlp ||
+                         hd.nvp - hd.n_vert >= 32 || hd.nlp - hd.n_lmk >= 32 || hd.basis_floats != basis_float_count(hd.nvp, hd.nlp)))
+        return fail(SYN_ERR_INVALID, "%s: basis size mismatch", who);
+    const uint64_t payload = sizeof(ConstHeader) + ((hd.has_backbone ? hd.backbone_floats : 0) + (hd.has_basis ? hd.basis_floats : 0)) * sizeof(float);
+    if (payload > bytes || payload > hd.total_bytes)
+        return fail(SYN_ERR_INVALID, "%s: header + payload = %llu bytes, buffer has %zu", who, (unsigned long long)payload, bytes);
+    return SYN_OK;
+}
+}  // namespace
+
+int syn_check_constants_host(const void *host_blob, size_t bytes) {
+    if (!host_blob) return fail(SYN_ERR_INVALID, "syn_check_constants_host: NULL argument");
+    if (bytes < sizeof(ConstHeader)) return fail(SYN_ERR_INVALID, "syn_check_constants_host: %zu bytes is smaller than the header", bytes);
+    ConstHeader hd;
+    memcpy(&hd, host_blob, sizeof hd);
+    return check_const_header(hd, bytes, "syn_check_constants_host");
 }
 
 size_t syn_constants_bytes(syn_handle *h) {
@@ -821,13 +926,7 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
     ConstHeader hd{};
     HIP_TRY(hipMemcpyAsync(&hd, dev_src, sizeof hd, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (hd.magic != kMagic || hd.version != 1) return fail(SYN_ERR_INVALID, "syn_import_constants: bad magic/version");
-    if (hd.total_bytes > bytes) return fail(SYN_ERR_INVALID, "syn_import_constants: header says %llu bytes, buffer has %zu",
-                                            (unsigned long long)hd.total_bytes, bytes);
-    if (hd.has_backbone && (hd.arch > 1 || hd.backbone_floats != backbone_floats((int)hd.arch)))
-        return fail(SYN_ERR_INVALID, "syn_import_constants: backbone size mismatch");
-    if (hd.has_basis && hd.basis_floats != basis_float_count(hd.nvp, hd.nlp))
-        return fail(SYN_ERR_INVALID, "syn_import_constants: basis size mismatch");
+    if (int rc = check_const_header(hd, bytes, "syn_import_constants")) return rc;
     const char *d = (const char *)dev_src + sizeof hd;
     if (hd.has_backbone) {
         if (h->d_backbone && h->arch != (int)hd.arch) { HIP_TRY(hipFree(h->d_backbone)); h->d_backbone = nullptr; }
@@ -847,7 +946,7 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
 
 size_t syn_workspace_bytes(syn_handle *, int B) {
     if (B <= 0) return 0;
-    return ((size_t)B * ws_floats_per_face() + syn::kRecSlack) * sizeof(float);
+    return ((size_t)B * (ws_floats_per_face() + syn::kRecFloatsPerFace) + 1024 + syn::kRecSlack) * sizeof(float);
 }
 
 int syn_backbone_forward(syn_handle *h, const float *img, int B, float *param, float *pool, void *stream) {
@@ -955,8 +1054,11 @@ int syn_debug_poison_workspace(syn_handle *h, int B, int byte) {
     DeviceGuard g(h->device);
     int rc = ensure_ws(h, B);
     if (rc) return rc;
+    rc = ensure_rec(h, B);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(h->ws, byte, h->ws_bytes));
+    HIP_TRY(hipMemset(h->rec, byte, h->rec_bytes));
     if (h->rws) HIP_TRY(hipMemset(h->rws, byte, h->rws_bytes));
     if (h->dws) HIP_TRY(hipMemset(h->dws, byte, h->dws_bytes));
     HIP_TRY(hipDeviceSynchronize());
@@ -982,9 +1084,9 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
     const int n = dense ? h->n_vert : h->n_lmk;
     if (row_pitch < n) return fail(SYN_ERR_INVALID, "syn_reconstruct: row_pitch=%d < %d columns", row_pitch, n);
     DeviceGuard g(h->device);
-    int rc = ensure_ws(h, B);
+    int rc = ensure_rec(h, B);
     if (rc) return rc;
-    float *rec = h->ws + (size_t)B * (ws_floats_per_face() - syn::kRecFloatsPerFace);
+    float *rec = h->rec;
     hipStream_t s = (hipStream_t)stream;
     if (h->fusion >= 2)
         syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
@@ -1047,6 +1149,8 @@ int syn_mesh_shade(syn_handle *h, const float *vertices, int F, int planar, cons
     if (F <= 0) return fail(SYN_ERR_INVALID, "syn_mesh_shade: F=%d", F);
     if (light && !cfg16) return fail(SYN_ERR_INVALID, "syn_mesh_shade: light requested without a lighting configuration");
     if (!h->d_tri) return fail(SYN_ERR_NOT_LOADED, "syn_mesh_shade: triangles not loaded");
+    if (planar < 0 || (planar > 1 && planar < h->tri_nver)) return fail(SYN_ERR_INVALID, "syn_mesh_shade: planar=%d (0, 1 or a row pitch >= %d)", planar, h->tri_nver);
+    if (planar == 1) planar = h->tri_nver;
     DeviceGuard g(h->device);
     const size_t tn = align256(sizeof(float) * 3 * (size_t)h->ntri * F), mmb = align256(sizeof(unsigned) * 6 * F + 64);
     int rc = ensure_rws(h, tn + mmb);
@@ -1070,6 +1174,8 @@ int syn_rasterize(syn_handle *h, const float *vertices, const float *colors, int
     if (F <= 0 || F > 254 || H <= 0 || W <= 0 || channels <= 0 || channels > 4)
         return fail(SYN_ERR_INVALID, "syn_rasterize: F=%d H=%d W=%d channels=%d", F, H, W, channels);
     if (!h->d_tri) return fail(SYN_ERR_NOT_LOADED, "syn_rasterize: triangles not loaded");
+    if (planar < 0 || (planar > 1 && planar < h->tri_nver)) return fail(SYN_ERR_INVALID, "syn_rasterize: planar=%d (0, 1 or a row pitch >= %d)", planar, h->tri_nver);
+    if (planar == 1) planar = h->tri_nver;
     DeviceGuard g(h->device);
     int rc = ensure_rws(h, sizeof(unsigned long long) * (size_t)H * W);
     if (rc) return rc;
@@ -1161,16 +1267,19 @@ int syn_load_detector(syn_handle *h, const float *flat, size_t count) {
 // Runs the detector on one uint8 BGR frame (device).  scale: 1 or the down-scaling factor FaceBoxes.__call__ computes
 // (FaceBoxes.py:63-80).  dets [keep_top_k,5] device, n_dets: HOST int (the call synchronises the stream to return it).
 // raw_loc / raw_conf / raw_boxes / raw_scores: optional device outputs of the network / decoder (tests).
-static int run_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k,
-                      int keep_top_k, float *dets, int *n_dets, float *raw_loc, float *raw_conf, float *raw_boxes,
+static int run_detect(syn_handle *h, const uint8_t *frame, int H, int W, int Hn, int Wn, float scale, float conf_thr, float nms_thr,
+                      int top_k, int keep_top_k, float *dets, int *n_dets, float *raw_loc, float *raw_conf, float *raw_boxes,
                       float *raw_scores, hipStream_t s) {
     const DetNet &n = detnet();
-    const int Hn = scale == 1.0f ? H : (int)(scale * H), Wn = scale == 1.0f ? W : (int)(scale * W);
     if (Hn < 1 || Wn < 1) return fail(SYN_ERR_INVALID, "syn_detect: scaled frame %dx%d", Hn, Wn);
     const int H1 = cdiv_i(Hn, 4), W1 = cdiv_i(Wn, 4), H2 = cdiv_i(H1, 2), W2 = cdiv_i(W1, 2), H3 = cdiv_i(H2, 2), W3 = cdiv_i(W2, 2);
     const int H4 = cdiv_i(H3, 2), W4 = cdiv_i(W3, 2), H5 = cdiv_i(H4, 2), W5 = cdiv_i(W4, 2), H6 = cdiv_i(H5, 2), W6 = cdiv_i(W5, 2);
     const int P = H4 * W4 * 21 + H5 * W5 + H6 * W6;
-    const int max_cand = syn::det_sort_capacity();
+    // every prior can be a candidate; when more than the in-LDS sorter holds pass the threshold, the NMS kernel first selects
+    // the top_k best of them exactly (radix select), which is all FaceBoxes.py:114-116 keeps
+    const int max_cand = P;
+    if (top_k > syn::det_sort_capacity())
+        return fail(SYN_ERR_INVALID, "syn_detect: top_k=%d exceeds the sorter's %d slots", top_k, syn::det_sort_capacity());
     // scratch carve (floats)
     size_t off = 0;
     auto carve = [&](size_t nfl) { const size_t o = off; off += (nfl + 63) & ~(size_t)63; return o; };
@@ -1230,37 +1339,35 @@ static int run_detect(syn_handle *h, const uint8_t *frame, int H, int W, float s
     HIP_TRY(hipMemcpyAsync(host_cnt, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
-    if (host_cnt[0] > max_cand)
-        return fail(SYN_ERR_INVALID, "syn_detect: %d priors pass the confidence threshold, more than the %d the sorter holds", host_cnt[0], max_cand);
     *n_dets = host_cnt[1];
     return SYN_OK;
 }
 
-int syn_detector_prior_count(int H, int W, float scale) {
-    const int Hn = scale == 1.0f ? H : (int)(scale * H), Wn = scale == 1.0f ? W : (int)(scale * W);
+int syn_detector_prior_count(int Hn, int Wn) {
     return cdiv_i(Hn, 32) * cdiv_i(Wn, 32) * 21 + cdiv_i(Hn, 64) * cdiv_i(Wn, 64) + cdiv_i(Hn, 128) * cdiv_i(Wn, 128);
 }
 
-int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float conf_thr, float nms_thr, int top_k, int keep_top_k,
-               float *dets, int *n_dets, void *stream) {
+int syn_detect(syn_handle *h, const uint8_t *frame, int H, int W, int Hs, int Ws, float scale, float conf_thr, float nms_thr, int top_k,
+               int keep_top_k, float *dets, int *n_dets, void *stream) {
     if (!h || !frame || !dets || !n_dets) return fail(SYN_ERR_INVALID, "syn_detect: NULL argument");
-    if (H <= 0 || W <= 0 || !(scale > 0.f) || scale > 1.f || top_k <= 0 || keep_top_k <= 0)
-        return fail(SYN_ERR_INVALID, "syn_detect: H=%d W=%d scale=%g top_k=%d keep_top_k=%d", H, W, (double)scale, top_k, keep_top_k);
+    if (H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || Hs > H || Ws > W || !(scale > 0.f) || scale > 1.f || top_k <= 0 || keep_top_k <= 0)
+        return fail(SYN_ERR_INVALID, "syn_detect: H=%d W=%d Hs=%d Ws=%d scale=%g top_k=%d keep_top_k=%d", H, W, Hs, Ws, (double)scale, top_k,
+                    keep_top_k);
     if (!h->d_det) return fail(SYN_ERR_NOT_LOADED, "syn_detect: detector weights not loaded");
     DeviceGuard g(h->device);
-    return run_detect(h, frame, H, W, scale, conf_thr, nms_thr, top_k, keep_top_k, dets, n_dets, nullptr, nullptr, nullptr, nullptr,
+    return run_detect(h, frame, H, W, Hs, Ws, scale, conf_thr, nms_thr, top_k, keep_top_k, dets, n_dets, nullptr, nullptr, nullptr, nullptr,
                       (hipStream_t)stream);
 }
 
 // Test hook, not part of include/synergy_hip.h: network outputs and decoded boxes / scores of every prior.
-int syn_debug_detect_raw(syn_handle *h, const uint8_t *frame, int H, int W, float scale, float *loc, float *conf, float *boxes,
+int syn_debug_detect_raw(syn_handle *h, const uint8_t *frame, int H, int W, int Hs, int Ws, float scale, float *loc, float *conf, float *boxes,
                          float *scores, void *stream) {
     if (!h || !frame || !h->d_det) return fail(SYN_ERR_INVALID, "syn_debug_detect_raw: bad argument");
     DeviceGuard g(h->device);
     float *dets = nullptr;
     HIP_TRY(hipMalloc((void **)&dets, 750 * 5 * sizeof(float)));
     int nd = 0;
-    int rc = run_detect(h, frame, H, W, scale, 0.05f, 0.3f, 5000, 750, dets, &nd, loc, conf, boxes, scores, (hipStream_t)stream);
+    int rc = run_detect(h, frame, H, W, Hs, Ws, scale, 0.05f, 0.3f, 5000, 750, dets, &nd, loc, conf, boxes, scores, (hipStream_t)stream);
     (void)hipFree(dets);
     return rc;
 }
@@ -1279,7 +1386,17 @@ int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double 
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_pose: B=%d", B);
     if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_pose: whitening statistics not loaded");
     DeviceGuard g(h->device);
-    syn::launch_pose(param, basis_mean(h), basis_std(h), roi, angles, t3d, B, (hipStream_t)stream);
+    syn::launch_pose(param, basis_mean(h), basis_std(h), roi, angles, t3d, nullptr, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
+int syn_pose_matrix(syn_handle *h, const float *param, int B, float *pmat, void *stream) {
+    if (!h || !param || !pmat) return fail(SYN_ERR_INVALID, "syn_pose_matrix: NULL argument");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_pose_matrix: B=%d", B);
+    if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_pose_matrix: whitening statistics not loaded");
+    DeviceGuard g(h->device);
+    syn::launch_pose(param, basis_mean(h), basis_std(h), nullptr, nullptr, nullptr, pmat, B, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
 }

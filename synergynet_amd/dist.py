@@ -40,3 +40,53 @@ def broadcast_constants(model, src: int = 0, group=None):
     if rank != src:
         model.import_constants(buf)
     return int(n.item())
+
+
+def pack_constants_host(pack=None, backbone_state=None, arch: str = 'mobilenet_v2', data_dir=None):
+    """The constants blob of `SynergyNet(...).export_constants()` built WITHOUT a device (syn_pack_constants_host): a uint8
+    numpy array [header 256 B | folded backbone | MFMA-ordered basis], byte-identical to the device export after the same
+    loads (tests/test_gpu_parity.py).  `pack` / `data_dir`: the 3DMM assets as for SynergyNet (None, None -> no basis);
+    `backbone_state`: plain state_dict of the backbone (None -> no backbone)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import abi
+    from .params import ParamsPack
+    from .synergy3DMM import flatten_backbone
+    lib = abi.lib()
+    a = {'mobilenet_v2': 0, 'resnet50': 1}[arch]
+    flat = None
+    if backbone_state is not None:
+        sd = {k: v for k, v in backbone_state.items() if not k.endswith('num_batches_tracked')}
+        flat = flatten_backbone(sd, '', arch)
+    n_vert = n_lmk = 0
+    arrs = [None] * 6
+    if pack is not None or data_dir is not None:
+        pp = ParamsPack(data_dir=data_dir, pack=pack)
+        f32 = lambda x: np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+        kp = np.ascontiguousarray(np.asarray(pp.keypoints), dtype=np.int64)
+        arrs = [f32(pp.w_shp), f32(pp.w_exp), f32(pp.u).reshape(-1), f32(pp.param_mean).reshape(-1), f32(pp.param_std).reshape(-1), kp]
+        if arrs[3].size < 62 or arrs[4].size < 62:
+            raise RuntimeError('param_mean/param_std shorter than 62')
+        n_vert, n_lmk = arrs[0].shape[0] // 3, kp.size // 3
+    n = int(lib.syn_pack_constants_host_bytes(a, int(flat is not None), n_vert, n_lmk))
+    out = np.empty(n, dtype=np.uint8)
+    ptr = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    abi.check(lib.syn_pack_constants_host(a, ptr(flat), 0 if flat is None else flat.size, *[ptr(x) for x in arrs], n_lmk, n_vert,
+                                          out.ctypes.data_as(C.c_void_p), n))
+    return out
+
+
+def check_constants_host(blob) -> dict:
+    """Vet a host copy of a constants blob exactly like syn_import_constants would (C side, syn_check_constants_host) and
+    return its parsed header (Python side, synergy3DMM.parse_constants_header); raises on a blob the import would refuse."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import abi
+    from .synergy3DMM import parse_constants_header
+    b = np.ascontiguousarray(np.asarray(blob, dtype=np.uint8))
+    abi.check(abi.lib().syn_check_constants_host(b.ctypes.data_as(C.c_void_p), b.size))
+    return parse_constants_header(b[:256].tobytes())

@@ -80,6 +80,14 @@ class FaceBoxes:
                 scale *= WIDTH / (w * scale)
         return scale
 
+    @staticmethod
+    def scaled_size(h, w, scale):
+        """FaceBoxes.py:71-75: the network input size, int() of a python-double product exactly like the reference (a float32
+        product differs by one pixel on ~8 % of frame sizes, which would move the resize taps and the prior grid)."""
+        if scale == 1:
+            return h, w
+        return int(scale * h), int(scale * w)
+
     def detect_all(self, img_):
         """Rows before the vis_thres filter: float32 [n,5] (x1, y1, x2, y2, score), score-descending.  img_: uint8 [H,W,3] BGR,
         numpy array or device tensor."""
@@ -89,11 +97,12 @@ class FaceBoxes:
         frame = frame.to(self.device).contiguous()
         h, w = int(frame.shape[0]), int(frame.shape[1])
         scale = self.frame_scale(h, w)
+        h_s, w_s = self.scaled_size(h, w, scale)
         n = C.c_int(0)
         with torch.cuda.device(self.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            abi.check(self._lib.syn_detect(self._h, frame.data_ptr(), h, w, float(scale), confidence_threshold, nms_threshold, top_k,
-                                           keep_top_k, self._dets.data_ptr(), C.byref(n), stream))
+            abi.check(self._lib.syn_detect(self._h, frame.data_ptr(), h, w, h_s, w_s, float(scale), confidence_threshold, nms_threshold,
+                                           top_k, keep_top_k, self._dets.data_ptr(), C.byref(n), stream))
         return self._dets[:n.value].cpu().numpy()
 
     def __call__(self, img_):

@@ -1,12 +1,13 @@
 """Host-side pre-processing of get_all_outputs (reference synergy3DMM.py:177-192) and the
 module-level helper names of the reference's utils/inference.py.
 
-`crop_img` restates reference utils/inference.py:95-125.  `resize_lanczos4` stands in for
-`cv2.resize(img, (120,120), interpolation=cv2.INTER_LANCZOS4)` (synergy3DMM.py:188): OpenCV is
-not installed in this environment and is an un-vendored, unpinned dependency of the reference
-(SURVEY 8c), so this restates OpenCV's published 8-tap Lanczos resampler (fixed-point 8-bit
-path: 11-bit coefficients, replicated borders) from its algorithm description.  PARITY OF THIS
-FUNCTION WITH cv2 IS UNPINNED (no cv2 here to compare against); it is outside the GPU hot path.
+The crop (`crop_img`, utils/inference.py:95-125) and the resize (`cv2.resize(img, (120,120),
+interpolation=cv2.INTER_LANCZOS4)`, synergy3DMM.py:188) run on the device (`syn_crop_resize`,
+csrc/preproc_kernels.hip); the host only supplies the per-box tap tables.  `lanczos4_tables` follows
+OpenCV's published 8-tap Lanczos resampler (fixed-point 8-bit path: 11-bit coefficients) from its
+algorithm description: OpenCV is not installed in this environment and is an un-vendored, unpinned
+dependency of the reference, so PARITY OF THESE TABLES WITH cv2 IS UNPINNED.  The host
+checker of the device kernel (whole-image crop + resize in numpy) lives in oracle/preproc_numpy.py.
 
 The vertex / pose helpers keep the reference names (`predict_sparseVert`, `predict_denseVert`,
 `predict_pose`) and dispatch to the HIP kernels through the most recently constructed model.
@@ -29,57 +30,35 @@ def _model():
     return _default_model
 
 
-def crop_img(img, roi_box):
-    """reference utils/inference.py:95-125: integer-rounded box, zero padding outside the image."""
-    h, w = img.shape[:2]
-    sx, sy, ex, ey, _ = [int(round(_)) for _ in roi_box]
-    dh, dw = ey - sy, ex - sx
-    if len(img.shape) == 3:
-        res = np.zeros((dh, dw, 3), dtype=np.uint8)
-    else:
-        res = np.zeros((dh, dw), dtype=np.uint8)
-    if sx < 0:
-        sx, dsx = 0, -sx
-    else:
-        dsx = 0
-    if ex > w:
-        ex, dex = w, dw - (ex - w)
-    else:
-        dex = dw
-    if sy < 0:
-        sy, dsy = 0, -sy
-    else:
-        dsy = 0
-    if ey > h:
-        ey, dey = h, dh - (ey - h)
-    else:
-        dey = dh
-    res[dsy:dey, dsx:dex] = img[sy:ey, sx:ex]
-    return res
-
-
 def _lanczos4_taps(n_dst: int, n_src: int):
-    """Per destination index: first source tap (may be out of range, clamp later) and 8 fixed-point weights."""
+    """Per destination index: first source tap (may be out of range, clamp later) and 8 fixed-point weights.
+    OpenCV's resize evaluates the source position in double, rounds it to float32 and takes floor / fraction of THAT
+    (`fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx`), so the fraction is always < 1; the kernel argument
+    `x + 3 - i` is float32 arithmetic and the eight weights are summed sequentially in float32."""
+    f32 = np.float32
     scale = n_src / n_dst
-    fx = (np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5
-    sx = np.floor(fx).astype(np.int64)
-    fx = (fx - sx).astype(np.float32)
+    pos = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(f32)
+    sx = np.floor(pos).astype(np.int64)
+    fx = pos - sx.astype(f32)                      # exact in float32
     s45 = 0.70710678118654752440084436210485
     cs = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]])
-    coeffs = np.zeros((n_dst, 8), dtype=np.float32)
+    coeffs = np.zeros((n_dst, 8), dtype=f32)
     for d in range(n_dst):
-        x = float(fx[d])
-        if x < np.finfo(np.float32).eps:
+        x = fx[d]
+        if x < np.finfo(f32).eps:
             coeffs[d, 3] = 1.0
             continue
-        y0 = -(x + 3) * np.pi * 0.25
+        x3 = f32(x + f32(3))
+        y0 = -float(x3) * np.pi * 0.25
         s0, c0 = np.sin(y0), np.cos(y0)
-        c = np.empty(8, dtype=np.float32)
+        c = np.empty(8, dtype=f32)
+        tot = f32(0)
         for i in range(8):
-            y = -(x + 3 - i) * np.pi * 0.25
-            c[i] = np.float32((cs[i, 0] * s0 + cs[i, 1] * c0) / (y * y))
-        coeffs[d] = c * (np.float32(1.0) / c.sum(dtype=np.float32))
-    icoef = np.clip(np.rint(coeffs * 2048.0), -32768, 32767).astype(np.int64)
+            y = -float(f32(x3 - f32(i))) * np.pi * 0.25
+            c[i] = f32((cs[i, 0] * s0 + cs[i, 1] * c0) / (y * y))
+            tot = f32(tot + c[i])
+        coeffs[d] = c * f32(f32(1.0) / tot)
+    icoef = np.clip(np.rint(coeffs * f32(2048.0)), -32768, 32767).astype(np.int64)
     return sx - 3, icoef
 
 
@@ -87,26 +66,6 @@ def lanczos4_tables(n_src: int, n_dst: int = 120):
     """(first tap in source coordinates [n_dst] int32, fixed-point weights [n_dst,8] int16) for syn_crop_resize."""
     x0, c = _lanczos4_taps(n_dst, n_src)
     return x0.astype(np.int32), c.astype(np.int16)
-
-
-def resize_lanczos4(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """uint8 [h,w(,c)] -> uint8 [out_h,out_w(,c)], separable 8-tap Lanczos, replicated borders."""
-    img = np.asarray(img)
-    squeeze = img.ndim == 2
-    if squeeze:
-        img = img[:, :, None]
-    h, w = img.shape[:2]
-    if h == 0 or w == 0:
-        raise ValueError('resize_lanczos4: empty crop')
-    x0, cx = _lanczos4_taps(out_w, w)
-    y0, cy = _lanczos4_taps(out_h, h)
-    src = img.astype(np.int64)
-    xi = np.clip(x0[:, None] + np.arange(8)[None, :], 0, w - 1)             # [out_w,8]
-    hor = (src[:, xi, :] * cx[None, :, :, None]).sum(axis=2)                # [h,out_w,c]
-    yi = np.clip(y0[:, None] + np.arange(8)[None, :], 0, h - 1)             # [out_h,8]
-    ver = (hor[yi] * cy[:, :, None, None]).sum(axis=1)                      # [out_h,out_w,c]
-    out = np.clip((ver + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
-    return out[:, :, 0] if squeeze else out
 
 
 def predict_sparseVert(param, roi_box, transform=False):
@@ -120,7 +79,5 @@ def predict_denseVert(param, roi_box, transform=False):
 
 
 def predict_pose(param, roi_bbox, ret_mat=False):
-    """reference utils/inference.py:146-157 (ret_mat=True is not supported on the device path)."""
-    if ret_mat:
-        raise NotImplementedError('ret_mat=True: only (angles, t3d) is produced by the HIP pose kernel')
-    return _model().predict_pose(param, roi_bbox)
+    """reference utils/inference.py:146-157; ret_mat=True returns parse_pose's P = [R | t3d] (3,4)."""
+    return _model().predict_pose(param, roi_bbox, ret_mat=ret_mat)

@@ -54,8 +54,19 @@ def _cfg16(pipe):
     return (C.c_float * 16)(*vals)
 
 
+def _planar_arg(meshes):
+    """The ABI's `planar` argument for a [F,3,N] float32 device tensor: 1 for packed rows, the row pitch for the pitched view
+    reconstruct() returns ([F,3,pitch][:, :, :N]); anything else (non-unit column stride, unevenly spaced faces) is refused."""
+    F, three, n = meshes.shape
+    pitch = meshes.stride(1) if n > 1 else n
+    if three != 3 or meshes.dtype != torch.float32 or (n > 1 and meshes.stride(2) != 1) or pitch < n or (F > 1 and meshes.stride(0) != 3 * pitch):
+        raise RuntimeError('meshes must be a float32 [F,3,N] tensor with unit column stride and equally pitched rows')
+    return 1 if pitch == n else int(pitch)
+
+
 def _shade(m, verts_t, planar, cfg=None):
-    """verts_t: device tensor [F,3,N] (planar) or [F,N,3]; returns (normal, light or None) device tensors [F,N,3]."""
+    """verts_t: device tensor [F,3,N] (planar: 1 packed, > 1 row pitch) or [F,N,3]; returns (normal, light or None) device
+    tensors [F,N,3]."""
     F = verts_t.shape[0]
     n = verts_t.shape[2] if planar else verts_t.shape[1]
     normal = torch.empty((F, n, 3), dtype=torch.float32, device=m.device)
@@ -146,12 +157,12 @@ def render_batch(model, img, meshes, alpha=0.6, cfg=None):
     H, W, ch = img_t.shape
     overlap = img_t.clone()
     res = torch.empty_like(img_t)
-    meshes = meshes.contiguous()
+    planar = _planar_arg(meshes)       # the pitched rows reconstruct() writes are read in place: no packed copy on the device path
     with torch.cuda.device(model.device):
-        normal, light = _shade(model, meshes, planar=True, cfg=_cfg16(pipe))
+        normal, light = _shade(model, meshes, planar=planar, cfg=_cfg16(pipe))
         for f0 in range(0, F, 254):                      # the z-key has an 8-bit face field; later faces overwrite earlier ones
             f1 = min(F, f0 + 254)
-            abi.check(model._lib.syn_rasterize(model._h, meshes[f0:f1].data_ptr(), light[f0:f1].data_ptr(), f1 - f0, 1, ch,
+            abi.check(model._lib.syn_rasterize(model._h, meshes[f0:f1].data_ptr(), light[f0:f1].data_ptr(), f1 - f0, planar, ch,
                                                overlap.data_ptr(), H, W, 0, model._stream()))
         abi.check(model._lib.syn_add_weighted(model._h, img_t.data_ptr(), C.c_float(1 - alpha), overlap.data_ptr(), C.c_float(alpha),
                                               res.data_ptr(), img_t.numel(), model._stream()))

@@ -5,7 +5,10 @@ run back to back they leave the other resource idle.  `OverlappedPipeline` puts 
 batch i on a second HIP stream so that it runs beside the backbone of batch i+1; events order the two streams and keep the
 parameters of a batch alive until its reconstruction has read them (at most two batches in flight).  Results are identical
 to the sequential calls -- the same kernels on the same inputs; only their placement in time changes (+2.5 % throughput at
-B = 1024).  The library's workspace regions of the two stages are disjoint (csrc/synergy_abi.hip: activations | records).
+B = 1024).  The two stages use separate scratch allocations of the handle (csrc/synergy_abi.hip: `ws` activations, `rec`
+reconstruction records), each of which only grows -- behind a device-wide synchronisation -- so batches of ANY sizes may follow
+each other (tests/test_gpu_parity.py::test_two_stream_pipeline_with_varying_batch_sizes).  All reconstruction calls of one
+handle must stay on ONE stream at a time (they share `rec`); that is what this class does.
 """
 from __future__ import annotations
 
@@ -22,9 +25,10 @@ class OverlappedPipeline:
         self._inflight = [None, None]              # per parity: (tensors kept alive, event "second stage done")
         self._n = 0
 
-    def submit(self, crops_u8, rois, lmk_out=None, mesh_out=None):
+    def submit(self, crops_u8, rois, lmk_out=None, mesh_out=None, dense=True):
         """Enqueue one batch: uint8 crops [B,120,120,3] and rois [B,5] (device tensors).  Returns (param, lmk, mesh, (angles,
-        t3d)) device tensors that are valid after `wait()` (or after synchronising with the event in `.last_done`)."""
+        t3d)) device tensors that are valid after `wait()` (or after synchronising with the event in `.last_done`).
+        dense=False: landmarks + pose only (BASELINE configs[1]); mesh is None."""
         m, k = self.model, self._n & 1
         self._n += 1
         if self._inflight[k] is not None:
@@ -36,7 +40,7 @@ class OverlappedPipeline:
         with torch.cuda.stream(self.s_rec):
             self.s_rec.wait_event(ready)
             lmk = m.reconstruct(param, roi=rois, dense=False, out=lmk_out)
-            mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out)
+            mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out) if dense else None
             pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
             done.record(self.s_rec)

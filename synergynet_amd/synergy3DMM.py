@@ -42,6 +42,30 @@ def parse_param_62(param):
     return p, offset, alpha_shp, alpha_exp
 
 
+_HDR_MAGIC = 0x53594e4833353558          # "SYNH355X" (csrc/synergy_abi.hip ConstHeader)
+
+
+def parse_constants_header(raw: bytes) -> dict:
+    """The 256-byte header of an exported constants blob (csrc/synergy_abi.hip `ConstHeader`): little-endian
+    u64 magic | u32 version, has_backbone, has_basis, n_vert, n_lmk, nvp, nlp, arch | u64 backbone_floats, basis_floats,
+    total_bytes.  Host-side twin of the checks syn_import_constants makes; raises ValueError on a blob it would refuse."""
+    import struct
+    if len(raw) < 256:
+        raise ValueError(f'constants blob: {len(raw)} bytes is smaller than the 256-byte header')
+    magic, version, has_bb, has_basis, n_vert, n_lmk, nvp, nlp, arch, bb_fl, basis_fl, total = struct.unpack_from('<Q8I3Q', raw, 0)
+    if magic != _HDR_MAGIC or version != 1:
+        raise ValueError('constants blob: bad magic/version')
+    if has_bb and arch > 1:
+        raise ValueError(f'constants blob: unknown backbone arch {arch}')
+    if has_basis and not (0 < n_vert <= nvp and 0 < n_lmk <= nlp and nvp % 32 == 0 and nlp % 32 == 0):
+        raise ValueError('constants blob: inconsistent basis sizes')
+    payload = 256 + 4 * ((bb_fl if has_bb else 0) + (basis_fl if has_basis else 0))
+    if payload > total:
+        raise ValueError(f'constants blob: header + payload = {payload} bytes exceeds total_bytes = {total}')
+    return dict(version=version, has_backbone=bool(has_bb), has_basis=bool(has_basis), n_vert=n_vert, n_lmk=n_lmk, nvp=nvp, nlp=nlp,
+                arch=arch, backbone_floats=bb_fl, basis_floats=basis_fl, total_bytes=total)
+
+
 def backbone_keys():
     """(state_dict key, shape) of every backbone tensor, in the order syn_load_backbone expects."""
     out = []
@@ -127,8 +151,10 @@ class SynergyNet(nn.Module):
         self.data_param = None
         self._n_vert = self._n_lmk = 0
         self._have_backbone = self._have_basis = False
-        if not load_constants:          # constants arrive later through receive_constants()
+        if not load_constants:          # constants arrive later through import_constants() (synergynet_amd/dist.py)
             self.eval()
+            from . import inference
+            inference.set_default_model(self)
             return
 
         # --- 3DMM constants (reference synergy3DMM.py:8-9,73-74,95-107) ---
@@ -235,11 +261,16 @@ class SynergyNet(nn.Module):
 
     def import_constants(self, buf: torch.Tensor):
         assert buf.is_cuda and buf.dtype == torch.uint8 and buf.is_contiguous()
+        hdr = parse_constants_header(buf[:256].cpu().numpy().tobytes())
         abi.check(self._lib.syn_import_constants(self._h, buf.data_ptr(), buf.numel(), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
-        self._have_backbone = self._have_basis = True
-        hdr = buf[:256].cpu().numpy()
-        self._n_vert, self._n_lmk = int(hdr[20:24].view(np.uint32)[0]), int(hdr[24:28].view(np.uint32)[0])
+        if hdr['has_backbone']:
+            # the blob decides which backbone the C handle now runs: follow it, or pool buffers would be sized for the wrong one
+            self.arch = ('mobilenet_v2', 'resnet50')[hdr['arch']]
+            self._have_backbone = True
+        if hdr['has_basis']:
+            self._n_vert, self._n_lmk = hdr['n_vert'], hdr['n_lmk']
+            self._have_basis = True
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -344,14 +375,29 @@ class SynergyNet(nn.Module):
     def predict_pose_batch(self, param, roi=None):
         """Batched predict_pose (utils/inference.py:146-157): angles [B,3] float64 degrees, t3d [B,3] fp32."""
         p = self._dev_f32(param)
+        if p.dim() != 2 or p.shape[1] != 62:
+            raise RuntimeError('length of params mismatch')
         B = p.shape[0]
         r = self._dev_f32(roi) if roi is not None else None
+        if r is not None and tuple(r.shape) != (B, 5):
+            raise RuntimeError('roi must be [B,5] (sx,sy,ex,ey,score)')
         with torch.cuda.device(self.device):
             ang = torch.empty((B, 3), dtype=torch.float64, device=self.device)
             t3d = torch.empty((B, 3), dtype=torch.float32, device=self.device)
             abi.check(self._lib.syn_pose(self._h, p.data_ptr(), B, r.data_ptr() if r is not None else None,
                                          ang.data_ptr(), t3d.data_ptr(), self._stream()))
         return ang, t3d
+
+    def pose_matrix_batch(self, param):
+        """Batched predict_pose(..., ret_mat=True) (utils/inference.py:146-157): [B,3,4] fp32 = [R | t3d] of parse_pose
+        (:86-92), the translation column WITHOUT the ROI affine (the reference builds P before rescaling t3d)."""
+        p = self._dev_f32(param)
+        if p.dim() != 2 or p.shape[1] != 62:
+            raise RuntimeError('length of params mismatch')
+        with torch.cuda.device(self.device):
+            out = torch.empty((p.shape[0], 3, 4), dtype=torch.float32, device=self.device)
+            abi.check(self._lib.syn_pose_matrix(self._h, p.data_ptr(), p.shape[0], out.data_ptr(), self._stream()))
+        return out
 
     # numpy single-face helpers with the reference's names and return types (utils/inference.py:140-157)
     def predict_sparseVert(self, param, roi_box, transform=False):
@@ -367,8 +413,10 @@ class SynergyNet(nn.Module):
         roi = np.asarray(roi_box, dtype=np.float32).reshape(1, 5)
         return self.reconstruct(p, roi=roi, dense=dense, transform=transform)[0].cpu().numpy()
 
-    def predict_pose(self, param, roi_bbox):
+    def predict_pose(self, param, roi_bbox, ret_mat=False):
         p = np.asarray(param, dtype=np.float32).reshape(1, -1)
+        if ret_mat:
+            return self.pose_matrix_batch(p)[0].cpu().numpy()
         roi = np.asarray(roi_bbox, dtype=np.float32).reshape(1, 5)
         ang, t3d = self.predict_pose_batch(p, roi)
         return [float(v) for v in ang[0].cpu().numpy()], t3d[0].cpu().numpy()
@@ -383,6 +431,9 @@ class SynergyNet(nn.Module):
         dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(self.device)
         bx, xo, xc, yo, yc = dev(boxes, np.int32), dev(xofs, np.int32), dev(xcoef, np.int16), dev(yofs, np.int32), dev(ycoef, np.int16)
         B = bx.shape[0]
+        if (bx.dim() != 2 or bx.shape[1] != 4 or tuple(xo.shape) != (B, 120) or tuple(yo.shape) != (B, 120) or
+                tuple(xc.shape) != (B, 120, 8) or tuple(yc.shape) != (B, 120, 8)):
+            raise RuntimeError('crop_resize: boxes [B,4], xofs/yofs [B,120], xcoef/ycoef [B,120,8] expected')
         with torch.cuda.device(self.device):
             out = torch.empty((B, 120, 120, 3), dtype=torch.uint8, device=self.device)
             abi.check(self._lib.syn_crop_resize(self._h, fr.data_ptr(), fr.shape[0], fr.shape[1], bx.data_ptr(), xo.data_ptr(),

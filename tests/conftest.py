@@ -42,3 +42,19 @@ def rel_max(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+ASSETS = os.path.join(ROOT, 'tests', 'golden', '_assets')
+
+
+def real_detector_assets():
+    """(weights path, {i: BGR uint8 frame}) of the reference's trained FaceBoxes weights and sample photographs, or None.
+    They are staged by tests/golden/make_golden.py / __graft_entry__.build() into the git-ignored tests/golden/_assets/ (the
+    weights may also come from $SYN_FACEBOXES_WEIGHTS); absent -> the real-data tests skip."""
+    w = os.environ.get('SYN_FACEBOXES_WEIGHTS') or os.path.join(ASSETS, 'FaceBoxesProd.pth')
+    if not os.path.isfile(w) or not all(os.path.isfile(os.path.join(ASSETS, f'sample_{i}.jpg')) for i in range(1, 5)):
+        return None
+    from PIL import Image
+    frames = {i: np.ascontiguousarray(np.asarray(Image.open(os.path.join(ASSETS, f'sample_{i}.jpg')).convert('RGB'))[:, :, ::-1])
+              for i in range(1, 5)}
+    return w, frames

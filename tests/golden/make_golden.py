@@ -100,6 +100,27 @@ def main():
     print('max |d param| for a corner perturbation:', d)
 
 
+def main_pose_mat():
+    """predict_pose(..., ret_mat=True) of the reference (utils/inference.py:146-157) on the parameter vectors / boxes of
+    reference_outputs.npz -> tests/golden/pose_mat_golden.npz.  Also records the reference's own crop_img on boxes that
+    overhang every border of a seeded frame (utils/inference.py:95-125) as a checksum per crop."""
+    g = dict(np.load(os.path.join(HERE, 'reference_outputs.npz')))
+    pack = synth.make_3dmm(int(g['seeds'][1]))
+    sd = synth.make_backbone_state(int(g['seeds'][0]))
+    ref_loader.build_reference_model(pack, sd)
+    inf = ref_loader._REF_MODULES['utils.inference']
+    mats = np.stack([np.asarray(inf.predict_pose(p.copy(), list(r), ret_mat=True), dtype=np.float32) for p, r in zip(g['params'], g['rois'])])
+    frame = synth.make_frame(97, 131, seed=12)
+    boxes = np.array([[-20.4, -10.6, 60.2, 70.5, 1], [90.5, 50.5, 160.4, 120.6, 1], [10, 20, 50, 60, 1], [-5.5, 80.5, 140.5, 110.4, 1],
+                      [40.49, -30.51, 80.5, 9.5, 1]], dtype=np.float64)
+    crops = [inf.crop_img(frame, list(bx)) for bx in boxes]
+    fp = os.path.join(HERE, 'pose_mat_golden.npz')
+    np.savez_compressed(fp, pose_mat=mats, crop_frame_hw_seed=np.array([97, 131, 12]), crop_boxes=boxes,
+                        crop_shapes=np.array([c.shape for c in crops]), crop_sums=np.array([int(c.astype(np.int64).sum()) for c in crops]),
+                        crop_weighted=np.array([int((c.astype(np.int64).reshape(-1) * (np.arange(c.size) % 251 + 1)).sum()) for c in crops]))
+    print('wrote', fp, os.path.getsize(fp), 'bytes; P[0] =', mats[0])
+
+
 def main_resnet50():
     """BASELINE config 5: outputs of the reference's own resnet50() module (backbone_nets/resnet_backbone.py:304-312,
     importable as-is: torch-only) on seeded crops -> tests/golden/resnet50_outputs.npz."""
@@ -241,6 +262,95 @@ def main_faceboxes():
         del sys.modules[k]
 
 
+ASSETS = os.path.join(HERE, '_assets')          # git-ignored; travels to the GPU box with the snapshot like oracle/_ref
+
+
+def stage_real_detector_assets():
+    """Copies the reference's trained detector weights (FaceBoxes/weights/FaceBoxesProd.pth, 4 MB) and its sample photographs
+    (img/sample_*.jpg) into tests/golden/_assets/ -- data files, not source; the directory is git-ignored so they stay out of
+    history, but it is not gpurun-ignored, so the real-data GPU test can run on the GPU box (where /root/reference is absent)."""
+    import shutil
+    if not os.path.isfile(os.path.join(ref_loader.REF_ROOT, 'FaceBoxes', 'weights', 'FaceBoxesProd.pth')):
+        return False
+    os.makedirs(ASSETS, exist_ok=True)
+    shutil.copyfile(os.path.join(ref_loader.REF_ROOT, 'FaceBoxes', 'weights', 'FaceBoxesProd.pth'), os.path.join(ASSETS, 'FaceBoxesProd.pth'))
+    for i in range(1, 5):
+        shutil.copyfile(os.path.join(ref_loader.REF_ROOT, 'img', f'sample_{i}.jpg'), os.path.join(ASSETS, f'sample_{i}.jpg'))
+    return True
+
+
+def load_bgr(path):
+    """cv2.imread stand-in: PIL decode (libjpeg), RGB -> BGR.  The decoded frame's SHA-256 is stored in the fixture so a test on
+    another machine knows whether it is looking at the same pixels."""
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1])
+
+
+def main_faceboxes_real():
+    """The reference's own FaceBoxesNet with its TRAINED weights (FaceBoxes/weights/FaceBoxesProd.pth) on its own sample
+    photographs (img/sample_*.jpg), glued exactly like FaceBoxes.__call__ (FaceBoxes.py:60-143) -> faceboxes_real_golden.npz:
+    realistic candidate counts and real faces for the device detector.  Frames above 720x1080 take the down-scaling branch,
+    whose cv2.resize is absent here: those frames are down-scaled with the oracle's restatement (unpinned) and flagged
+    `scaled` in the fixture; samples 2 and 3 need no scaling and are the reference end to end."""
+    import hashlib
+    import importlib
+    import types
+    assert stage_real_detector_assets(), 'reference detector weights not found'
+    fbroot = os.path.join(ref_loader.REF_ROOT, 'FaceBoxes')
+    pkg = types.ModuleType('FaceBoxes'); pkg.__path__ = [fbroot]; sys.modules['FaceBoxes'] = pkg
+    for sub in ('models', 'utils'):
+        m = types.ModuleType('FaceBoxes.' + sub); m.__path__ = [os.path.join(fbroot, sub)]; sys.modules['FaceBoxes.' + sub] = m
+    net_mod = importlib.import_module('FaceBoxes.models.faceboxes')
+    prior_mod = importlib.import_module('FaceBoxes.utils.prior_box')
+    box_mod = importlib.import_module('FaceBoxes.utils.box_utils')
+    cfg = importlib.import_module('FaceBoxes.utils.config').cfg
+    net = net_mod.FaceBoxesNet(phase='test', size=None, num_classes=2)
+    ck = torch.load(os.path.join(ASSETS, 'FaceBoxesProd.pth'), map_location='cpu')
+    net.load_state_dict({(k.split('module.', 1)[-1] if k.startswith('module.') else k): v for k, v in ck.items()}, strict=False)   # utils/functions.py:21-25
+    net.eval()
+    from oracle import faceboxes_torch as ofb
+    out = {}
+    for i in range(1, 5):
+        frame = load_bgr(os.path.join(ASSETS, f'sample_{i}.jpg'))
+        h, w = frame.shape[:2]
+        scale = 1                                            # FaceBoxes.py:63-80
+        if h > 720:
+            scale = 720 / h
+        if w * scale > 1080:
+            scale *= 1080 / (w * scale)
+        small = frame if scale == 1 else ofb.resize_linear_u8(frame, int(scale * h), int(scale * w))
+        img = np.float32(small)
+        im_height, im_width, _ = img.shape
+        scale_bbox = torch.Tensor([img.shape[1], img.shape[0], img.shape[1], img.shape[0]])
+        img -= (104, 117, 123)
+        with torch.no_grad():
+            loc, conf = net(torch.from_numpy(img.transpose(2, 0, 1)).unsqueeze(0))
+        priors = prior_mod.PriorBox(image_size=(im_height, im_width)).forward()
+        boxes = box_mod.decode(loc.data.squeeze(0), priors.data, cfg['variance'])
+        boxes = (boxes * scale_bbox / scale / 1).cpu().numpy()
+        scores = conf.squeeze(0).data.cpu().numpy()[:, 1]
+        inds = np.where(scores > 0.05)[0]
+        n_cand = inds.size
+        boxes, scores = boxes[inds], scores[inds]
+        order = scores.argsort()[::-1][:5000]
+        dets = np.hstack((boxes[order], scores[order][:, np.newaxis])).astype(np.float32, copy=False)
+        keep = ofb.cpu_nms(dets, 0.3) if dets.shape[0] else []
+        dets = dets[keep, :][:750]
+        tag = f's{i}'
+        out[tag + '_hw'] = np.array([h, w]); out[tag + '_scaled'] = np.array(scale != 1)
+        out[tag + '_sha256'] = np.array(hashlib.sha256(frame.tobytes()).hexdigest())
+        out[tag + '_loc_sub'] = loc.numpy()[0][::7].copy(); out[tag + '_conf_sub'] = conf.numpy()[0][::7].copy()
+        out[tag + '_loc_absmax'] = np.array(np.abs(loc.numpy()).max())
+        out[tag + '_n_cand'] = np.array(n_cand)
+        out[tag + '_dets'] = dets
+        print(tag, (h, w), 'scale', scale, 'priors', loc.shape[1], 'candidates', n_cand, 'dets', dets.shape[0], 'faces (score > 0.5):', int((dets[:, 4] > 0.5).sum()))
+    path = os.path.join(HERE, 'faceboxes_real_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KB')
+    for k in [k for k in sys.modules if k == 'FaceBoxes' or k.startswith('FaceBoxes.')]:
+        del sys.modules[k]
+
+
 def make_eval_inputs(n=96, seed=2024):
     """Seeded stand-ins for aflw2000_data/eval/*.npy (absent): ground-truth landmarks, crop boxes, yaws, fitted landmarks."""
     rng = np.random.default_rng(seed)
@@ -287,8 +397,14 @@ def main_evaluate():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                      # python make_golden.py main_pose_mat main_faceboxes_real ...: only those fixtures
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     main()
+    main_pose_mat()
     main_resnet50()
     main_render()
     main_faceboxes()
+    main_faceboxes_real()
     main_evaluate()

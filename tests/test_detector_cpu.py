@@ -46,3 +46,29 @@ def test_nms_follows_the_cython_variant():
     d = np.array([[0, 0, 10, 10, 0.9], [0, 0, 10, 10, 0.8], [20, 20, 30, 30, 0.7], [1, 1, 11, 11, 0.6]], dtype=np.float32)
     assert ofb.cpu_nms(d, 0.3) == [0, 2]
     assert ofb.cpu_nms(d[:0], 0.3) == []
+
+
+def test_oracle_detector_with_trained_weights_on_real_photographs():
+    """oracle/faceboxes_torch.py vs the REAL reference FaceBoxesNet carrying its TRAINED weights on its own sample photographs
+    (tests/golden/faceboxes_real_golden.npz, made by make_golden.py main_faceboxes_real): realistic candidate counts, real faces."""
+    import hashlib
+    import os
+    import torch
+    from conftest import real_detector_assets
+    from oracle import faceboxes_torch as ofb
+    assets = real_detector_assets()
+    if assets is None:
+        pytest.skip('tests/golden/_assets (reference detector weights + sample photographs) not staged')
+    wpath, frames = assets
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'faceboxes_real_golden.npz'))
+    ck = torch.load(wpath, map_location='cpu')
+    sd = {(k.split('module.', 1)[-1] if k.startswith('module.') else k): v.numpy() for k, v in ck.items()}
+    for i in (2, 3, 1):
+        if hashlib.sha256(frames[i].tobytes()).hexdigest() != str(g[f's{i}_sha256']):
+            pytest.skip('this machine decodes the JPEGs to different pixels than the authoring container')
+        got = ofb.detect(sd, frames[i], return_all=True)
+        want = g[f's{i}_dets']
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=2e-2)
+    assert int((g['s1_dets'][:, 4] > 0.5).sum()) == 10          # the group photograph

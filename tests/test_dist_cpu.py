@@ -69,6 +69,108 @@ def test_broadcast_and_sharding_world2():
     assert sorted(n for _, _, n in res) == [4095, 4096]
 
 
+class _HostReplica:
+    """Host stand-in of a rank's SynergyNet for the constant hand-off: the blob is the REAL one (packed by the library's own
+    host packer, syn_pack_constants_host -- byte-identical to a device export, tests/test_gpu_parity.py), and the receive side
+    runs the product's own acceptance path: syn_check_constants_host (the checks of syn_import_constants) + the header parsing
+    SynergyNet.import_constants uses (synergy3DMM.parse_constants_header) to set arch / n_vert / n_lmk."""
+
+    def __init__(self, blob=None):
+        self.device = torch.device('cpu')
+        self.blob = blob
+        self.arch, self._n_vert, self._n_lmk = 'mobilenet_v2', 0, 0
+
+    def export_constants(self):
+        return torch.from_numpy(self.blob)
+
+    def import_constants(self, buf):
+        from synergynet_amd.dist import check_constants_host
+        hdr = check_constants_host(buf.numpy())
+        self.blob = buf.numpy().copy()
+        if hdr['has_backbone']:
+            self.arch = ('mobilenet_v2', 'resnet50')[hdr['arch']]
+        if hdr['has_basis']:
+            self._n_vert, self._n_lmk = hdr['n_vert'], hdr['n_lmk']
+        self.hdr = hdr
+
+
+def _real_blob_worker(rank, world, port, q, arch):
+    import hashlib
+    import torch.distributed as dist
+    from synergynet_amd import synth
+    from synergynet_amd.dist import broadcast_constants, pack_constants_host
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        blob = None
+        if rank == 0:          # only the source rank ever touches host assets
+            sd = synth.make_resnet50_state(3) if arch == 'resnet50' else synth.make_backbone_state(3)
+            blob = pack_constants_host(pack=synth.make_3dmm(4, n_vert=700), backbone_state=sd, arch=arch)
+        m = _HostReplica(blob)
+        n = broadcast_constants(m, src=0)
+        digest = hashlib.sha256(m.blob.tobytes()).hexdigest()
+        q.put((rank, n, digest, m.arch, m._n_vert, m._n_lmk, getattr(m, 'hdr', None)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('arch', ['mobilenet_v2', 'resnet50'])
+def test_real_constants_blob_world2(arch):
+    """gloo world-2: rank 0 packs the real constants blob on the host and broadcasts it with synergynet_amd.dist.broadcast_constants;
+    rank 1 -- which starts as a default mobilenet_v2 replica with no assets -- accepts it through the library's own checks and
+    ends up with the source's arch and sizes."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_blob_worker, args=(r, 2, port, q, arch)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, n0, d0, *_), (_, n1, d1, arch1, nv1, nl1, hdr1) = res
+    assert n0 == n1 and d0 == d1
+    assert arch1 == arch and (nv1, nl1) == (700, 68)
+    assert hdr1['total_bytes'] == n1 and hdr1['nvp'] == 704 and hdr1['nlp'] == 96
+
+
+def test_constants_blob_acceptance_checks():
+    """What syn_import_constants refuses, exercised on the host twin: truncated buffers, a payload larger than the buffer, sizes
+    that do not match this library's tables, foreign bytes."""
+    from synergynet_amd import abi, synth
+    from synergynet_amd.dist import check_constants_host, pack_constants_host
+    from synergynet_amd.synergy3DMM import parse_constants_header
+    blob = pack_constants_host(pack=synth.make_3dmm(4, n_vert=300), backbone_state=synth.make_backbone_state(3))
+    hdr = check_constants_host(blob)
+    assert hdr['has_backbone'] and hdr['has_basis'] and hdr['arch'] == 0 and hdr['n_vert'] == 300 and hdr['total_bytes'] == blob.size
+    assert 256 + 4 * (hdr['backbone_floats'] + hdr['basis_floats']) == blob.size
+    basis_only = pack_constants_host(pack=synth.make_3dmm(4, n_vert=300))
+    h2 = check_constants_host(basis_only)
+    assert not h2['has_backbone'] and h2['has_basis'] and basis_only.size < blob.size
+    with pytest.raises(abi.SynergyHipError):
+        check_constants_host(blob[:100])                                   # shorter than the header
+    with pytest.raises(abi.SynergyHipError):
+        check_constants_host(blob[:-4])                                    # total_bytes > buffer
+    bad = blob.copy(); bad[0] ^= 0xFF
+    with pytest.raises(abi.SynergyHipError, match='magic'):
+        check_constants_host(bad)
+    bad = blob.copy(); bad[20:24] = np.frombuffer(np.uint32(5000).tobytes(), np.uint8)      # n_vert > nvp
+    with pytest.raises(abi.SynergyHipError, match='basis size'):
+        check_constants_host(bad)
+    bad = blob.copy(); bad[36:40] = np.frombuffer(np.uint32(7).tobytes(), np.uint8)          # unknown arch
+    with pytest.raises(abi.SynergyHipError, match='backbone size'):
+        check_constants_host(bad)
+    bad = blob.copy(); bad[56:64] = np.frombuffer(np.uint64(300).tobytes(), np.uint8)        # total_bytes smaller than the payload
+    with pytest.raises(abi.SynergyHipError):
+        check_constants_host(bad)
+    with pytest.raises(ValueError):
+        parse_constants_header(bad[:256].tobytes())
+    with pytest.raises(ValueError):
+        parse_constants_header(b'\x00' * 10)
+
+
 def test_shard_range_covers_everything():
     from synergynet_amd.dist import shard_range
     for total in (0, 1, 7, 1024, 8192, 8191):

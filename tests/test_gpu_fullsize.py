@@ -1,0 +1,161 @@
+"""GPU parity at the FULL sizes of BASELINE.json's configs, on DISTINCT faces, straight against the oracle (run with `-m gpu`).
+
+configs[1] B = 128, configs[2]/[3] B = 1024 (per GPU), configs[4] ResNet-50 B = 512 -- plus B = 512 on MobileNetV2.  Every face is
+a different seeded crop (white-noise and low-pass halves), so a data-dependent or tile-position-dependent fault of the large-batch
+schedule (persistent workgroups of features.2-7, un-sliced features.15-17 + head, uint8 stem on the matrix pipe) cannot hide
+behind repeated inputs.  The whole chain is compared per face: uint8 crops -> parameters -> 68 landmarks -> 53215-vertex mesh
+(row-pitched default output and the reference's packed layout) -> pose, HIP path (C ABI) vs oracle/backbone_torch.py +
+oracle/recon_numpy.py (pinned to the real reference by tests/test_oracle_golden.py).  Tolerance 1e-4 relative per face
+(BASELINE.json north_star); angles 1e-3 degrees.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def per_face_rel(got, want):
+    B = want.shape[0]
+    g, w = np.asarray(got, np.float64).reshape(B, -1), np.asarray(want, np.float64).reshape(B, -1)
+    return np.abs(g - w).max(axis=1) / np.maximum(np.abs(w).max(axis=1), 1e-30)
+
+
+def distinct_crops(B, seed):
+    from synergynet_amd import synth
+    c = synth.make_crops(B, seed=seed)
+    c[B // 2:] = synth.make_crops(B - B // 2, seed=seed + 1, smooth=True)
+    assert len({c[i].tobytes() for i in range(B)}) == B
+    return c
+
+
+@pytest.fixture(scope='module')
+def model(pack, backbone_sd):
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from synergynet_amd.synergy3DMM import SynergyNet
+    return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)       # default schedule (fused + bf16x3)
+
+
+@pytest.fixture(scope='module')
+def basis(pack):
+    from oracle import recon_numpy
+    return recon_numpy.Basis(pack)
+
+
+def oracle_params(sd, crops, chunk=128):
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    ps, pools = [], []
+    for i in range(0, crops.shape[0], chunk):
+        p, pool = backbone_torch.mobilenet_v2_forward(sd, synth.normalize_crops(crops[i:i + chunk]))
+        ps.append(p.numpy()); pools.append(pool.numpy())
+    return np.concatenate(ps), np.concatenate(pools)
+
+
+@pytest.mark.parametrize('B', [128, 512, 1024])
+def test_distinct_faces_whole_chain_matches_oracle(model, basis, backbone_sd, B):
+    import torch
+    from oracle import recon_numpy
+    from synergynet_amd import synth
+    crops = distinct_crops(B, seed=7000 + B)
+    rois = synth.make_rois(B, seed=7100 + B)
+    want_p, want_pool = oracle_params(backbone_sd, crops)
+
+    cd = torch.from_numpy(crops).cuda()
+    param, pool = model.forward_crops_u8(cd, return_pool=True)
+    e = per_face_rel(param.cpu().numpy(), want_p)
+    assert e.max() < TOL, f'parameters: worst face {e.argmax()} rel err {e.max():.3e}'
+    e = per_face_rel(pool.cpu().numpy(), want_pool)
+    assert e.max() < TOL, f'pooled feature: worst face {e.argmax()} rel err {e.max():.3e}'
+    # fp32 NCHW ingest (the reference's forward_test signature) on the same faces
+    pf = model.forward_test(torch.from_numpy(synth.normalize_crops(crops)).cuda())
+    e = per_face_rel(pf.cpu().numpy(), want_p)
+    assert e.max() < TOL, f'forward_test: worst face {e.argmax()} rel err {e.max():.3e}'
+
+    # 68 landmarks, batched method (no ROI affine): every face
+    lmk = model.reconstruct(param, dense=False).cpu().numpy()
+    want_l = recon_numpy.reconstruct_vertex_62(basis, want_p, dense=False)
+    e = per_face_rel(lmk, want_l)
+    assert e.max() < TOL, f'landmarks: worst face {e.argmax()} rel err {e.max():.3e}'
+
+    # 53215-vertex mesh, batched method: every face, default (row-pitched) output and the reference's packed layout
+    mesh = model.reconstruct(param, dense=True)
+    assert tuple(mesh.shape) == (B, 3, synth.N_VERT) and mesh.stride(1) % 128 == 0
+    packed = torch.empty((B, 3, synth.N_VERT), dtype=torch.float32, device='cuda')
+    model.reconstruct(param, dense=True, out=packed)
+    assert torch.equal(packed, mesh)
+    worst = 0.0
+    for i in range(0, B, 128):
+        want_m = recon_numpy.reconstruct_vertex_62(basis, want_p[i:i + 128], dense=True)
+        e = per_face_rel(mesh[i:i + 128].cpu().numpy(), want_m)
+        assert e.max() < TOL, f'mesh: worst face {i + e.argmax()} rel err {e.max():.3e}'
+        worst = max(worst, float(e.max()))
+    del packed
+
+    # ROI affine (utils/inference.py:127-138) + pose (:146-157): landmarks and pose on every face, dense on every 41st face
+    lmk_r = model.reconstruct(param, roi=rois, dense=False).cpu().numpy()
+    mesh_r = model.reconstruct(param, roi=rois, dense=True)
+    ang, t3d = model.predict_pose_batch(param, rois)
+    ang, t3d = ang.cpu().numpy(), t3d.cpu().numpy()
+    for i in range(B):
+        wl = recon_numpy.predict_vertices(basis, want_p[i].copy(), list(rois[i]), dense=False)
+        assert per_face_rel(lmk_r[i:i + 1], wl[None]).max() < TOL, f'ROI landmarks, face {i}'
+        wa, wt = recon_numpy.predict_pose(basis, want_p[i].copy(), list(rois[i]))
+        assert np.allclose(ang[i], wa, rtol=0, atol=1e-3), f'pose angles, face {i}: {ang[i]} vs {wa}'
+        assert per_face_rel(t3d[i:i + 1], np.asarray(wt)[None]).max() < TOL, f't3d, face {i}'
+    for i in range(0, B, 41):
+        wm = recon_numpy.predict_vertices(basis, want_p[i].copy(), list(rois[i]), dense=True)
+        assert per_face_rel(mesh_r[i:i + 1].cpu().numpy(), wm[None]).max() < TOL, f'ROI mesh, face {i}'
+    print(f'B={B}: worst per-face mesh rel err {worst:.3e}')
+
+
+def test_resnet50_b512_distinct_faces_match_oracle(pack, basis):
+    """BASELINE configs[4]: ResNet-50, B = 512 distinct faces + the full mesh, per face vs the oracle."""
+    import torch
+    from oracle import recon_numpy, resnet_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = synth.make_resnet50_state(2468)
+    m = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    B = 512
+    crops = distinct_crops(B, seed=7600)
+    wp, wpool = [], []
+    for i in range(0, B, 64):
+        p, pool = resnet_torch.resnet50_forward(sd, synth.normalize_crops(crops[i:i + 64]))
+        wp.append(p.numpy()[:, :62]); wpool.append(pool.numpy())
+    want_p, want_pool = np.concatenate(wp), np.concatenate(wpool)
+    param, pool = m.forward_crops_u8(torch.from_numpy(crops).cuda(), return_pool=True)
+    e = per_face_rel(param.cpu().numpy(), want_p)
+    assert e.max() < TOL, f'parameters: worst face {e.argmax()} rel err {e.max():.3e}'
+    e = per_face_rel(pool.cpu().numpy(), want_pool)
+    assert e.max() < TOL, f'pooled feature: worst face {e.argmax()} rel err {e.max():.3e}'
+    mesh = m.reconstruct(param, dense=True)
+    for i in range(0, B, 128):
+        want_m = recon_numpy.reconstruct_vertex_62(basis, want_p[i:i + 128], dense=True)
+        e = per_face_rel(mesh[i:i + 128].cpu().numpy(), want_m)
+        assert e.max() < TOL, f'mesh: worst face {i + e.argmax()} rel err {e.max():.3e}'
+
+
+def test_pose_matrix_matches_reference_golden_and_oracle(model, basis, golden):
+    """predict_pose(..., ret_mat=True) (utils/inference.py:146-157): vs the REAL reference's output (pose_mat_golden.npz) and,
+    on a big batch of distinct parameter vectors, vs the oracle."""
+    import os
+    from oracle import recon_numpy
+    from synergynet_amd import inference, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pose_mat_golden.npz'))
+    got = model.pose_matrix_batch(golden['params']).cpu().numpy()
+    assert got.shape == g['pose_mat'].shape
+    assert np.abs(got[:, :, :3] - g['pose_mat'][:, :, :3]).max() < 1e-5
+    assert per_face_rel(got[:, :, 3], g['pose_mat'][:, :, 3]).max() < TOL
+    P = inference.predict_pose(golden['params'][1], list(golden['rois'][1]), ret_mat=True)      # the reference's module-level name
+    assert isinstance(P, np.ndarray) and P.shape == (3, 4) and P.dtype == np.float32 and np.array_equal(P, got[1])
+    params = synth.make_params(777, seed=31, scale=1.2)
+    got = model.pose_matrix_batch(params).cpu().numpy()
+    want = np.stack([recon_numpy.pose_matrix(basis, p.copy()) for p in params])
+    assert np.abs(got[:, :, :3] - want[:, :, :3]).max() < 1e-5
+    assert per_face_rel(got[:, :, 3], want[:, :, 3]).max() < TOL
+    with pytest.raises(RuntimeError, match='length of params mismatch'):
+        model.predict_pose_batch(np.zeros((3, 61), np.float32))
+    with pytest.raises(RuntimeError, match=r'roi must be \[B,5\]'):
+        model.predict_pose_batch(np.zeros((3, 62), np.float32), np.zeros((3, 4), np.float32))

@@ -217,6 +217,35 @@ def test_two_stream_pipeline_equals_sequential_calls(model):
         assert torch.equal(p, p2) and torch.equal(l, l2) and torch.equal(m, m2) and torch.equal(a, a2) and torch.equal(t, t2)
 
 
+@pytest.mark.parametrize('arch', ['mobilenet_v2', 'resnet50'])
+def test_two_stream_pipeline_with_varying_batch_sizes(model, resnet_model, arch):
+    """The reconstruction of batch i (second stream) runs beside the backbone of batch i+1, whatever their sizes: the
+    reconstruction records live in an allocation of their own (csrc/synergy_abi.hip `rec`), so a LARGER next batch -- whose
+    activations used to reach the records region of the previous one -- must not change a single bit.  Growing a scratch
+    buffer mid-stream (first large batch) goes through a device-wide synchronisation."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.streams import OverlappedPipeline
+    m = model if arch == 'mobilenet_v2' else resnet_model
+    if arch == 'resnet50' and model._test_fusion != '2':
+        pytest.skip('the ResNet-50 handle is schedule-independent: once is enough')
+    sizes = [8, 40, 33, 400, 64, 1030, 1, 96] if arch == 'mobilenet_v2' else [8, 40, 16, 130, 3]
+    crops = [torch.from_numpy(synth.make_crops(B, seed=900 + i)).cuda() for i, B in enumerate(sizes)]
+    rois = [torch.from_numpy(synth.make_rois(B, seed=950 + i)).cuda() for i, B in enumerate(sizes)]
+    want = []
+    for c, r in zip(crops, rois):
+        p = m.forward_crops_u8(c)
+        want.append((p, m.reconstruct(p, roi=r, dense=False), m.reconstruct(p, roi=r, dense=True)))
+        torch.cuda.synchronize()
+    for rep in range(3):
+        pipe = OverlappedPipeline(m)
+        got = [pipe.submit(c, r) for c, r in zip(crops, rois)]
+        pipe.wait()
+        torch.cuda.synchronize()
+        for i, ((p, l, me), (p2, l2, m2, _)) in enumerate(zip(want, got)):
+            assert torch.equal(p, p2) and torch.equal(l, l2) and torch.equal(me, m2), f'batch {i} (B={sizes[i]}), repetition {rep}'
+
+
 @pytest.mark.parametrize('B', [1, 31, 32, 33, 64, 100])
 def test_pitched_and_packed_outputs_are_identical(model, B):
     """reconstruct() writes into a row-pitched [B,3,n] view by default (whole-line stores, syn_reconstruct_pitched) and into
@@ -304,13 +333,38 @@ def test_constants_export_import_roundtrip(model, golden):
     assert torch.equal(other.reconstruct(p, dense=True), model.reconstruct(p, dense=True))
     crops = golden['crops_u8']
     assert torch.equal(other.forward_crops_u8(crops), model.forward_crops_u8(crops))
+    # the device-free packer (syn_pack_constants_host, what tests/test_dist_cpu.py broadcasts over gloo) writes the same bytes
+    from synergynet_amd.dist import check_constants_host, pack_constants_host
+    from synergynet_amd import synth
+    host = pack_constants_host(pack=synth.make_3dmm(int(golden['seeds'][1])), backbone_state=synth.make_backbone_state(int(golden['seeds'][0])))
+    assert host.size == buf.numel() and np.array_equal(host, buf.cpu().numpy())
+    assert check_constants_host(host)['total_bytes'] == host.size
+    from synergynet_amd import abi
+    with pytest.raises(abi.SynergyHipError):
+        other.import_constants(buf[:buf.numel() - 64].contiguous())          # truncated blob: refused, nothing read past the end
+
+
+def test_import_constants_follows_the_blobs_arch(resnet_model):
+    """A rank built with the default arch and no assets that receives a ResNet-50 blob becomes a ResNet-50 replica: `arch` and
+    the pooled-feature width follow the header (a 1280-wide buffer under a 2048-wide kernel write would be out of bounds)."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    rx = SynergyNet(device='cuda:0', load_constants=False)
+    assert rx.arch == 'mobilenet_v2' and rx.pool_dim == 1280
+    rx.import_constants(resnet_model.export_constants())
+    assert rx.arch == 'resnet50' and rx.pool_dim == 2048
+    crops = torch.from_numpy(synth.make_crops(5, seed=12)).cuda()
+    p, pool = rx.forward_crops_u8(crops, return_pool=True)
+    p2, pool2 = resnet_model.forward_crops_u8(crops, return_pool=True)
+    assert tuple(pool.shape) == (5, 2048) and torch.equal(p, p2) and torch.equal(pool, pool2)
 
 
 def test_get_all_outputs_shapes_and_consistency(model):
     """get_all_outputs with supplied detections: types/shapes of reference synergy3DMM.py:167-207 and
     agreement with the batched calls on the same crops."""
     from synergynet_amd import synth
-    from synergynet_amd.inference import crop_img, resize_lanczos4
+    from oracle.preproc_numpy import crop_img, resize_lanczos4
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
     rects = [[100.0, 80.0, 260.0, 270.0, 0.99], [400.0, 200.0, 560.0, 420.0, 0.95]]   # second one overhangs the border
@@ -359,10 +413,11 @@ def test_resnet50_matches_reference_golden_and_oracle(resnet_model):
 
 
 def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
-    """syn_crop_resize (row f-1) vs synergynet_amd.inference.crop_img + resize_lanczos4 on boxes that overhang every
+    """syn_crop_resize (row f-1) vs oracle.preproc_numpy.crop_img + resize_lanczos4 on boxes that overhang every
     border of the frame, and get_all_outputs' landmarks vs the batched path on those host-made crops."""
     import torch
-    from synergynet_amd.inference import crop_img, lanczos4_tables, resize_lanczos4
+    from oracle.preproc_numpy import crop_img, resize_lanczos4
+    from synergynet_amd.inference import lanczos4_tables
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, size=(360, 500, 3), dtype=np.uint8)
     boxes = np.array([[40, 30, 300, 290], [-35, -20, 140, 155], [380, 250, 560, 430], [100, 100, 220, 220], [200, -50, 421, 171]], np.int32)

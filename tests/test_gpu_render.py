@@ -106,6 +106,17 @@ def test_full_size_batch_pipeline_vs_reference_golden_and_oracle(rmodel, rgold):
     # the list-of-(3,N)-arrays entry of utils/render.py gives the same image
     res2 = sim3dr.render(img, [meshes[f] for f in range(meshes.shape[0])], alpha=0.6)
     assert np.array_equal(res2, res)
+    # the row-pitched view reconstruct() returns ([F,3,53248][:, :, :53215]) is consumed in place -- no packed copy on the
+    # device path -- and gives the same bits; pad columns full of NaN must not matter
+    F, _, n = meshes.shape
+    store = torch.full((F, 3, (n + 127) // 128 * 128), float('nan'), device='cuda')
+    pitched = store[:, :, :n]
+    pitched.copy_(torch.from_numpy(meshes))
+    assert not pitched.is_contiguous()
+    ov4, res4 = sim3dr.render_batch(rmodel, img, pitched, alpha=0.6)
+    assert np.array_equal(ov4.cpu().numpy(), overlap) and np.array_equal(res4.cpu().numpy(), res)
+    with pytest.raises(RuntimeError, match='pitched rows'):
+        sim3dr.render_batch(rmodel, img, torch.from_numpy(meshes).cuda().permute(0, 2, 1).contiguous().permute(0, 2, 1), alpha=0.6)
 
 
 def test_reference_package_name_is_served(rmodel, rgold):

@@ -115,7 +115,7 @@ def test_params_pack_mirror(pack, tmp_path):
 
 
 def test_crop_img_zero_pads_like_reference():
-    from synergynet_amd.inference import crop_img
+    from oracle.preproc_numpy import crop_img
     img = np.arange(10 * 12 * 3, dtype=np.uint8).reshape(10, 12, 3)
     c = crop_img(img, [-2.4, -1.6, 5.2, 4.4, 1.0])          # rounds to [-2,-2,5,4]
     assert c.shape == (6, 7, 3)
@@ -126,7 +126,7 @@ def test_crop_img_zero_pads_like_reference():
 
 
 def test_resize_lanczos4_basic_properties():
-    from synergynet_amd.inference import resize_lanczos4
+    from oracle.preproc_numpy import resize_lanczos4
     flat = np.full((200, 170, 3), 97, np.uint8)
     assert (resize_lanczos4(flat, 120, 120) == 97).all()     # partition of unity
     rng = np.random.default_rng(0)

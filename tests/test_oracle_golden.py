@@ -86,3 +86,33 @@ def test_resnet50_oracle_matches_reference():
     assert out.shape == (2, 102) and pool.shape == (2, 2048)
     assert rel_max(out.numpy(), g['out102']) < TOL
     assert rel_max(pool.numpy(), g['pool']) < TOL
+
+
+def test_pose_matrix_and_crop_oracles_match_reference(golden, pack):
+    """predict_pose(..., ret_mat=True) and crop_img of the REAL reference (tests/golden/pose_mat_golden.npz, made by
+    make_golden.py main_pose_mat) vs oracle/recon_numpy.pose_matrix and oracle/preproc_numpy.crop_img."""
+    from oracle import preproc_numpy
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pose_mat_golden.npz'))
+    b = recon_numpy.Basis(pack)
+    got = np.stack([recon_numpy.pose_matrix(b, p.copy()) for p in golden['params']])
+    assert got.shape == g['pose_mat'].shape == (golden['params'].shape[0], 3, 4)
+    assert np.abs(got[:, :, :3] - g['pose_mat'][:, :, :3]).max() < 1e-6          # rotation entries are O(1)
+    assert rel_max(got[:, :, 3], g['pose_mat'][:, :, 3]) < TOL
+    hh, ww, seed = [int(v) for v in g['crop_frame_hw_seed']]
+    frame = synth.make_frame(hh, ww, seed=seed)
+    for bx, shp, s0, s1 in zip(g['crop_boxes'], g['crop_shapes'], g['crop_sums'], g['crop_weighted']):
+        c = preproc_numpy.crop_img(frame, list(bx))
+        assert tuple(c.shape) == tuple(shp)
+        assert int(c.astype(np.int64).sum()) == int(s0)
+        assert int((c.astype(np.int64).reshape(-1) * (np.arange(c.size) % 251 + 1)).sum()) == int(s1)
+
+
+def test_product_lanczos_tables_equal_the_oracle_taps():
+    """The tap tables the product hands to syn_crop_resize (synergynet_amd/inference.py, per-index loop) vs the oracle's
+    vectorised restatement of the same published algorithm, for every crop size a detection can produce."""
+    from oracle import preproc_numpy
+    from synergynet_amd.inference import lanczos4_tables
+    for n_src in list(range(1, 260)) + [333, 480, 719, 1024, 2047]:
+        first, fixed = preproc_numpy.lanczos4_taps(120, n_src)
+        x0, c = lanczos4_tables(n_src)
+        assert np.array_equal(x0, first.astype(np.int32)) and np.array_equal(c, fixed.astype(np.int16)), n_src
