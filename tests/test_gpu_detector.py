@@ -81,7 +81,15 @@ def test_detections_match_oracle_including_downscaled_frames(det, hw):
     assert got.shape == want.shape
     if want.shape[0]:
         np.testing.assert_allclose(got[:, 4], want[:, 4], rtol=0, atol=2e-5)
-        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=0, atol=5e-2)
+        # same detections in the same order, except that rows whose scores agree to within the score tolerance may swap places
+        # (the oracle's torch-CPU scores and the device's differ in the last bits, so a near-tie can sort either way)
+        used = np.zeros(want.shape[0], dtype=bool)
+        for i, row in enumerate(got):
+            near = np.where(~used & (np.abs(want[:, 4] - row[4]) <= 4e-5))[0]
+            hit = [j for j in near if np.abs(want[j, :4] - row[:4]).max() <= 5e-2]
+            assert hit, f'detection {i} {row} has no counterpart among the oracle rows of the same score'
+            assert abs(hit[0] - i) <= 3, f'detection {i} found at oracle rank {hit[0]}'
+            used[hit[0]] = True
     rects = det(frame)
     assert rects == [[b[0], b[1], b[2], b[3], b[4]] for b in got if b[4] > 0.5]
     # activations / candidate lists of the previous frame overwritten with NaN bytes (test hook): identical detections
