@@ -1,0 +1,383 @@
+// Row-marching fused inverted-residual block for the EARLY MobileNetV2 blocks (features.2-4), second generation.
+// Reference: backbone_nets/mobilenetv2_backbone.py:45-74 (InvertedResidual.forward), :33-42 (ConvBNReLU).
+//
+// The tiled kernel (fused_block_early.hip) moves every activation through LDS twice (expand -> Es -> depthwise -> D planes ->
+// project) behind two workgroup barriers per hidden chunk: LDS-array cycles and barrier stalls are ~2/3 of its time
+// (profiles/r2).  Here the hidden activations never leave registers:
+//
+//   * one WAVE owns 32 hidden channels ("group") of one face and marches down the image row by row;
+//   * expand runs on v_mfma_f32_32x32x16_bf16 (exact 3-way bf16 split, 6 partial products) with the hidden channels as the
+//     A rows and ONE IMAGE ROW as the 32 B columns: lane (j = l&31, h = l>>5) then holds 16 hidden channels
+//     {0-3, 8-11, 16-19, 24-27} + 4h of pixel j -- the horizontal neighbours of a pixel are the neighbouring LANES
+//     (v_mov_dpp wave_shr:1 / wave_shl:1), the vertical ones are earlier / later rows of the same lane;
+//   * the depthwise 3x3 is "scattered": a fresh expand row adds its three kernel rows into the accumulators of the (up to)
+//     three output rows it touches, so only accumulators are live, never a window of expanded rows;
+//   * a finished depthwise row is ReLU6'ed, split into its three bf16 pieces IN PLACE -- with K-slot (h, e) := register
+//     8s+e the D layout of one MFMA IS the B operand of the next (the host packs the project weights in that K order) --
+//     and projected (12 MFMAs) to a partial sum over this wave's 32 hidden channels;
+//   * the only LDS traffic is: the block-input row as pre-split B fragments (written once per row by a rotating owner wave,
+//     read by every wave), the per-wave partial sums (reduced in fixed wave order by a rotating duty wave, which adds the BN
+//     shift and the residual and stores the NHWC row) and broadcast reads of the depthwise filter; ONE barrier per input row.
+//
+//   stride 2: an input row is two column blocks, U = odd columns (-1, 1, 3, ...) and V = even columns, so that output pixel x
+//   needs U[x], V[x] (same lane) and U[x+1] (wave_shl:1); features.4 (15-wide output) puts TWO faces side by side in a block.
+//   Zero padding costs nothing: out-of-image lanes get ReLU6 ceiling 0 (v_med3), missing rows are simply not added.
+#include "syn_internal.h"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int cdivr(int a, int b) { return (a + b - 1) / b; }
+
+// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
+__device__ __forceinline__ void split2r(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mfma32r(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six partial products of weight >= 2^-16, smallest terms first (same order as the other bf16x3 kernels)
+__device__ __forceinline__ f32x16 mac6r(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+    c = mfma32r(a[2], b[0], c);
+    c = mfma32r(a[0], b[2], c);
+    c = mfma32r(a[1], b[1], c);
+    c = mfma32r(a[1], b[0], c);
+    c = mfma32r(a[0], b[1], c);
+    c = mfma32r(a[0], b[0], c);
+    return c;
+}
+// lane j <- lane j-1 / lane j+1 across the whole wave (lanes 0 / 32 resp. 31 / 63 receive a neighbour half's or no value:
+// they are padding columns whose results are never stored)
+__device__ __forceinline__ float from_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+}  // namespace
+
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_>
+struct RmCfg {
+    static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_;
+    static constexpr bool RES = RES_;
+    static constexpr int KS = cdivr(CIN, 16);            // k16 steps of the expand GEMM
+    static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = waves of a workgroup
+    static constexpr int HIDP = NG * 32;
+    static constexpr int NQ = COUT / 8;                  // valid register quads of the 32-row project tile
+    static constexpr int NB = S == 1 ? 1 : 2;            // column blocks per input row
+    static constexpr int HO = S == 2 ? H / 2 : H;
+    static constexpr int NW = NG, NT = NW * 64;
+    static constexpr int FR = NB * KS;                   // block-input fragments per input row (one owner wave each)
+    static constexpr int XP_DW = FR * 3 * 256, PART_DW = NW * NQ * 256;
+    static constexpr int LDS_DW = 2 * XP_DW + 2 * PART_DW + 11 * HIDP + 32;
+    static_assert(COUT % 8 == 0 && COUT <= 32, "project tile");
+    static_assert(S == 1 || H % 2 == 0, "stride-2 blocks have even input sizes");
+    static_assert(S == 1 ? (H + 2 <= 32 && NF == 1) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
+    static_assert(FR <= NW, "one fragment per wave and row");
+    static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
+    static_assert(S == 2 || H % 3 == 0, "row ring unrolled by 3");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
+void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][3][64][4]*/,
+                           const unsigned *__restrict__ Ap3 /*[NG][2][3][64][4]*/, const float *__restrict__ e_shift,
+                           const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
+                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    unsigned *Xp = smem;                                                      // [2][FR][3][64][4]
+    float *Part = reinterpret_cast<float *>(smem + 2 * C::XP_DW);             // [2][NW][NQ][64][4]
+    float *Filt = Part + 2 * C::PART_DW;                                      // [9][HIDP]
+    float *Dsh = Filt + 9 * C::HIDP, *Esh = Dsh + C::HIDP, *Psh = Esh + C::HIDP;   // [HIDP], [HIDP], [32]
+    constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
+
+    for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] : 0.f; }
+    for (int i = tid; i < C::HIDP; i += NT) { Dsh[i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
+    if (tid < 32) Psh[tid] = tid < C::COUT ? p_shift[tid] : 0.f;
+    // this wave's weight fragments stay in registers for the whole (persistent) kernel
+    u32x4 ae[C::KS][3], ap[2][3];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 3 + p) * 256 + lane * 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
+
+    // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
+    int ia, icol[C::NB], oa, ocol;
+    if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
+    else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
+    else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
+    __syncthreads();
+
+    f32x4 dsh4[4];                               // depthwise BN shift in D-register order (accumulator start)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dsh4[q] = *(const f32x4 *)&Dsh[cb + 8 * q];
+
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int f_in = unit * C::NF + ia, f_out = unit * C::NF + oa;
+        float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? 6.0f : 0.0f;
+        const bool out_ok = (unsigned)ocol < (unsigned)HO && f_out < B;
+
+        // ---- block-input fragments: frag = b*KS + s = channels 16s + 8h .. +7 of the pixels of block b ----
+        f32x4 xr[2];
+        auto frag_of = [&](int y) { return (wave - y % NW + NW) % NW; };             // the fragment of row y this wave owns (>= FR: none)
+        auto load_frag = [&](int y, int frag) {
+            const int b = frag / C::KS, s = frag % C::KS, c0 = 16 * s + 8 * h;
+            xr[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xr[1] = xr[0];
+            if (c0 + 8 <= C::CIN && (unsigned)icol[b] < (unsigned)H && f_in < B) {
+                const float *src = X + ((size_t)(f_in * H + y) * H + icol[b]) * C::CIN + c0;
+                xr[0] = *(const f32x4 *)src; xr[1] = *(const f32x4 *)(src + 4);
+            }
+        };
+        auto store_frag = [&](int slot, int frag) {
+            u32x4 pc[3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split2r(xr[t][0], xr[t][1], h0, m0, l0);
+                split2r(xr[t][2], xr[t][3], h1, m1, l1);
+                pc[0][2 * t] = h0; pc[0][2 * t + 1] = h1; pc[1][2 * t] = m0; pc[1][2 * t + 1] = m1; pc[2][2 * t] = l0; pc[2][2 * t + 1] = l1;
+            }
+            unsigned *dst = Xp + (size_t)slot * C::XP_DW + frag * 768 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
+        };
+        // ---- expand one block of the row in slot `slot`: 16 hidden channels per lane, BN shift, ReLU6 (0 on padding lanes) ----
+        auto expand = [&](int slot, int b, f32x16 &e, int cbo) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sh = *(const f32x4 *)&Esh[cbo + 8 * q];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e[4 * q + t] = sh[t];
+            }
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                u32x4 xb[3];
+                const unsigned *src = Xp + (size_t)slot * C::XP_DW + (b * C::KS + s) * 768 + lane * 4;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xb[p] = *(const u32x4 *)(src + p * 256);
+                e = mac6r(ae[s], xb, e);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehi[b]);
+        };
+        // ---- finished depthwise row -> ReLU6 -> bf16 x3 pieces (in place: register 8s+e = K slot e of step s) -> project
+        //      partial over this wave's 32 hidden channels -> LDS ----
+        auto finalize = [&](f32x16 &d, int pslot) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 db[3];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
+                    unsigned hh, mm, ll;
+                    split2r(v0, v1, hh, mm, ll);
+                    db[0][t] = hh; db[1][t] = mm; db[2][t] = ll;
+                }
+                acc = mac6r(ap[s], db, acc);
+            }
+            float *dst = Part + (size_t)pslot * C::PART_DW + (size_t)wave * C::NQ * 256 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) *(f32x4 *)(dst + q * 256) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        };
+        // ---- duty wave: partial sums of all waves in fixed order + BN shift (+ residual) -> NHWC row ----
+        auto reduce_store = [&](int yo, int pslot) {
+            f32x4 res[C::NQ];
+            if (C::RES) {
+#pragma unroll
+                for (int q = 0; q < C::NQ; ++q) {
+                    res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (out_ok) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < C::NQ; ++q) {
+                f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
+                const float *src = Part + (size_t)pslot * C::PART_DW + q * 256 + lane * 4;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += *(const f32x4 *)(src + (size_t)w * C::NQ * 256);
+                if (C::RES) v += res[q];
+                if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
+            }
+        };
+
+        // prologue: row 0 of this unit -> slot 0
+        {
+            const int fr = frag_of(0);
+            if (fr < C::FR) { load_frag(0, fr); store_frag(0, fr); }
+        }
+        __syncthreads();
+
+        if (C::S == 1) {
+            f32x16 d0, d1, d2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { d0[r] = dsh4[r >> 2][r & 3]; d1[r] = 0.f; d2[r] = 0.f; }     // output row 0 starts at the BN shift
+            auto step = [&](int y, f32x16 &dm, f32x16 &dc, f32x16 &dn) {          // input row y -> output rows y-1 (dm), y (dc), y+1 (dn)
+                const int fr = frag_of(y + 1);
+                const bool own = fr < C::FR && y + 1 < H;
+                if (own) load_frag(y + 1, fr);
+                // the filter / shift reads below are loop invariant; an opaque base keeps the compiler from hoisting 150 registers'
+                // worth of them out of the row loop (and spilling them)
+                int cbo = cb;
+                asm volatile("" : "+v"(cbo));
+                f32x16 e;
+                expand(y & 1, 0, e, cbo);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 c4, l4, r4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; l4[t] = from_left(c4[t]); r4[t] = from_right(c4[t]); }
+                    const float *wq = Filt + cbo + 8 * q;
+                    f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w1 = *(const f32x4 *)(wq + 1 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dn[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dsh4[q][t])));
+                    w0 = *(const f32x4 *)(wq + 3 * C::HIDP); w1 = *(const f32x4 *)(wq + 4 * C::HIDP); w2 = *(const f32x4 *)(wq + 5 * C::HIDP);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dc[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dc[4 * q + t])));
+                    w0 = *(const f32x4 *)(wq + 6 * C::HIDP); w1 = *(const f32x4 *)(wq + 7 * C::HIDP); w2 = *(const f32x4 *)(wq + 8 * C::HIDP);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dm[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dm[4 * q + t])));
+                    // pin the updates here: otherwise the compiler sinks the dc / dn FMAs into the next step (where their results are
+                    // first read) and keeps their 3x4 operands + 6 filter quads alive across the barrier instead
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dn[4 * q + t]), "+v"(dc[4 * q + t]), "+v"(dm[4 * q + t]));
+                }
+                if (y >= 1) finalize(dm, (y - 1) & 1);
+                if (own) store_frag((y + 1) & 1, fr);
+                __syncthreads();
+                if (y >= 1 && (y - 1) % NW == wave) reduce_store(y - 1, (y - 1) & 1);
+            };
+            for (int y = 0; y < H; y += 3) {
+                step(y, d2, d0, d1);
+                step(y + 1, d0, d1, d2);
+                step(y + 2, d1, d2, d0);
+            }
+            // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
+            finalize(d2, (H - 1) & 1);
+            __syncthreads();
+            if ((H - 1) % NW == wave) reduce_store(H - 1, (H - 1) & 1);
+        } else {
+            f32x16 dcur, dnext;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dcur[r] = dsh4[r >> 2][r & 3];
+            for (int y = 0; y < H; y += 2) {
+                const int yo = y >> 1;
+                // ---- even input row 2yo: kernel row 1 of output row yo ----
+                {
+                    const int fr = frag_of(y + 1);
+                    const bool own = fr < C::FR;
+                    if (own) load_frag(y + 1, fr);
+                    int cbo = cb;
+                    asm volatile("" : "+v"(cbo));
+                    f32x16 e;
+                    expand(y & 1, 0, e, cbo);                                // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float *wq = Filt + cbo + 8 * q;
+                        const f32x4 w0 = *(const f32x4 *)(wq + 3 * C::HIDP), w2 = *(const f32x4 *)(wq + 5 * C::HIDP);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(from_right(e[4 * q + t]), w2[t], __builtin_fmaf(e[4 * q + t], w0[t], dcur[4 * q + t]));
+                    }
+                    expand(y & 1, 1, e, cbo);                                // V: column 2x (tap 4)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 w1 = *(const f32x4 *)(Filt + cbo + 8 * q + 4 * C::HIDP);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dcur[4 * q + t]);
+                    }
+                    if (own) store_frag((y + 1) & 1, fr);
+                    __syncthreads();
+                }
+                // ---- odd input row 2yo+1: kernel row 2 of output row yo, kernel row 0 of output row yo+1 ----
+                {
+                    const int fr = frag_of(y + 2);
+                    const bool own = fr < C::FR && y + 2 < H;
+                    if (own) load_frag(y + 2, fr);
+                    int cbo = cb;
+                    asm volatile("" : "+v"(cbo));
+                    f32x16 e;
+                    expand((y + 1) & 1, 0, e, cbo);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float *wq = Filt + cbo + 8 * q;
+                        const f32x4 w6 = *(const f32x4 *)(wq + 6 * C::HIDP), w8 = *(const f32x4 *)(wq + 8 * C::HIDP);
+                        const f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float c = e[4 * q + t], r = from_right(c);
+                            dcur[4 * q + t] = __builtin_fmaf(r, w8[t], __builtin_fmaf(c, w6[t], dcur[4 * q + t]));
+                            dnext[4 * q + t] = __builtin_fmaf(r, w2[t], __builtin_fmaf(c, w0[t], dsh4[q][t]));
+                        }
+                    }
+                    expand((y + 1) & 1, 1, e, cbo);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float *wq = Filt + cbo + 8 * q;
+                        const f32x4 w7 = *(const f32x4 *)(wq + 7 * C::HIDP), w1 = *(const f32x4 *)(wq + 1 * C::HIDP);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w7[t], dcur[4 * q + t]);
+                            dnext[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dnext[4 * q + t]);
+                        }
+                    }
+                    finalize(dcur, yo & 1);
+                    dcur = dnext;
+                    if (own) store_frag((y + 2) & 1, fr);
+                    __syncthreads();
+                    if (yo % NW == wave) reduce_store(yo, yo & 1);
+                }
+            }
+        }
+        // no barrier here: the next unit's prologue writes Xp slot 0, whose last readers passed two barriers ago, and the Part
+        // slot the last duty wave is still reading is next written two barriers into the next unit -- barriers that wave must
+        // pass too, after its reads
+    }
+}
+
+template <class C>
+static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
+    const int n_units = (B + C::NF - 1) / C::NF;
+    const int cap = 256 * wgs_per_cu;                       // persistent: as many workgroups as the CUs hold at once
+    const int grid = n_units < cap ? n_units : cap;
+    fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units);
+}
+
+//                  CIN  HID COUT  H  S NF  RES   waves/SIMD
+using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 2>;    // features.2   60 -> 30      3 waves per workgroup
+using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  2>;    // features.3   30            5 waves
+using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 2>;    // features.4   30 -> 15      5 waves, two faces per workgroup
+
+bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
+    if (!a.Arm_e || !a.Arm_p || a.prof) return false;
+    switch (feature) {
+        case 2: launch_rm<R2>(a, B, s, 4); return true;
+        case 3: launch_rm<R3>(a, B, s, 2); return true;
+        case 4: launch_rm<R4>(a, B, s, 2); return true;
+        default: return false;
+    }
+}
+
+}  // namespace syn

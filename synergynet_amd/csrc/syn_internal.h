@@ -46,12 +46,21 @@ struct FusedBlockArgs {
     float *Y;                                         // block output NHWC
     unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
     const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
+    const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of
 // early_block_hc(HID) channels, each zero padded to a multiple of 32 in the project GEMM's K: the host packs Wp3 that way.
 constexpr int early_block_hc(int hid) { return hid % 32 == 0 ? 32 : 48; }
 bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// early blocks, row-marching schedule (fused_block_rm.hip): hidden activations stay in registers, one wave per 32 hidden channels.
+// Weight fragments for v_mfma_f32_32x32x16_bf16 (lane (i = l&31, hh = l>>5) holds 8 K slots), [group][k16 step][piece 3][lane 64][4 dwords]:
+//   expand  Arm_e: row i = hidden channel 32g + i, slot e of step s = input channel 16s + 8hh + e        (ceil(CIN/16) steps)
+//   project Arm_p: row i = output channel i,       slot e of step s = hidden channel 32g + 16s + 8(e>>2) + 4hh + (e&3)   (2 steps)
+// -- the project K order is the register order in which the expand / depthwise stage leaves a lane's 16 channels.
+constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 768; }
+constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 768; }
+bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 

@@ -56,6 +56,7 @@ struct Layer {
     size_t dst_w, dst_scale, dst_shift;   // offsets (floats) into the packed device blob
     size_t dst_wpk;      // PW layers of fused blocks: weights in MFMA lane order (fused_block.hip)
     size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
+    size_t dst_wrm;      // PW layers of features.2-4: fragments of the row-marching kernel (fused_block_rm.hip), or 0
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -123,6 +124,11 @@ struct Net {
                 const int hc = L.relu6 ? L.cin : syn::early_block_hc(L.cin);
                 const int steps = (L.relu6 ? 1 : L.cin / hc) * (round_up(hc, 32) / 32);
                 dst += (size_t)(round_up(L.cout, 16) / 16) * steps * 768;
+            }
+            L.dst_wrm = 0;
+            if (L.kind == PW && L.feature >= 2 && L.feature <= 4) {
+                L.dst_wrm = dst;
+                dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
             }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
@@ -249,6 +255,8 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
+    int early_rm = 7;              // SYNERGY_HIP_EARLY_RM: bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel
+                                   // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
                                    // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
 };
@@ -408,7 +416,12 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
             }
-            if ((a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
+            if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature - 2)) & 1)) {
+                a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
+                a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
+            }
+            if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
+                (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
                 syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
@@ -509,6 +522,7 @@ int syn_create(int device, syn_handle **out) {
     syn_handle *h = new syn_handle();
     h->device = device;
     if (const char *e = getenv("SYNERGY_HIP_FUSION")) h->fusion = atoi(e);
+    if (const char *e = getenv("SYNERGY_HIP_EARLY_RM")) h->early_rm = atoi(e);
     *out = h;
     return SYN_OK;
 }
@@ -638,6 +652,39 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                             }
                             for (int pcs = 0; pcs < 3; ++pcs)
                                 dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                        }
+        }
+        if (L.dst_wrm) {                 // row-marching early blocks: v_mfma_f32_32x32x16_bf16 fragments (syn_internal.h)
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            const bool expand = L.relu6 != 0;
+            const int hid = expand ? L.cout : L.cin, ng = (hid + 31) / 32, ks = expand ? (L.cin + 15) / 16 : 2;
+            for (int g = 0; g < ng; ++g)
+                for (int st = 0; st < ks; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            const int i = lane & 31, hh = lane >> 5;
+                            for (int e = 0; e < 2; ++e) {
+                                const int sl = 2 * d + e;
+                                float v = 0.f;
+                                if (expand) {
+                                    const int ch = 32 * g + i, k = 16 * st + 8 * hh + sl;
+                                    if (ch < L.cout && k < L.cin) v = w[(size_t)ch * L.cin + k] * bn_scale[ch];
+                                } else {
+                                    const int c = 32 * g + 16 * st + 8 * (sl >> 2) + 4 * hh + (sl & 3);
+                                    if (i < L.cout && c < L.cin) v = w[(size_t)i * L.cin + c] * bn_scale[i];
+                                }
+                                split(v, pc[e]);
+                            }
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[(((size_t)(g * ks + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
         }
         for (int c = 0; c < L.cout; ++c) {
