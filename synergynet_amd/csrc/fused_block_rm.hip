@@ -24,6 +24,8 @@
 //   Zero padding costs nothing: out-of-image lanes get ReLU6 ceiling 0 (v_med3), missing rows are simply not added.
 #include "syn_internal.h"
 
+#include <cstdlib>
+
 namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,9 +69,9 @@ __device__ __forceinline__ float from_right(float v) {
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_>
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_>
 struct RmCfg {
-    static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_;
+    static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
     static constexpr int KS = cdivr(CIN, 16);            // k16 steps of the expand GEMM
     static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = waves of a workgroup
@@ -77,10 +79,14 @@ struct RmCfg {
     static constexpr int NQ = COUT / 8;                  // valid register quads of the 32-row project tile
     static constexpr int NB = S == 1 ? 1 : 2;            // column blocks per input row
     static constexpr int HO = S == 2 ? H / 2 : H;
-    static constexpr int NW = NG, NT = NW * 64;
+    // A workgroup carries U independent units (a unit = NF faces marching together), NG waves each, on one barrier: the
+    // hardware reserves ceil(waves / 4) wave slots on EVERY SIMD per workgroup, so two 5-wave workgroups do not share a CU at 3
+    // waves per SIMD -- one 10- or 12-wave workgroup does.
+    static constexpr int NW = NG, NT = U * NW * 64;
     static constexpr int FR = NB * KS;                   // block-input fragments per input row (one owner wave each)
     static constexpr int XP_DW = FR * 3 * 256, PART_DW = NW * NQ * 256;
-    static constexpr int LDS_DW = 2 * XP_DW + 2 * PART_DW + 11 * HIDP + 32;
+    static constexpr int UNIT_DW = 2 * XP_DW + 2 * PART_DW;
+    static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32;     // X fragments | partial sums | filter 9 rows + depthwise shift | expand shift | project shift
     static_assert(COUT % 8 == 0 && COUT <= 32, "project tile");
     static_assert(S == 1 || H % 2 == 0, "stride-2 blocks have even input sizes");
     static_assert(S == 1 ? (H + 2 <= 32 && NF == 1) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
@@ -89,20 +95,28 @@ struct RmCfg {
     static_assert(S == 2 || H % 3 == 0, "row ring unrolled by 3");
 };
 
-template <class C>
+#define SYNR_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+
+template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
 void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][3][64][4]*/,
                            const unsigned *__restrict__ Ap3 /*[NG][2][3][64][4]*/, const float *__restrict__ e_shift,
                            const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
-                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units) {
+                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units,
+                           unsigned long long *prof = nullptr) {
+    // PROF: s_memtime sums of wave 0 per phase {fragment loads / duty begin, expand, fragment store + reduce, depthwise, finalize,
+    // barrier wait, (unused)} and the number of row steps (syn_debug_profile_block)
+    unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, nsteps = 0;
+    const unsigned long long t_begin = tk;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
-    unsigned *Xp = smem;                                                      // [2][FR][3][64][4]
-    float *Part = reinterpret_cast<float *>(smem + 2 * C::XP_DW);             // [2][NW][NQ][64][4]
-    float *Filt = Part + 2 * C::PART_DW;                                      // [9][HIDP]
-    float *Dsh = Filt + 9 * C::HIDP, *Esh = Dsh + C::HIDP, *Psh = Esh + C::HIDP;   // [HIDP], [HIDP], [32]
-    constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int uw = wave_wg / C::NW, wave = wave_wg % C::NW;                   // unit inside the workgroup, hidden group inside the unit
+    unsigned *Xp = smem + uw * C::UNIT_DW;                                    // per unit: [2][FR][3][64][4]
+    float *Part = reinterpret_cast<float *>(Xp + 2 * C::XP_DW);               // per unit: [2][NW][NQ][64][4]
+    float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);        // [9][HIDP], shared
+    float *Dsh = Filt + 9 * C::HIDP, *Esh = Dsh + C::HIDP, *Psh = Esh + C::HIDP;   // [HIDP] (= Filt row 9), [HIDP], [32]
+    constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
     const int j = lane & 31, h = lane >> 5;
     const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
 
@@ -127,11 +141,12 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
     __syncthreads();
 
-    f32x4 dsh4[4];                               // depthwise BN shift in D-register order (accumulator start)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dsh4[q] = *(const f32x4 *)&Dsh[cb + 8 * q];
+    constexpr int DSH = 9 * C::HIDP;             // Filt row 9 = depthwise BN shift (accumulator start)
 
-    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
+    // stores nothing (its faces are >= B)
+    for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
+        const int unit = ub + uw;
         const int f_in = unit * C::NF + ia, f_out = unit * C::NF + oa;
         float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
 #pragma unroll
@@ -203,9 +218,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int q = 0; q < C::NQ; ++q) *(f32x4 *)(dst + q * 256) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         };
-        // ---- duty wave: partial sums of all waves in fixed order + BN shift (+ residual) -> NHWC row ----
-        auto reduce_store = [&](int yo, int pslot) {
-            f32x4 res[C::NQ];
+        // ---- duty wave: partial sums of all waves in fixed order + BN shift (+ residual) -> NHWC row.  Split in two so that the
+        //      residual's global load is in flight while the next row's expand MFMAs run, and nothing of it is live in the
+        //      depthwise phase (the register peak) ----
+        f32x4 res[C::RES ? C::NQ : 1];
+        auto reduce_begin = [&](int yo) {
             if (C::RES) {
 #pragma unroll
                 for (int q = 0; q < C::NQ; ++q) {
@@ -213,6 +230,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     if (out_ok) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
                 }
             }
+        };
+        auto reduce_store = [&](int yo, int pslot) {
 #pragma unroll
             for (int q = 0; q < C::NQ; ++q) {
                 f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
@@ -222,6 +241,23 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 if (C::RES) v += res[q];
                 if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
             }
+        };
+        // three taps of one kernel row into one accumulator quad; `init`: the accumulator starts at the BN shift (Filt row 9)
+        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+            const f32x4 w0 = *(const f32x4 *)(wq + (3 * ky + 0) * C::HIDP), w1 = *(const f32x4 *)(wq + (3 * ky + 1) * C::HIDP),
+                        w2 = *(const f32x4 *)(wq + (3 * ky + 2) * C::HIDP);
+            f32x4 base;
+            if (init) base = *(const f32x4 *)(wq + DSH);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b0 = init ? base[t] : d[4 * q + t];
+                d[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0)));
+            }
+            // pin the update here: otherwise the compiler sinks these FMAs to where the accumulator is next read (the following
+            // row's step) and keeps their operands + filter quads alive across the barrier instead
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
+            __builtin_amdgcn_sched_barrier(0);
         };
 
         // prologue: row 0 of this unit -> slot 0
@@ -233,73 +269,105 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 
         if (C::S == 1) {
             f32x16 d0, d1, d2;
+            {
+                int cbo = cb;
+                asm volatile("" : "+v"(cbo));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { d0[r] = dsh4[r >> 2][r & 3]; d1[r] = 0.f; d2[r] = 0.f; }     // output row 0 starts at the BN shift
-            auto step = [&](int y, f32x16 &dm, f32x16 &dc, f32x16 &dn) {          // input row y -> output rows y-1 (dm), y (dc), y+1 (dn)
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sh = *(const f32x4 *)(Filt + cbo + 8 * q + DSH);      // output row 0 starts at the BN shift
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { d0[4 * q + t] = sh[t]; d1[4 * q + t] = 0.f; d2[4 * q + t] = 0.f; }
+                }
+            }
+            // input row y -> kernel row 2 of output row y-1 (dm), row 1 of y (dc), row 0 of y+1 (dn).  `rduty`: this wave reduces
+            // output row y-2, whose partial sums were completed by the barrier that ended the previous step.
+            auto step = [&](int y, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
                 const int fr = frag_of(y + 1);
                 const bool own = fr < C::FR && y + 1 < H;
+                const bool rduty = y >= 2 && (y - 2) % NW == wave;
+                SYNR_LAP(5);
                 if (own) load_frag(y + 1, fr);
+                if (rduty) reduce_begin(y - 2);
+                SYNR_LAP(0);
                 // the filter / shift reads below are loop invariant; an opaque base keeps the compiler from hoisting 150 registers'
                 // worth of them out of the row loop (and spilling them)
                 int cbo = cb;
                 asm volatile("" : "+v"(cbo));
                 f32x16 e;
                 expand(y & 1, 0, e, cbo);
+                SYNR_LAP(1);
+                if (own) store_frag((y + 1) & 1, fr);            // slot (y+1)&1 was last read in step y-1
+                if (rduty) reduce_store(y - 2, y & 1);
+                SYNR_LAP(2);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 c4, l4, r4;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; l4[t] = from_left(c4[t]); r4[t] = from_right(c4[t]); }
                     const float *wq = Filt + cbo + 8 * q;
-                    f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w1 = *(const f32x4 *)(wq + 1 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dn[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dsh4[q][t])));
-                    w0 = *(const f32x4 *)(wq + 3 * C::HIDP); w1 = *(const f32x4 *)(wq + 4 * C::HIDP); w2 = *(const f32x4 *)(wq + 5 * C::HIDP);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dc[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dc[4 * q + t])));
-                    w0 = *(const f32x4 *)(wq + 6 * C::HIDP); w1 = *(const f32x4 *)(wq + 7 * C::HIDP); w2 = *(const f32x4 *)(wq + 8 * C::HIDP);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dm[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], dm[4 * q + t])));
-                    // pin the updates here: otherwise the compiler sinks the dc / dn FMAs into the next step (where their results are
-                    // first read) and keeps their 3x4 operands + 6 filter quads alive across the barrier instead
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dn[4 * q + t]), "+v"(dc[4 * q + t]), "+v"(dm[4 * q + t]));
+                    taps3(dn, q, wq, 0, l4, c4, r4, true);
+                    taps3(dc, q, wq, 1, l4, c4, r4, false);
+                    taps3(dm, q, wq, 2, l4, c4, r4, false);
                 }
+                SYNR_LAP(3);
                 if (y >= 1) finalize(dm, (y - 1) & 1);
-                if (own) store_frag((y + 1) & 1, fr);
+                SYNR_LAP(4);
                 __syncthreads();
-                if (y >= 1 && (y - 1) % NW == wave) reduce_store(y - 1, (y - 1) & 1);
+                SYNR_LAP(5);
+                nsteps += 1;
             };
             for (int y = 0; y < H; y += 3) {
                 step(y, d2, d0, d1);
                 step(y + 1, d0, d1, d2);
                 step(y + 2, d1, d2, d0);
             }
-            // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
+            // output row H-2 was completed by the last barrier; the last output row has no input row below it: complete as it is
+            // ((H-1) % 3 == 2 -> d2)
+            if ((H - 2) % NW == wave) { reduce_begin(H - 2); reduce_store(H - 2, (H - 2) & 1); }
             finalize(d2, (H - 1) & 1);
             __syncthreads();
-            if ((H - 1) % NW == wave) reduce_store(H - 1, (H - 1) & 1);
+            if ((H - 1) % NW == wave) { reduce_begin(H - 1); reduce_store(H - 1, (H - 1) & 1); }
         } else {
             f32x16 dcur, dnext;
+            {
+                int cbo = cb;
+                asm volatile("" : "+v"(cbo));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dcur[r] = dsh4[r >> 2][r & 3];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 sh = *(const f32x4 *)(Filt + cbo + 8 * q + DSH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { dcur[4 * q + t] = sh[t]; dnext[4 * q + t] = 0.f; }
+                }
+            }
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             for (int y = 0; y < H; y += 2) {
                 const int yo = y >> 1;
-                // ---- even input row 2yo: kernel row 1 of output row yo ----
+                // ---- even input row 2yo: kernel row 1 of output row yo.  Output row yo-1 was completed by the last barrier. ----
                 {
                     const int fr = frag_of(y + 1);
                     const bool own = fr < C::FR;
+                    const bool rduty = yo >= 1 && (yo - 1) % NW == wave;
                     if (own) load_frag(y + 1, fr);
                     int cbo = cb;
                     asm volatile("" : "+v"(cbo));
                     f32x16 e;
                     expand(y & 1, 0, e, cbo);                                // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
+                    if (own) store_frag((y + 1) & 1, fr);
+                    if (rduty) reduce_store(yo - 1, (yo - 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        f32x4 c4, r4;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
                         const float *wq = Filt + cbo + 8 * q;
                         const f32x4 w0 = *(const f32x4 *)(wq + 3 * C::HIDP), w2 = *(const f32x4 *)(wq + 5 * C::HIDP);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(from_right(e[4 * q + t]), w2[t], __builtin_fmaf(e[4 * q + t], w0[t], dcur[4 * q + t]));
+                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w0[t], dcur[4 * q + t]));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     expand(y & 1, 1, e, cbo);                                // V: column 2x (tap 4)
 #pragma unroll
@@ -307,8 +375,10 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                         const f32x4 w1 = *(const f32x4 *)(Filt + cbo + 8 * q + 4 * C::HIDP);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dcur[4 * q + t]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (own) store_frag((y + 1) & 1, fr);
                     __syncthreads();
                 }
                 // ---- odd input row 2yo+1: kernel row 2 of output row yo, kernel row 0 of output row yo+1 ----
@@ -320,17 +390,27 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     asm volatile("" : "+v"(cbo));
                     f32x16 e;
                     expand((y + 1) & 1, 0, e, cbo);
+                    if (own) store_frag((y + 2) & 1, fr);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float *wq = Filt + cbo + 8 * q;
-                        const f32x4 w6 = *(const f32x4 *)(wq + 6 * C::HIDP), w8 = *(const f32x4 *)(wq + 8 * C::HIDP);
-                        const f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP);
+                        f32x4 c4, r4;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float c = e[4 * q + t], r = from_right(c);
-                            dcur[4 * q + t] = __builtin_fmaf(r, w8[t], __builtin_fmaf(c, w6[t], dcur[4 * q + t]));
-                            dnext[4 * q + t] = __builtin_fmaf(r, w2[t], __builtin_fmaf(c, w0[t], dsh4[q][t]));
+                        for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
+                        const float *wq = Filt + cbo + 8 * q;
+                        {
+                            const f32x4 w6 = *(const f32x4 *)(wq + 6 * C::HIDP), w8 = *(const f32x4 *)(wq + 8 * C::HIDP);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(r4[t], w8[t], __builtin_fmaf(c4[t], w6[t], dcur[4 * q + t]));
                         }
+                        {
+                            const f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP), sh = *(const f32x4 *)(wq + DSH);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) dnext[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w0[t], sh[t]));
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]), "+v"(dnext[4 * q + t]));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     expand((y + 1) & 1, 1, e, cbo);
 #pragma unroll
@@ -342,40 +422,52 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                             dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w7[t], dcur[4 * q + t]);
                             dnext[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dnext[4 * q + t]);
                         }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]), "+v"(dnext[4 * q + t]));
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     finalize(dcur, yo & 1);
                     dcur = dnext;
-                    if (own) store_frag((y + 2) & 1, fr);
                     __syncthreads();
-                    if (yo % NW == wave) reduce_store(yo, yo & 1);
                 }
             }
+            (void)z4;
+            if ((HO - 1) % NW == wave) reduce_store(HO - 1, (HO - 1) & 1);
         }
         // no barrier here: the next unit's prologue writes Xp slot 0, whose last readers passed two barriers ago, and the Part
         // slot the last duty wave is still reading is next written two barriers into the next unit -- barriers that wave must
         // pass too, after its reads
+    }
+    if (PROF && tid == 0) {
+        pt_[6] = __builtin_amdgcn_s_memtime() - t_begin;          // whole lifetime of the workgroup (column "epilog" of tools/stage_profile.py)
+        for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], nsteps);
     }
 }
 
 template <class C>
 static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
     const int n_units = (B + C::NF - 1) / C::NF;
-    const int cap = 256 * wgs_per_cu;                       // persistent: as many workgroups as the CUs hold at once
-    const int grid = n_units < cap ? n_units : cap;
-    fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units);
+    if (const char *e = getenv("SYN_RM_WGS")) wgs_per_cu = atoi(e);      // tuning knob: persistent workgroups per CU
+    const int cap = 256 * wgs_per_cu, wgs = (n_units + C::U - 1) / C::U;  // persistent: as many workgroups as the CUs hold at once
+    const int grid = wgs < cap ? wgs : cap;
+    if (a.prof)
+        fused_block_rm_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.prof);
+    else
+        fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units);
 }
 
-//                  CIN  HID COUT  H  S NF  RES   waves/SIMD
-using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 2>;    // features.2   60 -> 30      3 waves per workgroup
-using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  2>;    // features.3   30            5 waves
-using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 2>;    // features.4   30 -> 15      5 waves, two faces per workgroup
+//                  CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
+using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, 4>;    // features.2   60 -> 30      4 x 3 waves
+using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, 2>;    // features.3   30            2 x 5 waves
+using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, 2>;    // features.4   30 -> 15      2 x 5 waves, two faces per unit
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
-    if (!a.Arm_e || !a.Arm_p || a.prof) return false;
+    if (!a.Arm_e || !a.Arm_p) return false;
     switch (feature) {
-        case 2: launch_rm<R2>(a, B, s, 4); return true;
-        case 3: launch_rm<R3>(a, B, s, 2); return true;
-        case 4: launch_rm<R4>(a, B, s, 2); return true;
+        case 2: launch_rm<R2>(a, B, s, 1); return true;
+        case 3: launch_rm<R3>(a, B, s, 1); return true;
+        case 4: launch_rm<R4>(a, B, s, 1); return true;
         default: return false;
     }
 }
