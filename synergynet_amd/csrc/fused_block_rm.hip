@@ -15,9 +15,12 @@
 //   * a finished depthwise row is ReLU6'ed, split into its three bf16 pieces IN PLACE -- with K-slot (h, e) := register
 //     8s+e the D layout of one MFMA IS the B operand of the next (the host packs the project weights in that K order) --
 //     and projected (12 MFMAs) to a partial sum over this wave's 32 hidden channels;
-//   * the only LDS traffic is: the block-input row as pre-split B fragments (written once per row by a rotating owner wave,
-//     read by every wave), the per-wave partial sums (reduced in fixed wave order by a rotating duty wave, which adds the BN
-//     shift and the residual and stores the NHWC row) and broadcast reads of the depthwise filter; ONE barrier per input row.
+//   * the only LDS traffic is: the block-input row as pre-split B fragments, the per-wave partial sums and broadcast reads
+//     of the depthwise filter; ONE barrier per input row;
+//   * per unit one SERVICE wave does everything that is not the hidden pipeline: it loads the next block-input row, splits it
+//     into the bf16 fragments all compute waves read, and reduces the partial sums of a finished output row in fixed wave order
+//     (+ BN shift, + residual) into the NHWC store.  The compute waves run straight-line code; the service waves sit on the
+//     SIMDs that hold one compute wave fewer (waves go to SIMDs cyclically), which evens out the 5-groups-on-4-SIMDs split.
 //
 //   stride 2: an input row is two column blocks, U = odd columns (-1, 1, 3, ...) and V = even columns, so that output pixel x
 //   needs U[x], V[x] (same lane) and U[x+1] (wave_shl:1); features.4 (15-wide output) puts TWO faces side by side in a block.
@@ -74,25 +77,26 @@ struct RmCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
     static constexpr int KS = cdivr(CIN, 16);            // k16 steps of the expand GEMM
-    static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = waves of a workgroup
+    static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = compute waves of a unit
     static constexpr int HIDP = NG * 32;
     static constexpr int NQ = COUT / 8;                  // valid register quads of the 32-row project tile
     static constexpr int NB = S == 1 ? 1 : 2;            // column blocks per input row
     static constexpr int HO = S == 2 ? H / 2 : H;
-    // A workgroup carries U independent units (a unit = NF faces marching together), NG waves each, on one barrier: the
-    // hardware reserves ceil(waves / 4) wave slots on EVERY SIMD per workgroup, so two 5-wave workgroups do not share a CU at 3
-    // waves per SIMD -- one 10- or 12-wave workgroup does.
-    static constexpr int NW = NG, NT = U * NW * 64;
-    static constexpr int FR = NB * KS;                   // block-input fragments per input row (one owner wave each)
+    // A workgroup carries U independent units (a unit = NF faces marching together) on one barrier: NG compute waves each
+    // (wave ids 0 .. U*NG-1) and one service wave each (ids U*NG ..).  One big workgroup, not several small ones: the hardware
+    // reserves ceil(waves / 4) wave slots on EVERY SIMD per workgroup, so two 5-wave workgroups never share a CU at 3 waves
+    // per SIMD.
+    static constexpr int NW = NG, NCW = U * NG, NT = (NCW + U) * 64;
+    static constexpr int FR = NB * KS;                   // block-input fragments per input row
     static constexpr int XP_DW = FR * 3 * 256, PART_DW = NW * NQ * 256;
     static constexpr int UNIT_DW = 2 * XP_DW + 2 * PART_DW;
-    static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32;     // X fragments | partial sums | filter 9 rows + depthwise shift | expand shift | project shift
+    static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32;     // per unit: X fragments x2 | partial sums x2;  filter 9 rows + depthwise shift | expand shift | project shift
     static_assert(COUT % 8 == 0 && COUT <= 32, "project tile");
     static_assert(S == 1 || H % 2 == 0, "stride-2 blocks have even input sizes");
     static_assert(S == 1 ? (H + 2 <= 32 && NF == 1) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
-    static_assert(FR <= NW, "one fragment per wave and row");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
     static_assert(S == 2 || H % 3 == 0, "row ring unrolled by 3");
+    static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
 };
 
 #define SYNR_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
@@ -104,25 +108,122 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                            const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
                            const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units,
                            unsigned long long *prof = nullptr) {
-    // PROF: s_memtime sums of wave 0 per phase {fragment loads / duty begin, expand, fragment store + reduce, depthwise, finalize,
-    // barrier wait, (unused)} and the number of row steps (syn_debug_profile_block)
+    // PROF: s_memtime sums of compute wave 0 per phase {(unused), expand, (unused), depthwise, finalize, barrier wait,
+    // whole workgroup lifetime} and the number of row steps (syn_debug_profile_block)
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, nsteps = 0;
     const unsigned long long t_begin = tk;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int uw = wave_wg / C::NW, wave = wave_wg % C::NW;                   // unit inside the workgroup, hidden group inside the unit
+    const bool service = wave_wg >= C::NCW;
+    const int uw = service ? wave_wg - C::NCW : wave_wg / NW;                 // unit inside the workgroup
+    const int wave = service ? 0 : wave_wg % NW;                              // hidden group inside the unit (compute waves)
     unsigned *Xp = smem + uw * C::UNIT_DW;                                    // per unit: [2][FR][3][64][4]
     float *Part = reinterpret_cast<float *>(Xp + 2 * C::XP_DW);               // per unit: [2][NW][NQ][64][4]
-    float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);        // [9][HIDP], shared
-    float *Dsh = Filt + 9 * C::HIDP, *Esh = Dsh + C::HIDP, *Psh = Esh + C::HIDP;   // [HIDP] (= Filt row 9), [HIDP], [32]
-    constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
+    float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);        // [9][HIDP] + row 9 = depthwise BN shift, shared
+    float *Esh = Filt + 10 * C::HIDP, *Psh = Esh + C::HIDP;                   // [HIDP], [32]
+    constexpr int DSH = 9 * C::HIDP;
     const int j = lane & 31, h = lane >> 5;
     const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
 
     for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] : 0.f; }
-    for (int i = tid; i < C::HIDP; i += NT) { Dsh[i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
+    for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
     if (tid < 32) Psh[tid] = tid < C::COUT ? p_shift[tid] : 0.f;
+
+    // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
+    int ia, icol[C::NB], oa, ocol;
+    if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
+    else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
+    else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
+    __syncthreads();
+
+    if (service) {
+        // =====================================================================================================================
+        // service wave of unit uw: block-input rows -> bf16 x3 fragments in LDS; finished output rows: partial sums -> NHWC row
+        // =====================================================================================================================
+        for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
+            const int unit = ub + uw;
+            const int f_in = unit * C::NF + ia, f_out = unit * C::NF + oa;
+            const bool out_ok = (unsigned)ocol < (unsigned)HO && f_out < B;
+            f32x4 xr[C::FR][2];
+            // fragment b*KS + s = channels 16s + 8h .. +7 of the pixels of block b
+            auto load_row = [&](int y) {
+#pragma unroll
+                for (int fr = 0; fr < C::FR; ++fr) {
+                    const int b = fr / C::KS, sk = fr % C::KS, c0 = 16 * sk + 8 * h;
+                    xr[fr][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xr[fr][1] = xr[fr][0];
+                    if (c0 + 8 <= C::CIN && (unsigned)icol[b] < (unsigned)H && f_in < B) {
+                        const float *src = X + ((size_t)(f_in * H + y) * H + icol[b]) * C::CIN + c0;
+                        xr[fr][0] = *(const f32x4 *)src; xr[fr][1] = *(const f32x4 *)(src + 4);
+                    }
+                }
+            };
+            auto store_row = [&](int slot) {
+#pragma unroll
+                for (int fr = 0; fr < C::FR; ++fr) {
+                    u32x4 pc[3];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        split2r(xr[fr][t][0], xr[fr][t][1], h0, m0, l0);
+                        split2r(xr[fr][t][2], xr[fr][t][3], h1, m1, l1);
+                        pc[0][2 * t] = h0; pc[0][2 * t + 1] = h1; pc[1][2 * t] = m0; pc[1][2 * t + 1] = m1; pc[2][2 * t] = l0; pc[2][2 * t + 1] = l1;
+                    }
+                    unsigned *dst = Xp + (size_t)slot * C::XP_DW + fr * 768 + lane * 4;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
+                }
+            };
+            // partial sums of all compute waves in fixed order + BN shift (+ residual) -> NHWC row
+            auto reduce_row = [&](int yo, int pslot) {
+                f32x4 res[C::RES ? C::NQ : 1];
+                if (C::RES) {
+#pragma unroll
+                    for (int q = 0; q < C::NQ; ++q) {
+                        res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (out_ok) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < C::NQ; ++q) {
+                    f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
+                    const float *src = Part + (size_t)pslot * C::PART_DW + q * 256 + lane * 4;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) v += *(const f32x4 *)(src + (size_t)w * C::NQ * 256);
+                    if (C::RES) v += res[q];
+                    if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
+                }
+            };
+            load_row(0);
+            store_row(0);
+            __syncthreads();                                  // (P) row 0 is in slot 0
+            if (C::S == 1) {
+                for (int y = 0; y < H; ++y) {
+                    if (y + 1 < H) load_row(y + 1);
+                    if (y >= 2) reduce_row(y - 2, y & 1);     // completed by the barrier that ended step y-1; slot y&1 is rewritten in step y+1
+                    if (y + 1 < H) store_row((y + 1) & 1);    // slot (y+1)&1 was last read in step y-1
+                    __syncthreads();
+                }
+                reduce_row(H - 2, (H - 2) & 1);
+                __syncthreads();                              // the compute waves finalized the last row
+                reduce_row(H - 1, (H - 1) & 1);
+            } else {
+                for (int y = 0; y < H; ++y) {
+                    if (y + 1 < H) load_row(y + 1);
+                    if (!(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
+                    if (y + 1 < H) store_row((y + 1) & 1);
+                    __syncthreads();
+                }
+                reduce_row(HO - 1, (HO - 1) & 1);
+            }
+        }
+        return;
+    }
+
+    // =========================================================================================================================
+    // compute wave: hidden group `wave` of unit uw
+    // =========================================================================================================================
     // this wave's weight fragments stay in registers for the whole (persistent) kernel
     u32x4 ae[C::KS][3], ap[2][3];
 #pragma unroll
@@ -134,49 +235,15 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
         for (int p = 0; p < 3; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
 
-    // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
-    int ia, icol[C::NB], oa, ocol;
-    if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
-    else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
-    else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
-    __syncthreads();
-
-    constexpr int DSH = 9 * C::HIDP;             // Filt row 9 = depthwise BN shift (accumulator start)
-
     // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
     // stores nothing (its faces are >= B)
     for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
         const int unit = ub + uw;
-        const int f_in = unit * C::NF + ia, f_out = unit * C::NF + oa;
+        const int f_in = unit * C::NF + ia;
         float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? 6.0f : 0.0f;
-        const bool out_ok = (unsigned)ocol < (unsigned)HO && f_out < B;
 
-        // ---- block-input fragments: frag = b*KS + s = channels 16s + 8h .. +7 of the pixels of block b ----
-        f32x4 xr[2];
-        auto frag_of = [&](int y) { return (wave - y % NW + NW) % NW; };             // the fragment of row y this wave owns (>= FR: none)
-        auto load_frag = [&](int y, int frag) {
-            const int b = frag / C::KS, s = frag % C::KS, c0 = 16 * s + 8 * h;
-            xr[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xr[1] = xr[0];
-            if (c0 + 8 <= C::CIN && (unsigned)icol[b] < (unsigned)H && f_in < B) {
-                const float *src = X + ((size_t)(f_in * H + y) * H + icol[b]) * C::CIN + c0;
-                xr[0] = *(const f32x4 *)src; xr[1] = *(const f32x4 *)(src + 4);
-            }
-        };
-        auto store_frag = [&](int slot, int frag) {
-            u32x4 pc[3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                split2r(xr[t][0], xr[t][1], h0, m0, l0);
-                split2r(xr[t][2], xr[t][3], h1, m1, l1);
-                pc[0][2 * t] = h0; pc[0][2 * t + 1] = h1; pc[1][2 * t] = m0; pc[1][2 * t + 1] = m1; pc[2][2 * t] = l0; pc[2][2 * t + 1] = l1;
-            }
-            unsigned *dst = Xp + (size_t)slot * C::XP_DW + frag * 768 + lane * 4;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
-        };
         // ---- expand one block of the row in slot `slot`: 16 hidden channels per lane, BN shift, ReLU6 (0 on padding lanes) ----
         auto expand = [&](int slot, int b, f32x16 &e, int cbo) {
 #pragma unroll
@@ -218,30 +285,6 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int q = 0; q < C::NQ; ++q) *(f32x4 *)(dst + q * 256) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         };
-        // ---- duty wave: partial sums of all waves in fixed order + BN shift (+ residual) -> NHWC row.  Split in two so that the
-        //      residual's global load is in flight while the next row's expand MFMAs run, and nothing of it is live in the
-        //      depthwise phase (the register peak) ----
-        f32x4 res[C::RES ? C::NQ : 1];
-        auto reduce_begin = [&](int yo) {
-            if (C::RES) {
-#pragma unroll
-                for (int q = 0; q < C::NQ; ++q) {
-                    res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (out_ok) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
-                }
-            }
-        };
-        auto reduce_store = [&](int yo, int pslot) {
-#pragma unroll
-            for (int q = 0; q < C::NQ; ++q) {
-                f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
-                const float *src = Part + (size_t)pslot * C::PART_DW + q * 256 + lane * 4;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) v += *(const f32x4 *)(src + (size_t)w * C::NQ * 256);
-                if (C::RES) v += res[q];
-                if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
-            }
-        };
         // three taps of one kernel row into one accumulator quad; `init`: the accumulator starts at the BN shift (Filt row 9)
         auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
             const f32x4 w0 = *(const f32x4 *)(wq + (3 * ky + 0) * C::HIDP), w1 = *(const f32x4 *)(wq + (3 * ky + 1) * C::HIDP),
@@ -257,21 +300,34 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             // row's step) and keeps their operands + filter quads alive across the barrier instead
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
-            __builtin_amdgcn_sched_barrier(0);
         };
+        // two taps (U blocks of the stride-2 layout: this lane and its right neighbour) / one tap (V blocks)
+        auto taps2 = [&](f32x16 &d, int q, const float *wq, int ta, int tb, const f32x4 &c4, const f32x4 &r4, bool init) {
+            const f32x4 wa = *(const f32x4 *)(wq + ta * C::HIDP), wb = *(const f32x4 *)(wq + tb * C::HIDP);
+            f32x4 base;
+            if (init) base = *(const f32x4 *)(wq + DSH);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[4 * q + t] = __builtin_fmaf(r4[t], wb[t], __builtin_fmaf(c4[t], wa[t], init ? base[t] : d[4 * q + t]));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
+        };
+        auto taps1 = [&](f32x16 &d, int q, const float *wq, int ta, const f32x16 &e) {
+            const f32x4 wa = *(const f32x4 *)(wq + ta * C::HIDP);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[4 * q + t] = __builtin_fmaf(e[4 * q + t], wa[t], d[4 * q + t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
+        };
+        // the filter / shift reads are loop invariant; an opaque base keeps the compiler from hoisting 150 registers' worth of them
+        // out of the row loop (and spilling them)
+        auto opaque_cb = [&]() { int c = cb; asm volatile("" : "+v"(c)); return c; };
 
-        // prologue: row 0 of this unit -> slot 0
-        {
-            const int fr = frag_of(0);
-            if (fr < C::FR) { load_frag(0, fr); store_frag(0, fr); }
-        }
-        __syncthreads();
+        __syncthreads();                                      // (P) row 0 is in slot 0
 
         if (C::S == 1) {
             f32x16 d0, d1, d2;
             {
-                int cbo = cb;
-                asm volatile("" : "+v"(cbo));
+                const int cbo = opaque_cb();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 sh = *(const f32x4 *)(Filt + cbo + 8 * q + DSH);      // output row 0 starts at the BN shift
@@ -279,27 +335,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     for (int t = 0; t < 4; ++t) { d0[4 * q + t] = sh[t]; d1[4 * q + t] = 0.f; d2[4 * q + t] = 0.f; }
                 }
             }
-            // input row y -> kernel row 2 of output row y-1 (dm), row 1 of y (dc), row 0 of y+1 (dn).  `rduty`: this wave reduces
-            // output row y-2, whose partial sums were completed by the barrier that ended the previous step.
+            // input row y -> kernel row 2 of output row y-1 (dm), row 1 of y (dc), row 0 of y+1 (dn)
             auto step = [&](int y, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
-                const int fr = frag_of(y + 1);
-                const bool own = fr < C::FR && y + 1 < H;
-                const bool rduty = y >= 2 && (y - 2) % NW == wave;
                 SYNR_LAP(5);
-                if (own) load_frag(y + 1, fr);
-                if (rduty) reduce_begin(y - 2);
-                SYNR_LAP(0);
-                // the filter / shift reads below are loop invariant; an opaque base keeps the compiler from hoisting 150 registers'
-                // worth of them out of the row loop (and spilling them)
-                int cbo = cb;
-                asm volatile("" : "+v"(cbo));
+                const int cbo = opaque_cb();
                 f32x16 e;
                 expand(y & 1, 0, e, cbo);
                 SYNR_LAP(1);
-                if (own) store_frag((y + 1) & 1, fr);            // slot (y+1)&1 was last read in step y-1
-                if (rduty) reduce_store(y - 2, y & 1);
-                SYNR_LAP(2);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 c4, l4, r4;
@@ -309,12 +351,12 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     taps3(dn, q, wq, 0, l4, c4, r4, true);
                     taps3(dc, q, wq, 1, l4, c4, r4, false);
                     taps3(dm, q, wq, 2, l4, c4, r4, false);
+                    __builtin_amdgcn_sched_barrier(0);          // one register quad at a time
                 }
                 SYNR_LAP(3);
                 if (y >= 1) finalize(dm, (y - 1) & 1);
                 SYNR_LAP(4);
                 __syncthreads();
-                SYNR_LAP(5);
                 nsteps += 1;
             };
             for (int y = 0; y < H; y += 3) {
@@ -322,17 +364,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 step(y + 1, d0, d1, d2);
                 step(y + 2, d1, d2, d0);
             }
-            // output row H-2 was completed by the last barrier; the last output row has no input row below it: complete as it is
-            // ((H-1) % 3 == 2 -> d2)
-            if ((H - 2) % NW == wave) { reduce_begin(H - 2); reduce_store(H - 2, (H - 2) & 1); }
+            // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
             finalize(d2, (H - 1) & 1);
             __syncthreads();
-            if ((H - 1) % NW == wave) { reduce_begin(H - 1); reduce_store(H - 1, (H - 1) & 1); }
         } else {
             f32x16 dcur, dnext;
             {
-                int cbo = cb;
-                asm volatile("" : "+v"(cbo));
+                const int cbo = opaque_cb();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 sh = *(const f32x4 *)(Filt + cbo + 8 * q + DSH);
@@ -340,103 +378,63 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     for (int t = 0; t < 4; ++t) { dcur[4 * q + t] = sh[t]; dnext[4 * q + t] = 0.f; }
                 }
             }
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             for (int y = 0; y < H; y += 2) {
                 const int yo = y >> 1;
-                // ---- even input row 2yo: kernel row 1 of output row yo.  Output row yo-1 was completed by the last barrier. ----
+                // ---- even input row 2yo: kernel row 1 of output row yo ----
                 {
-                    const int fr = frag_of(y + 1);
-                    const bool own = fr < C::FR;
-                    const bool rduty = yo >= 1 && (yo - 1) % NW == wave;
-                    if (own) load_frag(y + 1, fr);
-                    int cbo = cb;
-                    asm volatile("" : "+v"(cbo));
+                    SYNR_LAP(5);
+                    const int cbo = opaque_cb();
                     f32x16 e;
                     expand(y & 1, 0, e, cbo);                                // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
-                    if (own) store_frag((y + 1) & 1, fr);
-                    if (rduty) reduce_store(yo - 1, (yo - 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 c4, r4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
-                        const float *wq = Filt + cbo + 8 * q;
-                        const f32x4 w0 = *(const f32x4 *)(wq + 3 * C::HIDP), w2 = *(const f32x4 *)(wq + 5 * C::HIDP);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w0[t], dcur[4 * q + t]));
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]));
+                        taps2(dcur, q, Filt + cbo + 8 * q, 3, 5, c4, r4, false);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     expand(y & 1, 1, e, cbo);                                // V: column 2x (tap 4)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 w1 = *(const f32x4 *)(Filt + cbo + 8 * q + 4 * C::HIDP);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dcur[4 * q + t]);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]));
+                        taps1(dcur, q, Filt + cbo + 8 * q, 4, e);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    SYNR_LAP(3);
                     __syncthreads();
+                    nsteps += 1;
                 }
                 // ---- odd input row 2yo+1: kernel row 2 of output row yo, kernel row 0 of output row yo+1 ----
                 {
-                    const int fr = frag_of(y + 2);
-                    const bool own = fr < C::FR && y + 2 < H;
-                    if (own) load_frag(y + 2, fr);
-                    int cbo = cb;
-                    asm volatile("" : "+v"(cbo));
+                    SYNR_LAP(5);
+                    const int cbo = opaque_cb();
                     f32x16 e;
                     expand((y + 1) & 1, 0, e, cbo);
-                    if (own) store_frag((y + 2) & 1, fr);
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 c4, r4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
-                        const float *wq = Filt + cbo + 8 * q;
-                        {
-                            const f32x4 w6 = *(const f32x4 *)(wq + 6 * C::HIDP), w8 = *(const f32x4 *)(wq + 8 * C::HIDP);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) dcur[4 * q + t] = __builtin_fmaf(r4[t], w8[t], __builtin_fmaf(c4[t], w6[t], dcur[4 * q + t]));
-                        }
-                        {
-                            const f32x4 w0 = *(const f32x4 *)(wq + 0 * C::HIDP), w2 = *(const f32x4 *)(wq + 2 * C::HIDP), sh = *(const f32x4 *)(wq + DSH);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) dnext[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w0[t], sh[t]));
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]), "+v"(dnext[4 * q + t]));
+                        taps2(dcur, q, Filt + cbo + 8 * q, 6, 8, c4, r4, false);
+                        taps2(dnext, q, Filt + cbo + 8 * q, 0, 2, c4, r4, true);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     expand((y + 1) & 1, 1, e, cbo);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float *wq = Filt + cbo + 8 * q;
-                        const f32x4 w7 = *(const f32x4 *)(wq + 7 * C::HIDP), w1 = *(const f32x4 *)(wq + 1 * C::HIDP);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            dcur[4 * q + t] = __builtin_fmaf(e[4 * q + t], w7[t], dcur[4 * q + t]);
-                            dnext[4 * q + t] = __builtin_fmaf(e[4 * q + t], w1[t], dnext[4 * q + t]);
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(dcur[4 * q + t]), "+v"(dnext[4 * q + t]));
+                        taps1(dcur, q, Filt + cbo + 8 * q, 7, e);
+                        taps1(dnext, q, Filt + cbo + 8 * q, 1, e);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    SYNR_LAP(3);
                     finalize(dcur, yo & 1);
+                    SYNR_LAP(4);
                     dcur = dnext;
                     __syncthreads();
+                    nsteps += 1;
                 }
             }
-            (void)z4;
-            if ((HO - 1) % NW == wave) reduce_store(HO - 1, (HO - 1) & 1);
         }
-        // no barrier here: the next unit's prologue writes Xp slot 0, whose last readers passed two barriers ago, and the Part
-        // slot the last duty wave is still reading is next written two barriers into the next unit -- barriers that wave must
-        // pass too, after its reads
     }
     if (PROF && tid == 0) {
         pt_[6] = __builtin_amdgcn_s_memtime() - t_begin;          // whole lifetime of the workgroup (column "epilog" of tools/stage_profile.py)
@@ -458,9 +456,9 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
 }
 
 //                  CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
-using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, 4>;    // features.2   60 -> 30      4 x 3 waves
-using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, 2>;    // features.3   30            2 x 5 waves
-using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, 2>;    // features.4   30 -> 15      2 x 5 waves, two faces per unit
+using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, 3>;    // features.2   60 -> 30      3 x (3 + 1) waves
+using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, 2>;    // features.3   30            2 x (5 + 1) waves
+using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, 2>;    // features.4   30 -> 15      2 x (5 + 1) waves, two faces per unit
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p) return false;
