@@ -126,6 +126,10 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     constexpr int DSH = 9 * C::HIDP;
     const int j = lane & 31, h = lane >> 5;
     const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
+    // HID % 32 == 16: the last group has 16 real channels = register quads 0, 1 (rows 0-15 of its A tile); quads 2, 3 are zero
+    // padding -- their depthwise taps, splits and the second project k-step are skipped (wave-uniform), which makes that wave
+    // light; with the cyclic wave -> SIMD placement the light waves are the third compute wave of their SIMD.
+    const int nq_live = (C::HID % 32 == 16 && wave == NW - 1) ? 2 : 4;
 
     for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] : 0.f; }
     for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
@@ -175,16 +179,20 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     for (int p = 0; p < 3; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
                 }
             };
-            // partial sums of all compute waves in fixed order + BN shift (+ residual) -> NHWC row
-            auto reduce_row = [&](int yo, int pslot) {
-                f32x4 res[C::RES ? C::NQ : 1];
+            // Global latencies get a whole row step: row y+2 and the residual of output row y-1 are requested in step y and
+            // consumed in step y+1.
+            f32x4 res[C::RES ? C::NQ : 1];
+            auto load_res = [&](int yo) {
                 if (C::RES) {
 #pragma unroll
                     for (int q = 0; q < C::NQ; ++q) {
                         res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (out_ok) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
+                        if (out_ok && yo >= 0 && yo < HO) res[q] = *(const f32x4 *)(X + ((size_t)(f_out * H + yo) * H + ocol) * C::CIN + 8 * q + 4 * h);
                     }
                 }
+            };
+            // partial sums of all compute waves in fixed order + BN shift (+ residual, already in `res`) -> NHWC row
+            auto reduce_row = [&](int yo, int pslot) {
 #pragma unroll
                 for (int q = 0; q < C::NQ; ++q) {
                     f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
@@ -197,22 +205,26 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             };
             load_row(0);
             store_row(0);
+            load_row(1);                                      // in flight across the barrier
             __syncthreads();                                  // (P) row 0 is in slot 0
             if (C::S == 1) {
+                load_res(0);
                 for (int y = 0; y < H; ++y) {
-                    if (y + 1 < H) load_row(y + 1);
                     if (y >= 2) reduce_row(y - 2, y & 1);     // completed by the barrier that ended step y-1; slot y&1 is rewritten in step y+1
-                    if (y + 1 < H) store_row((y + 1) & 1);    // slot (y+1)&1 was last read in step y-1
+                    load_res(y - 1);                          // for the next step's reduction
+                    if (y + 1 < H) store_row((y + 1) & 1);    // row y+1 (requested a step ago); slot (y+1)&1 was last read in step y-1
+                    if (y + 2 < H) load_row(y + 2);
                     __syncthreads();
                 }
                 reduce_row(H - 2, (H - 2) & 1);
+                load_res(H - 1);
                 __syncthreads();                              // the compute waves finalized the last row
                 reduce_row(H - 1, (H - 1) & 1);
             } else {
                 for (int y = 0; y < H; ++y) {
-                    if (y + 1 < H) load_row(y + 1);
                     if (!(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
                     if (y + 1 < H) store_row((y + 1) & 1);
+                    if (y + 2 < H) load_row(y + 2);
                     __syncthreads();
                 }
                 reduce_row(HO - 1, (HO - 1) & 1);
@@ -271,6 +283,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                if (2 * s >= nq_live) break;                // padded half of the last group: its pieces and weights are zero
                 u32x4 db[3];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -344,6 +357,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 SYNR_LAP(1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (q >= nq_live) break;
                     f32x4 c4, l4, r4;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; l4[t] = from_left(c4[t]); r4[t] = from_right(c4[t]); }
@@ -388,6 +402,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     expand(y & 1, 0, e, cbo);                                // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (q >= nq_live) break;
                         f32x4 c4, r4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
@@ -397,6 +412,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     expand(y & 1, 1, e, cbo);                                // V: column 2x (tap 4)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (q >= nq_live) break;
                         taps1(dcur, q, Filt + cbo + 8 * q, 4, e);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -412,6 +428,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     expand((y + 1) & 1, 0, e, cbo);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (q >= nq_live) break;
                         f32x4 c4, r4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; r4[t] = from_right(c4[t]); }
@@ -422,6 +439,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     expand((y + 1) & 1, 1, e, cbo);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (q >= nq_live) break;
                         taps1(dcur, q, Filt + cbo + 8 * q, 7, e);
                         taps1(dnext, q, Filt + cbo + 8 * q, 1, e);
                         __builtin_amdgcn_sched_barrier(0);
@@ -456,7 +474,7 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
 }
 
 //                  CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
-using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, 3>;    // features.2   60 -> 30      3 x (3 + 1) waves
+using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 4, 4>;    // features.2   60 -> 30      4 x (3 + 1) waves, 4 per SIMD
 using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, 2>;    // features.3   30            2 x (5 + 1) waves
 using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, 2>;    // features.4   30 -> 15      2 x (5 + 1) waves, two faces per unit
 
