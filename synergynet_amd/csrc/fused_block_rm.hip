@@ -100,6 +100,8 @@ struct RmCfg {
 };
 
 #define SYNR_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+// PROF: barrier that also books the time since the previous barrier as this wave's busy time
+#define SYNR_BARRIER() do { if (PROF) { const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); busy_ += tb_ - tw_; __syncthreads(); tw_ = __builtin_amdgcn_s_memtime(); } else __syncthreads(); } while (0)
 
 template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
@@ -112,6 +114,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     // whole workgroup lifetime} and the number of row steps (syn_debug_profile_block)
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, nsteps = 0;
     const unsigned long long t_begin = tk;
+    unsigned long long busy_ = 0, tw_ = tk;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
     constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,7 +209,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             load_row(0);
             store_row(0);
             load_row(1);                                      // in flight across the barrier
-            __syncthreads();                                  // (P) row 0 is in slot 0
+            SYNR_BARRIER();                                  // (P) row 0 is in slot 0
             if (C::S == 1) {
                 load_res(0);
                 for (int y = 0; y < H; ++y) {
@@ -214,22 +217,23 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     load_res(y - 1);                          // for the next step's reduction
                     if (y + 1 < H) store_row((y + 1) & 1);    // row y+1 (requested a step ago); slot (y+1)&1 was last read in step y-1
                     if (y + 2 < H) load_row(y + 2);
-                    __syncthreads();
+                    SYNR_BARRIER();
                 }
                 reduce_row(H - 2, (H - 2) & 1);
                 load_res(H - 1);
-                __syncthreads();                              // the compute waves finalized the last row
+                SYNR_BARRIER();                              // the compute waves finalized the last row
                 reduce_row(H - 1, (H - 1) & 1);
             } else {
                 for (int y = 0; y < H; ++y) {
                     if (!(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
                     if (y + 1 < H) store_row((y + 1) & 1);
                     if (y + 2 < H) load_row(y + 2);
-                    __syncthreads();
+                    SYNR_BARRIER();
                 }
                 reduce_row(HO - 1, (HO - 1) & 1);
             }
         }
+        if (PROF && lane == 0) atomicAdd(&prof[8 + wave_wg], busy_);
         return;
     }
 
@@ -335,7 +339,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
         // out of the row loop (and spilling them)
         auto opaque_cb = [&]() { int c = cb; asm volatile("" : "+v"(c)); return c; };
 
-        __syncthreads();                                      // (P) row 0 is in slot 0
+        SYNR_BARRIER();                                      // (P) row 0 is in slot 0
 
         if (C::S == 1) {
             f32x16 d0, d1, d2;
@@ -370,7 +374,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 SYNR_LAP(3);
                 if (y >= 1) finalize(dm, (y - 1) & 1);
                 SYNR_LAP(4);
-                __syncthreads();
+                SYNR_BARRIER();
                 nsteps += 1;
             };
             for (int y = 0; y < H; y += 3) {
@@ -380,7 +384,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             }
             // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
             finalize(d2, (H - 1) & 1);
-            __syncthreads();
+            SYNR_BARRIER();
         } else {
             f32x16 dcur, dnext;
             {
@@ -417,7 +421,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     SYNR_LAP(3);
-                    __syncthreads();
+                    SYNR_BARRIER();
                     nsteps += 1;
                 }
                 // ---- odd input row 2yo+1: kernel row 2 of output row yo, kernel row 0 of output row yo+1 ----
@@ -448,12 +452,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     finalize(dcur, yo & 1);
                     SYNR_LAP(4);
                     dcur = dnext;
-                    __syncthreads();
+                    SYNR_BARRIER();
                     nsteps += 1;
                 }
             }
         }
     }
+    if (PROF && lane == 0) atomicAdd(&prof[8 + wave_wg], busy_);
     if (PROF && tid == 0) {
         pt_[6] = __builtin_amdgcn_s_memtime() - t_begin;          // whole lifetime of the workgroup (column "epilog" of tools/stage_profile.py)
         for (int i = 0; i < 7; ++i) atomicAdd(&prof[i], pt_[i]);

@@ -1,0 +1,282 @@
+// Row-marching network head for uint8 crops: features.0 (3x3 s2 conv 3->32 + BN + ReLU6) and features.1 (depthwise 3x3 + BN +
+// ReLU6, linear 1x1 32->16 + BN) with the 60x60x32 stem output living in registers only.
+// Reference: backbone_nets/mobilenetv2_backbone.py:129 (features.0), :58-66 (t = 1 block), synergy3DMM.py:189-192 (the
+// HWC->CHW permute and (x-127.5)/128 are folded in).  Same dataflow as fused_block_rm.hip:
+//
+//   * a compute wave owns one 30-column half of one face (32 lanes = 30 output columns + one neighbour column each side: the
+//     two halves overlap by two stem columns instead of exchanging them) and marches down the 60 rows;
+//   * the stem convolution is an im2col GEMM on v_mfma_f32_32x32x16_bf16: A = the 32 stem channels x 27 taps (two k16 steps),
+//     B = the raw pixel bytes as bf16 -- every integer 0..255 IS a bf16 number, so only the filter needs the exact 3-way
+//     split (3 MFMAs per step).  The normalisation is folded: (2p-255)/256 = p/128 - 255/256, i.e. the packed filter is w/128
+//     (exact) and the accumulator starts at shift - 255/256 * sum(w); zero padding (0 in normalised space) is the raw value
+//     127.5 = 0x42FF, also exact in bf16.  K-slot layout chosen so that a lane's sixteen taps are two runs of consecutive
+//     bytes: lane half 0 carries kernel row 0 (9 taps) + the first 5 taps of row 1, half 1 carries row 2 + the last 4 of row 1;
+//   * depthwise 3x3 scattered into three row accumulators, neighbours through wave_shr / wave_shl, filter from LDS
+//     (broadcast reads); ReLU6 -> in-place bf16 x3 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
+//     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
+//   * ONE service wave per workgroup keeps the image rows of all units flowing: global dwords -> bf16 -> LDS row ring
+//     (8 slots per unit), one barrier per output row.
+// fp32 crops (forward_test) keep the tiled kernel of stem_block1.hip: arbitrary floats need the 3-way split on both sides.
+#include "syn_internal.h"
+
+#include <cstdlib>
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+__device__ __forceinline__ void split2s(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mfma32s(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float left_of(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float right_of(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+constexpr int kImgW = 120, kHid = 60;
+constexpr int kRowEl = 384;               // bf16 elements per image-row slot: [0] unused, [1..3] left padding pixel, [4 + 3x + c], tail
+constexpr int kSlots = 8;                 // image-row ring per unit
+constexpr unsigned kPadBf16 = 0x42FFu;    // 127.5: the raw value of a zero in normalised space
+}  // namespace
+
+template <int U_, int WPE_>
+struct StemRmCfg {
+    static constexpr int U = U_, WPE = WPE_;                                  // faces (units) per workgroup
+    static constexpr int NCW = 2 * U, NT = (NCW + 1) * 64;         // compute waves (face, half) + one service wave
+    static constexpr int UNIT_DW = (kSlots + 1) * kRowEl / 2;      // ring + one all-padding row (image row -1)
+    static constexpr int LDS_DW = U * UNIT_DW + 10 * 32 + 32 + 32; // + depthwise filter 9x32 | depthwise shift | stem shift | project shift
+    static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, 3)))
+void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][3][64][4]*/,
+                    const float *__restrict__ s_shift /*[32] folded*/, const float *__restrict__ Wd /*[9][32] scaled*/,
+                    const float *__restrict__ d_shift, const unsigned *__restrict__ Ap3 /*[1][2][3][64][4]*/,
+                    const float *__restrict__ p_shift /*[16]*/, float *__restrict__ Y /*[B,60,60,16]*/, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool service = wave_wg >= C::NCW;
+    float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);       // [9][32] + row 9 = depthwise shift
+    float *Ssh = Filt + 10 * 32, *Psh = Ssh + 32;
+    constexpr int DSH = 9 * 32;
+    for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i];
+    if (tid < 32) { Filt[DSH + tid] = d_shift[tid]; Ssh[tid] = s_shift[tid]; Psh[tid] = tid < 16 ? p_shift[tid] : 0.f; }
+    // padding row (image row -1) and the left padding pixel / tails of every ring slot: 127.5 everywhere, then the service wave only
+    // ever rewrites elements 4 .. 363
+    for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadBf16 | (kPadBf16 << 16);
+    __syncthreads();
+
+    if (service) {
+        // ---- image rows -> bf16 -> ring: row iy of unit u lands in slot iy & 7 ----
+        // two image rows of every unit per call: all dword loads first (one global round trip), then byte -> float -> bf16
+        // (exact: the high half of the float) and one 8-byte LDS store per dword
+        constexpr int PER_ROW = kImgW * 3 / 4;                     // 90 dwords
+        constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
+        auto stage_rows = [&](int fb, int iy0) {                   // rows iy0, iy0+1 of faces fb .. fb+U-1
+            const uint8_t *fbase = img + (size_t)fb * kImgW * kImgW * 3;
+            unsigned v[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                const int f = fb + u, iy = iy0 + r;
+                v[it] = 0u;
+                // uniform 64-bit base + 32-bit lane offset: one address register per load instead of two
+                const unsigned off = (unsigned)((u * kImgW + iy) * kImgW * 3 + 4 * d);
+                if (i < TOTAL && f < B && iy < kImgW) v[it] = *reinterpret_cast<const unsigned *>(fbase + off);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                const int iy = iy0 + r;
+                if (i < TOTAL && iy < kImgW) {
+                    const unsigned b0 = __builtin_bit_cast(unsigned, (float)(v[it] & 0xff)), b1 = __builtin_bit_cast(unsigned, (float)((v[it] >> 8) & 0xff));
+                    const unsigned b2 = __builtin_bit_cast(unsigned, (float)((v[it] >> 16) & 0xff)), b3 = __builtin_bit_cast(unsigned, (float)(v[it] >> 24));
+                    u32x2 o;
+                    o[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+                    o[1] = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+                    *reinterpret_cast<u32x2 *>(smem + u * C::UNIT_DW + (iy & (kSlots - 1)) * (kRowEl / 2) + 2 + 2 * d) = o;   // elements 4 + 4d ..
+                }
+            }
+        };
+        for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
+            stage_rows(fb, 0);
+            __syncthreads();                                   // (P) image rows 0, 1
+            for (int hy = 0; hy < kHid; ++hy) {
+                stage_rows(fb, 2 * hy + 2);                    // what output row hy+1 adds; the slots were last read in step hy-2
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ---- compute wave: half c of face (fb + uw) ----
+    const int uw = wave_wg >> 1, c = wave_wg & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const int hc = 30 * c + j - 1;                                 // stem / hidden column of this lane
+    const bool col_ok = (unsigned)hc < (unsigned)kHid;
+    const bool out_lane = j >= 1 && j <= 30;
+    const unsigned short *ring = reinterpret_cast<const unsigned short *>(smem + uw * C::UNIT_DW);
+    // element offset of this lane's first tap inside a row slot: column 2*hc - 1 -> 4 + 3*(2hc - 1) = 6hc + 1 (clamped for the
+    // out-of-image lanes, whose result is forced to zero anyway)
+    const int run0 = 6 * (col_ok ? hc : 0) + 1;
+    u32x4 as[2][3], ap[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            as[s][p] = *(const u32x4 *)(As3 + ((size_t)s * 3 + p) * 256 + lane * 4);
+            ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)s * 3 + p) * 256 + lane * 4);
+        }
+    const int cb = 4 * h;
+    auto opaque_cb = [&]() { int v = cb; asm volatile("" : "+v"(v)); return v; };
+
+    for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
+        const int f = fb + uw;
+        const float ehi = (col_ok && f < B) ? 6.0f : 0.0f;
+        const bool st_ok = out_lane && f < B;
+        const int yofs = (30 * c + j - 1) * 16 + 4 * h;             // (column, channel quad) inside an output row; < 2^31 elements per face
+
+        auto finalize = [&](f32x16 &d, int oy) {
+            const int cbo = opaque_cb();
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sh = *(const f32x4 *)&Psh[(cbo + 8 * q) & 31];          // rows >= 16 are padding (never stored)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = q < 2 ? sh[t] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 db[3];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
+                    unsigned hh, mm, ll;
+                    split2s(v0, v1, hh, mm, ll);
+                    db[0][t] = hh; db[1][t] = mm; db[2][t] = ll;
+                }
+                acc = mfma32s(ap[s][2], db[0], acc);
+                acc = mfma32s(ap[s][0], db[2], acc);
+                acc = mfma32s(ap[s][1], db[1], acc);
+                acc = mfma32s(ap[s][1], db[0], acc);
+                acc = mfma32s(ap[s][0], db[1], acc);
+                acc = mfma32s(ap[s][0], db[0], acc);
+            }
+            if (st_ok) {
+                float *dst = Y + ((size_t)f * kHid + oy) * kHid * 16 + yofs;
+                *(f32x4 *)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]};              // channels 4h .. 4h+3
+                *(f32x4 *)(dst + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]};        // channels 8 + 4h ..
+            }
+        };
+        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+            const f32x4 w0 = *(const f32x4 *)(wq + (3 * ky + 0) * 32), w1 = *(const f32x4 *)(wq + (3 * ky + 1) * 32), w2 = *(const f32x4 *)(wq + (3 * ky + 2) * 32);
+            f32x4 base;
+            if (init) base = *(const f32x4 *)(wq + DSH);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b0 = init ? base[t] : d[4 * q + t];
+                d[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0)));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
+        };
+
+        f32x16 d0, d1, d2;
+        {
+            const int cbo = opaque_cb();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sh = *(const f32x4 *)(Filt + cbo + 8 * q + DSH);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { d0[4 * q + t] = sh[t]; d1[4 * q + t] = 0.f; d2[4 * q + t] = 0.f; }
+            }
+        }
+        __syncthreads();                                       // (P)
+
+        // stem row hy -> kernel row 2 of output row hy-1 (dm), row 1 of hy (dc), row 0 of hy+1 (dn)
+        auto step = [&](int hy, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
+            const int cbo = opaque_cb();
+            // ---- im2col B operand: image rows 2hy-1 (kernel row 0), 2hy, 2hy+1 from the ring; row -1 = the padding row ----
+            const unsigned short *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * kRowEl + run0;
+            const unsigned short *r1 = ring + ((2 * hy) & (kSlots - 1)) * kRowEl + run0;
+            const unsigned short *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * kRowEl + run0;
+            // lane half 0: slots 0..8 = kernel row 0 taps 0..8, slots 9..13 = row 1 taps 0..4; half 1: slots 0..8 = row 2 taps 0..8,
+            // slots 9..12 = row 1 taps 5..8 (the remaining slots have zero weights: any finite value will do)
+            const unsigned short *pa = h ? r2 : r0, *pb = h ? r1 - 4 : r1 - 9;
+            u32x4 xb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dq = 0; dq < 4; ++dq) {
+                    const int q0 = 8 * s + 2 * dq, q1 = q0 + 1;
+                    const unsigned lo = q0 < 9 ? pa[q0] : pb[q0 < 14 ? q0 : 13], hi = q1 < 9 ? pa[q1] : pb[q1 < 14 ? q1 : 13];
+                    xb[s][dq] = lo | (hi << 16);
+                }
+            f32x16 e;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 sh = *(const f32x4 *)&Ssh[cbo + 8 * q];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) e[4 * q + t] = sh[t];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                e = mfma32s(as[s][2], xb[s], e);
+                e = mfma32s(as[s][1], xb[s], e);
+                e = mfma32s(as[s][0], xb[s], e);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 c4, l4, r4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; l4[t] = left_of(c4[t]); r4[t] = right_of(c4[t]); }
+                const float *wq = Filt + cbo + 8 * q;
+                taps3(dn, q, wq, 0, l4, c4, r4, true);
+                taps3(dc, q, wq, 1, l4, c4, r4, false);
+                taps3(dm, q, wq, 2, l4, c4, r4, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (hy >= 1) finalize(dm, hy - 1);
+            __syncthreads();
+        };
+        for (int hy = 0; hy < kHid; hy += 3) {
+            step(hy, d2, d0, d1);
+            step(hy + 1, d0, d1, d2);
+            step(hy + 2, d1, d2, d0);
+        }
+        finalize(d2, kHid - 1);              // (60 - 1) % 3 == 2
+    }
+}
+
+bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
+    if (!img8 || !As3 || !Ap3) return false;
+    using C = StemRmCfg<4, 2>;
+    const int wgs = (B + C::U - 1) / C::U;
+    const int grid = wgs < 256 ? wgs : 256;
+    stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B);
+    return true;
+}
+
+}  // namespace syn

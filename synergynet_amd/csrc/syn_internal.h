@@ -69,6 +69,15 @@ void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const 
                         const float *b0, const float *wd, const float *sd, const float *bd, const float *wp_pk,
                         const float *sp, const float *bp, float *Y, int B, hipStream_t s);
 
+// features.0 + features.1 from uint8 crops, row-marching schedule (stem_rm.hip).  As3: stem filter / 128 as fragments of
+// v_mfma_f32_32x32x16_bf16, [k16 step 2][piece 3][lane 64][4 dwords], lane (i = stem channel, hh = l>>5) K slot q = 8s + e:
+//   hh = 0: q < 9 -> tap (ky 0, m = q), 9 <= q < 14 -> (ky 1, m = q - 9);   hh = 1: q < 9 -> (ky 2, m = q), 9 <= q < 13 -> (ky 1, m = q - 4)
+//   with m = 3*kx + ci (the byte order of a pixel triple in the HWC image); the other slots are zero.
+// s_shift [32]: BN shift - 255/256 * sum of the (scaled) filter; Ap3: the 32->16 projection in rm_project order (1 group).
+constexpr int rm_stem_dwords() { return 2 * 3 * 256 + 32; }
+bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s);
+
 // features.18 + global average pool + the three heads fused (head_kernel.hip): NHWC [B,4,4,320] -> param [B,62].
 void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const float *scale, const float *shift,
                  const float *Wfc /*[64,1280]*/, const float *bfc, float *param, float *pool /*nullable*/, int B,

@@ -130,6 +130,8 @@ struct Net {
                 L.dst_wrm = dst;
                 dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
             }
+            if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); }     // stem_rm.hip
+            if (L.kind == STEM) { L.dst_wrm = dst; dst += syn::rm_stem_dwords(); }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
                 dst += 2 * 3 * 64 * 4;
@@ -255,7 +257,8 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 7;              // SYNERGY_HIP_EARLY_RM: bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel
+    int early_rm = 15;             // SYNERGY_HIP_EARLY_RM: bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+                                   // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
                                    // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
@@ -396,6 +399,17 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused network head: stem conv + features.1 (dw + linear project) in one launch
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
+            if (h->fusion >= 2 && img8 && (h->early_rm & 8) &&
+                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 2 * 3 * 256, P + D.dst_wpk, P + D.dst_shift,
+                                    reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, X, B, s)) {
+                li += 2;
+                mark(1);
+                if (stop_feature == 1) {
+                    HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Pj.cout * Pj.hout * Pj.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    return SYN_OK;
+                }
+                continue;
+            }
             syn::launch_stem_block1(img, img8, P + L.dst_wpk, h->fusion >= 2 ? reinterpret_cast<const unsigned *>(P + L.dst_wb3) : nullptr, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                     P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, X, B, s);
             li += 2;
@@ -654,7 +668,37 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                                 dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
         }
-        if (L.dst_wrm) {                 // row-marching early blocks: v_mfma_f32_32x32x16_bf16 fragments (syn_internal.h)
+        if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 in its K-slot order + folded shift
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
+            float *fsh = pk.data() + L.dst_wrm + 2 * 3 * 256;
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            auto tapw = [&](int co, int ky, int m) { return w[co * 27 + (m % 3) * 9 + ky * 3 + m / 3] * bn_scale[co]; };   // m = 3*kx + ci
+            for (int st = 0; st < 2; ++st)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                        const int co = lane & 31, hh = lane >> 5;
+                        for (int e = 0; e < 2; ++e) {
+                            const int q = 8 * st + 2 * d + e;
+                            float v = 0.f;
+                            if (hh == 0) { if (q < 9) v = tapw(co, 0, q); else if (q < 14) v = tapw(co, 1, q - 9); }
+                            else { if (q < 9) v = tapw(co, 2, q); else if (q < 13) v = tapw(co, 1, q - 4); }
+                            split(v * (1.0f / 128.0f), pc[e]);       // power of two: exact
+                        }
+                        for (int pcs = 0; pcs < 3; ++pcs) dp[((size_t)(st * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                    }
+            for (int co = 0; co < 32; ++co) {
+                double sum = 0;
+                for (int t = 0; t < 27; ++t) sum += (double)(w[co * 27 + t] * bn_scale[co]);
+                fsh[co] = (float)((double)(beta[co] - mean[co] * bn_scale[co]) - 255.0 / 256.0 * sum);
+            }
+        } else if (L.dst_wrm) {          // row-marching early blocks: v_mfma_f32_32x32x16_bf16 fragments (syn_internal.h)
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
             auto split = [](float x, unsigned (&pc)[3]) {
                 for (int i = 0; i < 3; ++i) {
@@ -1067,19 +1111,20 @@ int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_l
 // Profiling hook, not part of include/synergy_hip.h: runs the backbone with the fused block of
 // .features[feature] instrumented; out8 (host) = summed s_memtime ticks of wave 0 per stage
 // {stage0, expand, barrier, depthwise, barrier, project, epilogue} and the workgroup count.
+// out8: 8 counters as above + 24 more (row-marching kernels: busy cycles per wave id of the workgroup) = 32 values.
 int syn_debug_profile_block(syn_handle *h, const float *img, int B, int feature, unsigned long long *out8) {
     if (!h || !img || !out8 || B <= 0) return fail(SYN_ERR_INVALID, "syn_debug_profile_block: bad argument");
     if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_debug_profile_block: backbone weights not loaded");
     DeviceGuard g(h->device);
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&d, 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 32 * sizeof(unsigned long long)));
     float *param = nullptr;
     HIP_TRY(hipMalloc((void **)&param, (size_t)B * 62 * sizeof(float)));
     int rc = run_backbone(h, img, nullptr, B, param, nullptr, nullptr, -1, nullptr, feature, d);
     if (rc == SYN_OK) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out8, d, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     (void)hipFree(d);
     (void)hipFree(param);

@@ -16,8 +16,10 @@ x = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=1))).cuda()
 names = ['stage0', 'expand', 'bar1', 'dw', 'bar2', 'project', 'epilog']
 print(f'{"feature":>8s} ' + ' '.join(f'{n:>9s}' for n in names) + '     total  (shader cycles per tile, view of wave 0)')
 for f in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (2, 3, 4, 5, 7, 8, 11, 12, 14, 15, 17)):
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 32)()
     abi.check(abi.lib().syn_debug_profile_block(m._h, x.data_ptr(), B, f, out))
     n = max(out[7], 1)
     v = [out[i] / n for i in range(7)]
     print(f'{f:8d} ' + ' '.join(f'{t:9.1f}' for t in v) + f' {sum(v):9.1f}   wgs={out[7]}')
+    if any(out[8:]):
+        print('         busy cycles per step by wave id of the workgroup (row-marching kernels): ' + ' '.join(f'{out[8 + i] / n:.0f}' for i in range(24) if out[8 + i]))
