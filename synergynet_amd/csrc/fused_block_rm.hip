@@ -478,17 +478,38 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
         fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units);
 }
 
-//                  CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
-using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, 4, 4>;    // features.2   60 -> 30      4 x (3 + 1) waves, 4 per SIMD
-using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, 2>;    // features.3   30            2 x (5 + 1) waves
-using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, 2>;    // features.4   30 -> 15      2 x (5 + 1) waves, two faces per unit
+// Units per workgroup: as many as fit a CU, but a batch must still fill the chip -- the kernels are persistent over units, so with
+// fewer units than 256 workgroups x U the time of a launch stops shrinking with the batch (one round of a workgroup is ~35 us per
+// unit row-march).  Smaller batches take a smaller U; below the last threshold the spatially tiled kernels (fused_block_early.hip),
+// which split a face over many workgroups, are faster and the launcher declines.
+//                       CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
+template <int U> using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, (U == 4 ? 4 : 3), U>;    // features.2   60 -> 30      U x (3 + 1) waves
+template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U>;                   // features.3   30            U x (5 + 1) waves
+template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
+
+namespace {
+int rm_threshold(const char *env, int dflt) {
+    const char *e = getenv(env);
+    return e ? atoi(e) : dflt;
+}
+}  // namespace
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p) return false;
+    // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N; SYN_RM_MIN<f>_<U> override them)
     switch (feature) {
-        case 2: launch_rm<R2>(a, B, s, 1); return true;
-        case 3: launch_rm<R3>(a, B, s, 1); return true;
-        case 4: launch_rm<R4>(a, B, s, 1); return true;
+        case 2:
+            if (B >= rm_threshold("SYN_RM_MIN2_4", 768)) { launch_rm<R2<4>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN2_2", 352)) { launch_rm<R2<2>>(a, B, s, 1); return true; }
+            return false;
+        case 3:
+            if (B >= rm_threshold("SYN_RM_MIN3_2", 448)) { launch_rm<R3<2>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN3_1", 200)) { launch_rm<R3<1>>(a, B, s, 1); return true; }
+            return false;
+        case 4:
+            if (B >= rm_threshold("SYN_RM_MIN4_2", 768)) { launch_rm<R4<2>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN4_1", 480)) { launch_rm<R4<1>>(a, B, s, 1); return true; }
+            return false;
         default: return false;
     }
 }

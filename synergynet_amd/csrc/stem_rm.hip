@@ -269,14 +269,24 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     }
 }
 
-bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
-                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
-    if (!img8 || !As3 || !Ap3) return false;
-    using C = StemRmCfg<4, 2>;
+template <class C>
+static void launch_stem_cfg(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                            const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
     const int wgs = (B + C::U - 1) / C::U;
     const int grid = wgs < 256 ? wgs : 256;
     stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B);
-    return true;
+}
+
+bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
+    if (!img8 || !As3 || !Ap3) return false;
+    // like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
+    // threshold, the spatially tiled kernel (stem_block1.hip)
+    static const int min4 = getenv("SYN_RM_MIN1_4") ? atoi(getenv("SYN_RM_MIN1_4")) : 768;
+    static const int min2 = getenv("SYN_RM_MIN1_2") ? atoi(getenv("SYN_RM_MIN1_2")) : 480;
+    if (B >= min4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B, s); return true; }
+    if (B >= min2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B, s); return true; }
+    return false;
 }
 
 }  // namespace syn

@@ -171,8 +171,12 @@ def test_full_size_properties_b1024(model, golden):
     crops = torch.from_numpy(synth.make_crops(4, seed=77)).cuda()
     big = crops.repeat(B // 4, 1, 1, 1)
     p_big = model.forward_crops_u8(big)
+    assert torch.equal(p_big, p_big[:4].repeat(B // 4, 1))             # position in the batch does not matter, bitwise
+    assert torch.equal(model.forward_crops_u8(torch.roll(big, 1, 0)), torch.roll(p_big, 1, 0))
+    # a small batch may run other kernels for the early blocks (row-marching kernels need a batch that fills the chip,
+    # fused_block_rm.hip): same numbers to fp32 rounding, not the same bits
     p4 = model.forward_crops_u8(crops)
-    assert torch.equal(p_big, p4.repeat(B // 4, 1))
+    assert rel_max(p_big[:4].cpu().numpy(), p4.cpu().numpy()) < 1e-5
     params = torch.from_numpy(synth.make_params(8, seed=5)).cuda().repeat(B // 8, 1)
     mesh = model.reconstruct(params, dense=True)
     assert torch.equal(mesh[:8].repeat(B // 8, 1, 1), mesh)
@@ -182,17 +186,59 @@ def test_full_size_properties_b1024(model, golden):
     assert torch.isfinite(mesh).all()
 
 
+@pytest.fixture(scope='module')
+def model_tiled_early(model, pack, backbone_sd):
+    """Same schedule as `model`, but with the early blocks on the spatially tiled kernels at EVERY batch size
+    (SYNERGY_HIP_EARLY_RM=0): by default batches of a few hundred faces and more run them on the row-marching kernels
+    (fused_block_rm.hip, stem_rm.hip), so bits may differ between a small and a large batch there."""
+    from synergynet_amd.synergy3DMM import SynergyNet
+    os.environ['SYNERGY_HIP_FUSION'] = model._test_fusion
+    os.environ['SYNERGY_HIP_EARLY_RM'] = '0'
+    try:
+        return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    finally:
+        os.environ.pop('SYNERGY_HIP_FUSION', None)
+        os.environ.pop('SYNERGY_HIP_EARLY_RM', None)
+
+
 @pytest.mark.parametrize('B', [1, 2, 5, 96, 97, 190, 192, 193, 194, 200])
-def test_small_batch_schedules_are_bitwise_batch_independent(model, B):
+def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, B):
     """Below ~200 faces the late blocks and the tail run in the output-channel-sliced schedule (fused_block_bf3.hip
     kSliceMaxGrid, head_kernel.hip launch_head_bf16x3); a face's parameters must not depend on which schedule ran."""
     import torch
     from synergynet_amd import synth
+    model = model_tiled_early
     crops = torch.from_numpy(synth.make_crops(8, seed=78)).cuda()
     ref = model.forward_crops_u8(crops.repeat(64, 1, 1, 1))[:8]          # B = 512: fused schedule
     idx = torch.arange(B) % 8
     got = model.forward_crops_u8(crops[idx.cuda()].contiguous())
     assert torch.equal(got, ref[idx.cuda()])
+
+
+@pytest.mark.parametrize('B', [200, 224, 352, 353, 480, 511, 768, 769, 1030])
+def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_early, backbone_sd, B):
+    """The early blocks switch kernels with the batch size (tiled below a few hundred faces, row-marching with 1, 2 or 4 units
+    per workgroup above: fused_block_rm.hip / stem_rm.hip launchers).  On DISTINCT faces, at batch sizes on both sides of every
+    threshold (incl. odd sizes: features.4 marches two faces per unit, the last unit of an odd batch is half empty): every face
+    equals the all-tiled schedule to fp32 rounding, and a spot check of faces against the oracle."""
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    if model._test_fusion != '2':
+        pytest.skip('the row-marching kernels belong to the default schedule')
+    crops = synth.make_crops(B, seed=500 + B)
+    crops[::2] = synth.make_crops((B + 1) // 2, seed=900 + B, smooth=True)
+    cd = torch.from_numpy(crops).cuda()
+    got = model.forward_crops_u8(cd)
+    ref = model_tiled_early.forward_crops_u8(cd)
+    g, r = got.cpu().numpy().astype(np.float64), ref.cpu().numpy().astype(np.float64)
+    per_face = np.abs(g - r).max(axis=1) / np.abs(r).max(axis=1)
+    assert per_face.max() < 1e-5, f'face {per_face.argmax()}: {per_face.max():.3e}'
+    pick = np.unique(np.r_[0, 1, B // 2, B - 2, B - 1])
+    want, _ = backbone_torch.mobilenet_v2_forward(backbone_sd, synth.normalize_crops(crops[pick]))
+    assert rel_max(got[torch.from_numpy(pick).cuda()].cpu().numpy(), want.numpy()) < TOL
+    # bitwise independence of the position inside a batch of this size
+    assert torch.equal(model.forward_crops_u8(torch.roll(cd, 3, 0)), torch.roll(got, 3, 0))
 
 
 def test_two_stream_pipeline_equals_sequential_calls(model):
