@@ -355,10 +355,11 @@ def main():
                     pass
         ceiling = PEAK_BF16_MFMA_TFLOPS / 6.0
         roof = dict(bound='mfma',
-                    kernel=f'syn::fused_block_{{early,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
-                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs); fp32-accurate results on '
-                           f'v_mfma_f32_16x16x32_bf16 with an exact 3-way bf16 split of both operands (6 MFMAs per K=32 block); '
-                           f'algorithmic fp32 FLOPs priced against the fp32 (f32-input) MFMA peak',
+                    kernel=f'syn::fused_block_{{rm,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
+                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; features.2-4 row-marching with the '
+                           f'hidden activations in registers, features.5-17 whole-image tiles in LDS); fp32-accurate results on '
+                           f'v_mfma_f32_{{32x32x16,16x16x32}}_bf16 with an exact 3-way bf16 split of both operands (6 MFMAs per block '
+                           f'product); algorithmic fp32 FLOPs priced against the fp32 (f32-input) MFMA peak',
                     achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                     # the pipe these kernels actually issue on: 6 bf16 MFMAs per fp32 block product -> ceiling 2500 / 6 TFLOP/s of

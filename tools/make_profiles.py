@@ -1,35 +1,70 @@
-"""Copy a tools_round.sh result directory into profiles/<name>/ and derive profiles/traffic_r1.json.
-usage: python tools/make_profiles.py gpurun_out/round_<tag> r1"""
+"""Copy a tools/round_profile.sh result directory into profiles/<name>/ and derive profiles/traffic_<name>.json.
+usage: python tools/make_profiles.py gpurun_out/round_<tag> r2"""
 import csv, glob, json, os, shutil, sys
 src, name = sys.argv[1], sys.argv[2]
 dst = os.path.join('profiles', name)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, 'stats', 'k_kernel_stats.csv'), os.path.join(dst, 'kernel_stats_b1024.csv'))
-shutil.copy(os.path.join(src, 'stats', 'k_agent_info.csv'), os.path.join(dst, 'agent_info.csv'))
-shutil.copy(os.path.join(src, 'bench.json'), os.path.join(dst, 'bench_b1024.json'))
-raw = {}
-counts = {}
-for kind in ('fetch', 'write'):
-    agg, cnt = {}, {}
-    for f in glob.glob(os.path.join(src, kind, '*counter_collection.csv')):
-        for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name']
-            agg[k] = agg.get(k, 0.0) + float(r['Counter_Value'])
-            cnt[k] = cnt.get(k, 0) + 1
-    raw[kind] = {k: agg[k] / cnt[k] for k in agg}
-    counts[kind] = cnt
-json.dump(raw, open(os.path.join(dst, 'hbm_pmc_raw_b1024.json'), 'w'), indent=1)
-n_fwd = min(c for k, c in counts['fetch'].items() if 'stem_block1' in k)          # one stem launch per forward
-fam = [k for k in raw['fetch'] if 'fused_block' in k]
-rd = sum(raw['fetch'][k] * 2 * 1024 * counts['fetch'][k] / n_fwd for k in fam)
-wr = sum(raw['write'][k] * 1024 * counts['write'][k] / n_fwd for k in fam)
-n_launch = sum(counts['fetch'][k] for k in fam) / n_fwd
-out = dict(source='rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) of bench.py B=1024; '
-                  'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); KB -> bytes',
+
+
+def cp(a, b):
+    if os.path.isfile(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+
+
+cp('stats/k_kernel_stats.csv', 'kernel_stats_b1024.csv')
+cp('stats1/k_kernel_stats.csv', 'kernel_stats_b1024_one_stream.csv')
+cp('stats_r50/k_kernel_stats.csv', 'resnet50_kernel_stats_b512.csv')
+cp('stats/k_agent_info.csv', 'agent_info.csv')
+cp('bench.json', 'bench_b1024.json')
+cp('bench_force_dist.json', 'bench_force_dist_b1024.json')
+cp('stage_profile_b1024.txt', 'stage_profile_b1024.txt')
+cp('pmc_raw.json', 'pmc_raw_b1024.json')
+if os.path.isfile(os.path.join(src, 'bench_force_dist.log')):      # RCCL banner + the broadcast line, without the hundreds of topology warnings
+    keep = [l for l in open(os.path.join(src, 'bench_force_dist.log'), errors='replace')
+            if ('RCCL version' in l or 'NCCL INFO' in l and ('Bootstrap' in l or 'Using network' in l or 'comm 0x' in l or 'Init COMPLETE' in l or 'Broadcast' in l)
+                or 'RCCL broadcast' in l or 'Librccl' in l)]
+    open(os.path.join(dst, 'bench_force_dist_b1024.log'), 'w').writelines(keep[:60])
+
+raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
+fetch, write = raw['fetch'], raw['write']
+launches = raw['fetch_launches']
+n_fwd = min(c for k, c in launches.items() if 'stem' in k and 'kernel' in k)          # one stem launch per forward
+fam = [k for k in fetch if 'fused_block' in k]
+rd = sum(fetch[k]['FETCH_SIZE'] * 2 * 1024 * launches[k] / n_fwd for k in fam)
+wr = sum(write[k]['WRITE_SIZE'] * 1024 * raw['write_launches'][k] / n_fwd for k in fam)
+n_launch = sum(launches[k] for k in fam) / n_fwd
+
+
+def ratio(a, b):
+    return round(a / b, 4) if b else None
+
+
+per_kernel = {}
+busy_sum = act_sum = 0.0
+for k in fetch:
+    m, v, l, w = raw['mfma'].get(k, {}), raw['valu'].get(k, {}), raw['lds'].get(k, {}), raw['wait'].get(k, {})
+    simd_cycles = m.get('GRBM_GUI_ACTIVE', 0) * 128          # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; 1024 SIMDs
+    per_kernel[k] = dict(
+        read_bytes=fetch[k]['FETCH_SIZE'] * 2 * 1024, write_bytes=write.get(k, {}).get('WRITE_SIZE', 0) * 1024,
+        mfma_pipe_busy=ratio(m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0), simd_cycles),
+        valu_insts=v.get('SQ_INSTS_VALU'), mfma_mops_bf16=v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16'),
+        valu_active_of_wave_cycles=ratio(v.get('SQ_ACTIVE_INST_VALU', 0), v.get('SQ_WAVE_CYCLES', 0)),
+        lds_insts=l.get('SQ_INSTS_LDS'), lds_bank_conflict_of_active=ratio(l.get('SQ_LDS_BANK_CONFLICT', 0), l.get('SQ_LDS_IDX_ACTIVE', 0)),
+        lds_array_busy=ratio(l.get('SQ_LDS_IDX_ACTIVE', 0), m.get('GRBM_GUI_ACTIVE', 0) * 32),      # 256 LDS arrays, counter summed over XCDs
+        wait_any_of_wave_cycles=ratio(w.get('SQ_WAIT_ANY', 0), v.get('SQ_WAVE_CYCLES', 0)),
+        wait_inst_any_of_wave_cycles=ratio(w.get('SQ_WAIT_INST_ANY', 0), v.get('SQ_WAVE_CYCLES', 0)),
+        wait_inst_lds_of_wave_cycles=ratio(w.get('SQ_WAIT_INST_LDS', 0), v.get('SQ_WAVE_CYCLES', 0)))
+    if k in fam:
+        busy_sum += m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) * raw['mfma_launches'][k]
+        act_sum += simd_cycles * raw['mfma_launches'][k]
+out = dict(source='rocprofv3 --kernel-trace --pmc <one counter group per run> of bench.py B=1024 --overlap 0 (tools/round_profile.sh): '
+                  'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads), KB -> bytes; '
+                  'mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 128): the counter sums the per-SIMD busy cycles '
+                  'of all 1024 SIMDs and GRBM_GUI_ACTIVE arrives summed over the 8 XCDs',
            fused_block_launches_per_forward=n_launch, fused_block_bytes_per_forward=dict(read=rd, write=wr),
-           fused_block_bytes_per_launch=round((rd + wr) / n_launch),
-           all_kernels_bytes_per_launch={k: dict(read=raw['fetch'][k] * 2 * 1024, write=raw['write'].get(k, 0) * 1024) for k in raw['fetch']})
-json.dump(out, open('profiles/traffic_r1.json', 'w'), indent=1)
-print('launches/forward', n_launch, 'read MB', rd / 1e6, 'write MB', wr / 1e6)
+           fused_block_bytes_per_launch=round((rd + wr) / n_launch), fused_block_mfma_pipe_busy=ratio(busy_sum, act_sum),
+           per_kernel=per_kernel)
+json.dump(out, open(os.path.join('profiles', f'traffic_{name}.json'), 'w'), indent=1)
+print('launches/forward', n_launch, 'read MB', rd / 1e6, 'write MB', wr / 1e6, 'family MFMA pipe busy', out['fused_block_mfma_pipe_busy'])
 d = json.load(open(os.path.join(dst, 'bench_b1024.json')))
-print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d.get('cpu_baseline'))
+print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], {k: v for k, v in d.get('cpu_baseline', {}).items() if k in ('value', 'cores', 'kind')})
