@@ -211,8 +211,9 @@ def time_steps(fn, steps, warmup, sync):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults: 0.35 s of timed work after 35 ms of warm-up -- a 20-step / 40 ms window reads ~5 % low (clocks still ramping)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=None, help='faces per GPU per step (default 1024; 128 with --lmk-only; 512 with --arch resnet50)')
     ap.add_argument('--lmk-only', action='store_true', help='BASELINE configs[1]: 68 landmarks + pose only, no 53215-vertex mesh')
     ap.add_argument('--no-cpu-baseline', action='store_true')
