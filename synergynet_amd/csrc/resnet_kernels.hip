@@ -411,4 +411,151 @@ void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bi
     pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride);
 }
 
+// =====================================================================================
+// 7x7 / 2 stem on the bf16 matrix pipe for uint8 crops (round 2), same construction as stem_rm.hip:
+//   * raw pixel bytes ARE bf16 numbers, so only the filter is split (3 MFMAs per k16 step); (2p-255)/256 = p/128 - 255/256 is
+//     folded into filter (/128) and shift; zero padding of the normalised image = raw 127.5 (0x42FF);
+//   * im2col K order: kernel row ky contributes 22 consecutive elements of the image row (one don't-care byte + 7 pixels x 3
+//     channels, so that every pair of K slots is a 4-byte aligned LDS dword), 7 x 22 = 154 -> ten k16 steps; lane half h holds
+//     slots 8h..8h+7 of a step.  Whether a half's pair of a step lies in the same kernel row as the other half's (+16 bytes) or
+//     in the next one (row pointer + 1, -28 bytes) is a compile-time property of the slot, so two per-lane pointer tables
+//     (rsame / rsel, rebuilt per output row from scalar ring offsets) give every ds_read_b32 an immediate offset;
+//   * a compute wave = (face, 32 of the 64 channels) holds its 120 weight-fragment registers for the whole kernel and walks the
+//     60 output rows x 2 column blocks; one service wave per workgroup converts image rows to bf16 into a 16-slot LDS ring.
+// BN + ReLU epilogue, NHWC store.  (Was: a direct VALU convolution, 1.44 ms of the 12.4 ms forward at B = 512.)
+// =====================================================================================
+namespace {
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+constexpr int kRsRowEl = 384, kRsSlots = 16, kRsPadL = 12;
+constexpr unsigned kRsPad = 0x42FFu;
+__device__ __forceinline__ f32x16s mfma_rs(u32x4s a, u32x4s b, f32x16s c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a), __builtin_bit_cast(bf16x8s, b), c, 0, 0, 0);
+}
+}  // namespace
+
+template <int U>
+__global__ __launch_bounds__((2 * U + 1) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][10][3][64][4]*/,
+                             const float *__restrict__ s_shift /*[64] folded*/, float *__restrict__ out /*[B,60,60,64]*/, int B) {
+    constexpr int UNIT_DW = (kRsSlots + 1) * kRsRowEl / 2, NT = (2 * U + 1) * 64;
+    __shared__ __attribute__((aligned(16))) unsigned smem[U * UNIT_DW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < U * UNIT_DW; i += NT) smem[i] = kRsPad | (kRsPad << 16);      // padding row, side padding, tails
+    __syncthreads();
+
+    if (wave_wg == 2 * U) {
+        // ---- service wave: image rows -> bf16 -> ring (row iy -> slot iy & 15) ----
+        constexpr int PER_ROW = kImg * 3 / 4, TOTAL = U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
+        auto stage_rows = [&](int fb, int iy0) {
+            const uint8_t *fbase = img + (size_t)fb * kImg * kImg * 3;
+            unsigned v[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                const int iy = iy0 + r;
+                const unsigned off = (unsigned)((u * kImg + iy) * kImg * 3 + 4 * d);
+                v[it] = 0u;
+                if (i < TOTAL && fb + u < B && iy < kImg) v[it] = *reinterpret_cast<const unsigned *>(fbase + off);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                const int iy = iy0 + r;
+                if (i < TOTAL && iy < kImg) {
+                    const unsigned b0 = __builtin_bit_cast(unsigned, (float)(v[it] & 0xff)), b1 = __builtin_bit_cast(unsigned, (float)((v[it] >> 8) & 0xff));
+                    const unsigned b2 = __builtin_bit_cast(unsigned, (float)((v[it] >> 16) & 0xff)), b3 = __builtin_bit_cast(unsigned, (float)(v[it] >> 24));
+                    u32x2s o;
+                    o[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+                    o[1] = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+                    *reinterpret_cast<u32x2s *>(smem + u * UNIT_DW + (iy & (kRsSlots - 1)) * (kRsRowEl / 2) + kRsPadL / 2 + 2 * d) = o;
+                }
+            }
+        };
+        for (int fb = blockIdx.x * U; fb < B; fb += gridDim.x * U) {
+            stage_rows(fb, 0);
+            stage_rows(fb, 2);
+            __syncthreads();                                   // (P) image rows 0..3
+            for (int oy = 0; oy < 60; ++oy) {
+                stage_rows(fb, 2 * oy + 4);                    // what output row oy+1 adds
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ---- compute wave: channels 32G .. 32G+31 of face fb + uw ----
+    const int uw = wave_wg >> 1, G = wave_wg & 1;
+    const int j = lane & 31, h = lane >> 5;
+    u32x4s as[10][3];
+#pragma unroll
+    for (int s = 0; s < 10; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) as[s][p] = *(const u32x4s *)(As3 + ((size_t)(G * 10 + s) * 3 + p) * 256 + lane * 4);
+    f32x4 sh4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh4[q] = *(const f32x4 *)&s_shift[32 * G + 8 * q + 4 * h];
+    const char *ring = reinterpret_cast<const char *>(smem + uw * UNIT_DW);
+
+    for (int fb = blockIdx.x * U; fb < B; fb += gridDim.x * U) {
+        const int f = fb + uw;
+        __syncthreads();                                       // (P)
+        for (int oy = 0; oy < 60; ++oy) {
+            // byte offsets of the seven image rows 2oy-3 .. 2oy+3 inside the ring (the padding row for rows outside the image)
+            int rowoff[8];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const int iy = 2 * oy - 3 + r;
+                rowoff[r] = ((unsigned)iy < (unsigned)kImg ? (iy & (kRsSlots - 1)) : kRsSlots) * (kRsRowEl * 2);
+            }
+            rowoff[7] = rowoff[6];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int col = 32 * c + j;
+                const int lanebase = (6 * (col < 60 ? col : 59) + 2) * 2;             // first byte of this lane's 22-element runs
+                f32x16s e;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) e[4 * q + t] = sh4[q][t];
+#pragma unroll
+                for (int s = 0; s < 10; ++s) {
+                    u32x4s xb;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk0 = 16 * s + 2 * t, r0 = kk0 / 22, m0 = kk0 % 22;          // compile-time
+                        // half 0 reads (r0, m0); half 1 reads 8 slots further: same row (+16 bytes) or the next row (-28 bytes)
+                        const int a0 = rowoff[r0] + 2 * m0;
+                        const int a1 = m0 <= 12 ? rowoff[r0] + 2 * m0 + 16 : rowoff[r0 + 1] + 2 * m0 - 28;
+                        xb[t] = *reinterpret_cast<const unsigned *>(ring + lanebase + (h ? a1 : a0));
+                    }
+                    e = mfma_rs(as[s][2], xb, e);
+                    e = mfma_rs(as[s][1], xb, e);
+                    e = mfma_rs(as[s][0], xb, e);
+                }
+                if (col < 60 && f < B) {
+                    float *dst = out + ((size_t)(f * 60 + oy) * 60 + col) * 64 + 32 * G + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(f32x4 *)(dst + 8 * q) = (f32x4){fmaxf(e[4 * q], 0.f), fmaxf(e[4 * q + 1], 0.f), fmaxf(e[4 * q + 2], 0.f), fmaxf(e[4 * q + 3], 0.f)};
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s) {
+    if (!img8 || !As3) return false;
+    constexpr int U = 2;
+    const int wgs = (B + U - 1) / U;
+    resnet_stem_mfma_kernel<U><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B);
+    return true;
+}
+
 }  // namespace syn

@@ -166,6 +166,7 @@ const Net &net() {
 struct RConv {
     int cin, cout, k, stride, pad, hin, hout;
     size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: 3-way bf16 split, MFMA lane order (dwords)
+    size_t dst_wrm = 0;                                   // stem only: fragments + folded shift of resnet_stem_mfma_kernel
 };
 struct RBlock { int c1, c2, c3, ds; };
 struct ResNet50 {
@@ -208,6 +209,7 @@ struct ResNet50 {
             c.dst_shift = dst; dst += npad;
             c.dst_w3 = 0;
             if (c.cin % 32 == 0) { c.dst_w3 = dst; dst += (size_t)npad * c.cin * c.k * c.k * 3 / 2; }
+            if (c.cin == 3) { c.dst_wrm = dst; dst += syn::rn_stem_dwords(); }
             flops += 2.0 * c.cin * c.k * c.k * (double)c.cout * c.hout * c.hout;
             const size_t osz = (size_t)c.cout * c.hout * c.hout;
             buf_big = osz > buf_big ? osz : buf_big;
@@ -257,7 +259,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 15;             // SYNERGY_HIP_EARLY_RM: bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 31;             // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
@@ -505,7 +507,10 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                          c.stride, c.pad, act, s);
     };
     const RConv &st = n.convs[0];
-    syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);     // conv1+bn1+relu (:231-233)
+    // conv1+bn1+relu (:231-233): uint8 crops on the bf16 matrix pipe (batches that give every CU a workgroup), else the direct kernel
+    if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
+          syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 3 * 256, A, B, s)))
+        syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
     syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s);                                                    // maxpool (:234)
     for (const RBlock &b : n.blocks) {                     // Bottleneck.forward (:114-136)
         conv(n.convs[b.c1], X, nullptr, T1, 1);
@@ -813,6 +818,42 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                 for (int ci = 0; ci < c.cin; ++ci)
                     for (int t = 0; t < taps; ++t)
                         dw[(size_t)nn * taps * c.cin + (size_t)t * c.cin + ci] = w[((size_t)nn * c.cin + ci) * taps + t];
+        }
+        if (c.dst_wrm) {   // 7x7 stem for the bf16 pipe: K order / folding documented in syn_internal.h
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_wrm);
+            float *fsh = pk.data() + c.dst_wrm + 2 * 10 * 3 * 256;
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            for (int G = 0; G < 2; ++G)
+                for (int st = 0; st < 10; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            const int co = 32 * G + (lane & 31), hh = lane >> 5;
+                            for (int e = 0; e < 2; ++e) {
+                                const int kk = 16 * st + 8 * hh + 2 * d + e, ky = kk / 22, m = kk % 22;
+                                float v = 0.f;
+                                if (kk < 154 && m >= 1) {
+                                    const int kx = (m - 1) / 3, ci = (m - 1) % 3;
+                                    const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
+                                    v = w[(size_t)co * 147 + ci * 49 + ky * 7 + kx] * a * (1.0f / 128.0f);
+                                }
+                                split(v, pc[e]);
+                            }
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[((size_t)((G * 10 + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                        }
+            for (int co = 0; co < 64; ++co) {
+                const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
+                double sum = 0;
+                for (int t = 0; t < 147; ++t) sum += (double)(w[(size_t)co * 147 + t] * a);
+                fsh[co] = (float)((double)(beta[co] - mean[co] * a) - 255.0 / 256.0 * sum);
+            }
         }
         if (c.dst_w3) {   // [N][tap*Cin + ci] -> [n_tile][tap*Cin/32 + kc][piece][lane][4 dwords]
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_w3);
