@@ -72,10 +72,14 @@ __device__ __forceinline__ float from_right(float v) {
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_>
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false>
 struct RmCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
+    // LEAN (features.5/6: six hidden groups, two units = 14 waves want 4 waves per SIMD, i.e. <= 128 registers, and 160 KB of LDS):
+    // the project weight fragments live in LDS instead of 24 registers, and the partial sums have ONE slot -- a second barrier per
+    // step, which the compute waves pass only after the service wave has read the previous row's sums (it arrives long before).
+    static constexpr bool LEAN = LEAN_;
     static constexpr int KS = cdivr(CIN, 16);            // k16 steps of the expand GEMM
     static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = compute waves of a unit
     static constexpr int HIDP = NG * 32;
@@ -89,12 +93,15 @@ struct RmCfg {
     static constexpr int NW = NG, NCW = U * NG, NT = (NCW + U) * 64;
     static constexpr int FR = NB * KS;                   // block-input fragments per input row
     static constexpr int XP_DW = FR * 3 * 256, PART_DW = NW * NQ * 256;
-    static constexpr int UNIT_DW = 2 * XP_DW + 2 * PART_DW;
-    static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32;     // per unit: X fragments x2 | partial sums x2;  filter 9 rows + depthwise shift | expand shift | project shift
+    static constexpr int PSLOTS = LEAN ? 1 : 2;
+    static constexpr int UNIT_DW = 2 * XP_DW + PSLOTS * PART_DW;
+    static constexpr int APL_DW = LEAN ? NG * 2 * 3 * 256 : 0;
+    static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32 + APL_DW;     // per unit: X fragments x2 | partial sums;  filter 9 rows + depthwise shift | expand shift | project shift | (LEAN) project fragments
     static_assert(COUT % 8 == 0 && COUT <= 32, "project tile");
     static_assert(S == 1 || H % 2 == 0, "stride-2 blocks have even input sizes");
-    static_assert(S == 1 ? (H + 2 <= 32 && NF == 1) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
+    static_assert(S == 1 ? (NF == 1 ? H + 2 <= 32 : 2 * H + 2 <= 32) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
+    static_assert(!LEAN || S == 1, "LEAN is implemented for the stride-1 march");
     static_assert(S == 2 || H % 3 == 0, "row ring unrolled by 3");
     static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
 };
@@ -126,6 +133,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     float *Part = reinterpret_cast<float *>(Xp + 2 * C::XP_DW);               // per unit: [2][NW][NQ][64][4]
     float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);        // [9][HIDP] + row 9 = depthwise BN shift, shared
     float *Esh = Filt + 10 * C::HIDP, *Psh = Esh + C::HIDP;                   // [HIDP], [32]
+    unsigned *ApL = reinterpret_cast<unsigned *>(Psh + 32);                   // LEAN: [NG][2][3][64][4] project fragments
     constexpr int DSH = 9 * C::HIDP;
     const int j = lane & 31, h = lane >> 5;
     const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
@@ -137,10 +145,16 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] : 0.f; }
     for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
     if (tid < 32) Psh[tid] = tid < C::COUT ? p_shift[tid] : 0.f;
+    if (C::LEAN)
+        for (int i = tid; i < C::APL_DW / 4; i += NT) *(u32x4 *)&ApL[4 * i] = *(const u32x4 *)&Ap3[4 * i];
 
     // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
     int ia, icol[C::NB], oa, ocol;
-    if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
+    if (C::S == 1 && C::NF == 2) {
+        // two H-wide faces in one block sharing their zero-padding columns: lane 0 | face 0 columns 0..H-1 | lane H+1 | face 1 | (lane 32 = the
+        // other half's lane 0): every neighbour of an image column is either an image column of the same face or a zero lane
+        ia = j > C::H; icol[0] = (j == 0 || j == C::H + 1) ? -1 : j - 1 - (C::H + 1) * ia; oa = ia; ocol = icol[0];
+    } else if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
     else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
     else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
     __syncthreads();
@@ -212,17 +226,20 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             SYNR_BARRIER();                                  // (P) row 0 is in slot 0
             if (C::S == 1) {
                 load_res(0);
+                constexpr int PM = C::PSLOTS - 1;             // partial-sum slot of output row r: r & PM
                 for (int y = 0; y < H; ++y) {
-                    if (y >= 2) reduce_row(y - 2, y & 1);     // completed by the barrier that ended step y-1; slot y&1 is rewritten in step y+1
+                    if (y >= 2) reduce_row(y - 2, y & PM);    // completed by the barrier that ended step y-1; the slot is rewritten in step y+1 (LEAN: y, after the barrier below)
+                    if (C::LEAN) SYNR_BARRIER();              // the compute waves write this step's sums only after it
                     load_res(y - 1);                          // for the next step's reduction
                     if (y + 1 < H) store_row((y + 1) & 1);    // row y+1 (requested a step ago); slot (y+1)&1 was last read in step y-1
                     if (y + 2 < H) load_row(y + 2);
                     SYNR_BARRIER();
                 }
-                reduce_row(H - 2, (H - 2) & 1);
+                reduce_row(H - 2, (H - 2) & PM);
+                if (C::LEAN) SYNR_BARRIER();
                 load_res(H - 1);
                 SYNR_BARRIER();                              // the compute waves finalized the last row
-                reduce_row(H - 1, (H - 1) & 1);
+                reduce_row(H - 1, (H - 1) & PM);
             } else {
                 for (int y = 0; y < H; ++y) {
                     if (!(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
@@ -246,10 +263,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     for (int s = 0; s < C::KS; ++s)
 #pragma unroll
         for (int p = 0; p < 3; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 3 + p) * 256 + lane * 4);
+    if (!C::LEAN)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
+            for (int p = 0; p < 3; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
 
     // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
     // stores nothing (its faces are >= B)
@@ -296,7 +314,14 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     split2r(v0, v1, hh, mm, ll);
                     db[0][t] = hh; db[1][t] = mm; db[2][t] = ll;
                 }
-                acc = mac6r(ap[s], db, acc);
+                if (C::LEAN) {
+                    u32x4 apl[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) apl[p] = *(const u32x4 *)(ApL + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
+                    acc = mac6r(apl, db, acc);
+                } else {
+                    acc = mac6r(ap[s], db, acc);
+                }
             }
             float *dst = Part + (size_t)pslot * C::PART_DW + (size_t)wave * C::NQ * 256 + lane * 4;
 #pragma unroll
@@ -372,7 +397,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     __builtin_amdgcn_sched_barrier(0);          // one register quad at a time
                 }
                 SYNR_LAP(3);
-                if (y >= 1) finalize(dm, (y - 1) & 1);
+                if (C::LEAN) SYNR_BARRIER();                   // the service wave has read the previous row's sums
+                if (y >= 1) finalize(dm, (y - 1) & (C::PSLOTS - 1));
                 SYNR_LAP(4);
                 SYNR_BARRIER();
                 nsteps += 1;
@@ -383,7 +409,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 step(y + 2, d1, d2, d0);
             }
             // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
-            finalize(d2, (H - 1) & 1);
+            if (C::LEAN) SYNR_BARRIER();
+            finalize(d2, (H - 1) & (C::PSLOTS - 1));
             SYNR_BARRIER();
         } else {
             f32x16 dcur, dnext;
@@ -486,6 +513,7 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
 template <int U> using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, (U == 4 ? 4 : 3), U>;    // features.2   60 -> 30      U x (3 + 1) waves
 template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U>;                   // features.3   30            U x (5 + 1) waves
 template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
+template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true>;             // features.5/6 15            U x (6 + 1) waves, two faces per unit, 4 per SIMD
 
 namespace {
 int rm_threshold(const char *env, int dflt) {
@@ -509,6 +537,10 @@ bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStrea
         case 4:
             if (B >= rm_threshold("SYN_RM_MIN4_2", 768)) { launch_rm<R4<2>>(a, B, s, 1); return true; }
             if (B >= rm_threshold("SYN_RM_MIN4_1", 480)) { launch_rm<R4<1>>(a, B, s, 1); return true; }
+            return false;
+        case 5:
+        case 6:
+            if (B >= rm_threshold("SYN_RM_MIN5_2", 768)) { launch_rm<R5<2>>(a, B, s, 1); return true; }
             return false;
         default: return false;
     }

@@ -126,7 +126,7 @@ struct Net {
                 dst += (size_t)(round_up(L.cout, 16) / 16) * steps * 768;
             }
             L.dst_wrm = 0;
-            if (L.kind == PW && L.feature >= 2 && L.feature <= 4) {
+            if (L.kind == PW && L.feature >= 2 && L.feature <= 6) {
                 L.dst_wrm = dst;
                 dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
             }
@@ -259,7 +259,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 31;             // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 127;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
@@ -432,7 +432,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
             }
-            if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature - 2)) & 1)) {
+            if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
                 a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
             }
