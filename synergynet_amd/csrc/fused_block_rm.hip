@@ -160,6 +160,9 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     __syncthreads();
 
     if (service) {
+        // The service waves are the youngest of their SIMD and would be served last by the issue arbiter, yet every compute wave
+        // waits for them at the row barrier: raise their priority (their work is a fraction of a compute wave's).
+        __builtin_amdgcn_s_setprio(3);
         // =====================================================================================================================
         // service wave of unit uw: block-input rows -> bf16 x3 fragments in LDS; finished output rows: partial sums -> NHWC row
         // =====================================================================================================================

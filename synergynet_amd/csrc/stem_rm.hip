@@ -84,6 +84,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     __syncthreads();
 
     if (service) {
+        __builtin_amdgcn_s_setprio(3);          // every compute wave waits for this wave at the row barrier
         // ---- image rows -> bf16 -> ring: row iy of unit u lands in slot iy & 7 ----
         // two image rows of every unit per call: all dword loads first (one global round trip), then byte -> float -> bf16
         // (exact: the high half of the float) and one 8-byte LDS store per dword
