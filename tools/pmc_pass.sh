@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_pmc.sh <tag> "<counter list>"   (PMC pass only: no --stats / traces besides kernel-trace)
+# usage: bash tools/pmc_pass.sh <tag> "<counter list>"   (PMC pass only: no --stats / traces besides kernel-trace)
 tag=$1; ctrs=$2
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box via gpurun): bash tools_prof.sh <tag> [bench args]
+# usage (on the GPU box via gpurun): bash tools/prof_stats.sh <tag> [bench args]
 # runs bench.py plain, then under rocprofv3 --kernel-trace --stats, and prints a per-kernel table
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
