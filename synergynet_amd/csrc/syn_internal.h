@@ -47,6 +47,7 @@ struct FusedBlockArgs {
     unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
     const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
     const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
+    const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of
@@ -61,6 +62,12 @@ bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipSt
 constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 768; }
 constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 768; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip): expand weights as We3 below; project fragments
+// Alb_p [group HID/32][out tile COUT/16][piece 3][lane 64][4 dwords] for v_mfma_f32_16x16x32_bf16, lane (m = l&15, kg = l>>4):
+// row = output channel 16 mt + m, K slot e = hidden channel 32 G + (e < 4 ? 4 kg + e : 16 + 4 kg + e - 4) -- the order in which
+// the expand / depthwise stage leaves a lane group's eight channels.
+constexpr int lb_project_dwords(int hid, int cout) { return (hid / 32) * (cout / 16) * 768; }
+bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 

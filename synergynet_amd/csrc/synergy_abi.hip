@@ -57,6 +57,7 @@ struct Layer {
     size_t dst_wpk;      // PW layers of fused blocks: weights in MFMA lane order (fused_block.hip)
     size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
     size_t dst_wrm;      // PW layers of features.2-4: fragments of the row-marching kernel (fused_block_rm.hip), or 0
+    size_t dst_wlb;      // project layers of features.8-13: fragments of the register-resident kernel (fused_block_lb.hip), or 0
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -131,6 +132,8 @@ struct Net {
                 dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
             }
             if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); }     // stem_rm.hip
+            L.dst_wlb = 0;
+            if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             if (L.kind == STEM) { L.dst_wrm = dst; dst += syn::rm_stem_dwords(); }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
@@ -259,7 +262,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 127;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 255;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
@@ -436,7 +439,9 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
                 a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
             }
+            if (h->fusion >= 2 && a.We3 && Pj.dst_wlb && (h->early_rm & 128)) a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
+                (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
                 syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
@@ -671,6 +676,31 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                             }
                             for (int pcs = 0; pcs < 3; ++pcs)
                                 dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                        }
+        }
+        if (L.dst_wlb) {                 // register-resident 8x8 blocks: project fragments in the K order of syn_internal.h
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wlb);
+            auto split = [](float x, unsigned (&pc)[3]) {
+                for (int i = 0; i < 3; ++i) {
+                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
+                    float hf; memcpy(&hf, &u, 4);
+                    pc[i] = u >> 16; x -= hf;
+                }
+            };
+            const int ng = L.cin / 32, mtn = L.cout / 16;
+            for (int g = 0; g < ng; ++g)
+                for (int mt = 0; mt < mtn; ++mt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            const int nn = 16 * mt + (lane & 15), kg = lane >> 4;
+                            for (int e = 0; e < 2; ++e) {
+                                const int sl = 2 * d + e;
+                                const int c = 32 * g + (sl < 4 ? 4 * kg + sl : 16 + 4 * kg + sl - 4);
+                                split(w[(size_t)nn * L.cin + c] * bn_scale[nn], pc[e]);
+                            }
+                            for (int pcs = 0; pcs < 3; ++pcs)
+                                dp[(((size_t)(g * mtn + mt) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
         }
         if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 in its K-slot order + folded shift
