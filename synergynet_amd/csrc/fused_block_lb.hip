@@ -63,6 +63,25 @@ __device__ __forceinline__ f32x4 mac6l(const u32x4 (&a)[3], const u32x4 (&b)[3],
     return c;
 }
 // (by value: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- clang 19 / ROCm 7.2)
+__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 bload4f(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+// four independent accumulators side by side: an MFMA on the accumulator of the previous one waits out its latency (~2x the
+// issue time of v_mfma_f32_16x16x32_bf16); round-robin over four chains keeps the pipe paced.  Product order as mac6l.
+__device__ __forceinline__ void mac6x4(const u32x4 (&a0)[3], const u32x4 (&b0)[3], f32x4 &c0, const u32x4 (&a1)[3], const u32x4 (&b1)[3], f32x4 &c1,
+                                       const u32x4 (&a2)[3], const u32x4 (&b2)[3], f32x4 &c2, const u32x4 (&a3)[3], const u32x4 (&b3)[3], f32x4 &c3) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        c0 = mfmal(a0[PA[j]], b0[PB[j]], c0);
+        c1 = mfmal(a1[PA[j]], b1[PB[j]], c1);
+        c2 = mfmal(a2[PA[j]], b2[PB[j]], c2);
+        c3 = mfmal(a3[PA[j]], b3[PB[j]], c3);
+    }
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
@@ -77,9 +96,12 @@ __device__ __forceinline__ f32x2 dpp2(f32x2 v) {
 constexpr int kRowShr1 = 0x111, kRowShl1 = 0x101, kRowShr8 = 0x118, kRowShl8 = 0x108;   // lane n <- n-1 | n+1 | n-8 | n+8 of its 16-lane row, else 0
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, bool RES_, int FPW_ = 2>
+template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_ = 2>
 struct LbCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, FPW = FPW_;
+    static constexpr int PPF = PPF_;                     // output tiles the project fragments are fetched ahead (1 | 2)
+    static constexpr bool TLATE = COUT_ > 64;            // 96 accumulator registers: the next group's table is fetched after the project, not across it
+    static constexpr int EPF = EPF_;                     // k32 steps of the NEXT group's expand fragments fetched during the project (1 | KE)
     static constexpr bool RES = RES_;
     static constexpr int KE = CIN / 32;                  // k32 steps of the expand GEMM
     static constexpr int NG = HID / 32;                  // hidden groups
@@ -88,25 +110,31 @@ struct LbCfg {
     static constexpr int NW = FPW * NS, NT = NW * 64;
     static constexpr int XF_DW = KE * 4 * 3 * 256;       // block input of one face as fragments [KE][block 4][piece 3][lane 64][4 dwords]
     static constexpr int RED_DW = MT * 4 * 256;          // exchange buffer of one face: [stream 2][MT / 2][block 4][lane 64][4]
-    static constexpr int LDS_DW = FPW * XF_DW;
+    static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
+    static constexpr int LDS_DW = FPW * XF_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
+    static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
     static_assert(RED_DW <= XF_DW, "the exchange buffer reuses the fragments of its face");
     static_assert(!RES || CIN == COUT, "residual only on same-width blocks");
-    static_assert(2 * LDS_DW * 4 <= 160 * 1024, "two workgroups per CU");
+    static_assert((FPW == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
 // compiler fence between the phases of a hidden group: without it every load of a group is hoisted to the top of the loop body
 // and unchained arithmetic floats across the scheduling barriers (~370 registers live)
 #define SYNL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <class C>
+// PROF: s_memtime sums of every wave per phase {staging, expand, depthwise, project, exchange + store} into prof[0..4], the number
+// of waves into prof[7] (syn_debug_profile_block)
+#define SYNL_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
+
+template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/,
-                           const float *__restrict__ e_shift, const float *__restrict__ Wd /*[9][HID] scaled*/,
-                           const float *__restrict__ d_shift, const unsigned *__restrict__ Wlb /*[NG][MT][3][64][4]*/,
-                           const float *__restrict__ p_shift, float *__restrict__ Y, int B) {
+                           const float *__restrict__ Tlb /*[NG][12][32]*/, const unsigned *__restrict__ Wlb /*[NG][MT][3][64][4]*/,
+                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, unsigned long long *prof = nullptr) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
-    constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, HID = C::HID, COUT = C::COUT;
+    constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, COUT = C::COUT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = wave >> 1, st = wave & 1;
@@ -150,65 +178,85 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[mt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
 
-    // Weight fragments are fetched one step ahead of their use and scheduling barriers keep the compiler from hoisting every
-    // load of a group to its top (that spills): Ae = expand fragments of the current k32 step, Ap = project fragments of the
-    // current output tile.
-    u32x4 Ae[2][3];
+    // Per-group constants (depthwise filter and the two BN shifts of 32 channels, 1.4 KB) go through a private LDS buffer of the
+    // wave: fetched (two 16-byte loads per lane) at the start of the previous group's project, written at its end -- an L2 round
+    // trip per use would otherwise stand exposed five times per group with only two waves per SIMD to cover it.
+    float *Tb = reinterpret_cast<float *>(smem + C::FPW * C::XF_DW + wave * C::TB_DW);
+    // weights and tables through buffer loads: ONE address register (16 * lane) for every fragment, the rest is scalar -- flat
+    // addressing keeps a 64-bit lane pointer per 4 KB of fragment range alive across the loop (~25 registers)
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(We3), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Wlb), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Tlb), 0, 0x7fffffff, 0x00027000);
+    const unsigned l16 = lane * 16;
+    f32x4 tv[2];
+    auto fetch_t = [&](int G) __attribute__((always_inline)) {
+        tv[0] = bload4f(rs_t, l16, G * (C::TB_DW * 4));
+        tv[1] = bload4f(rs_t, l16 & 511, G * (C::TB_DW * 4) + 1024);            // rows 8..11; lanes 32-63 duplicate lanes 0-31
+    };
+    auto park_t = [&]() __attribute__((always_inline)) {
+        *(f32x4 *)&Tb[l4] = tv[0];
+        *(f32x4 *)&Tb[256 + (l4 & 127)] = tv[1];
+    };
+    // Weight fragments are fetched ahead of their use (expand: the next k32 step, and EPF steps of the next group during the
+    // project; project: two output tiles ahead) and compiler fences keep every load of a group from being hoisted to its top.
+    u32x4 Ae[C::EPF == 1 ? 2 : KE][2][3];
     auto fetch_e = [&](int G, int kc) __attribute__((always_inline)) {
-        const unsigned *we = We3 + (size_t)G * (2 * KE * 768);           // wave-uniform base + 32-bit lane offset
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Ae[t][p] = *(const u32x4 *)((we + ((t * KE + kc) * 3 + p) * 256) + l4);
+            for (int p = 0; p < 3; ++p)
+                Ae[kc % (C::EPF == 1 ? 2 : KE)][t][p] = bload4(rs_e, l16, G * (2 * KE * 3072) + ((t * KE + kc) * 3 + p) * 1024);
     };
-    fetch_e(st, 0);
+    fetch_t(st);
+#pragma unroll
+    for (int kc = 0; kc < C::EPF; ++kc) fetch_e(st, kc);
+    park_t();
+    __syncthreads();
+    SYNL_LAP(0);
+
     for (int G = st; G < C::NG; G += C::NS) {
         // ---- expand 1x1 (bf16 x3) + BN shift + ReLU6: D[t][r], channels 32 G + 16 t + 4 g + i of pixel (r, n) ----
         f32x4 D[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f32x4 es = *(const f32x4 *)((e_shift + 32 * G + 16 * t) + g4);
+            const f32x4 es = *(const f32x4 *)&Tb[10 * 32 + 16 * t + g4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) D[t][r] = es;
         }
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc) {
-            u32x4 A[2][3];
+            if (kc + C::EPF < KE) fetch_e(G, kc + C::EPF);
+            constexpr int SL = C::EPF == 1 ? 2 : KE;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 4; r += 2) {        // two blocks' fragments in flight, four accumulator chains
+                u32x4 Bx[2][3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) A[t][p] = Ae[t][p];
-            if (kc + 1 < KE) fetch_e(G, kc + 1);
+                for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                u32x4 Bx[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Bx[p] = *(const u32x4 *)&Xf[((kc * 4 + r) * 3 + p) * 256 + lane * 4];
-                D[0][r] = mac6l(A[0], Bx, D[0][r]);
-                D[1][r] = mac6l(A[1], Bx, D[1][r]);
-                if (r == 1) SYNL_FENCE();           // at most two blocks' fragments in flight
+                    for (int p = 0; p < 3; ++p) Bx[rr][p] = *(const u32x4 *)&Xf[((kc * 4 + r + rr) * 3 + p) * 256 + lane * 4];
+                mac6x4(Ae[kc % SL][0], Bx[0], D[0][r], Ae[kc % SL][1], Bx[0], D[1][r], Ae[kc % SL][0], Bx[1], D[0][r + 1], Ae[kc % SL][1], Bx[1], D[1][r + 1]);
+                SYNL_FENCE();
             }
-            SYNL_FENCE();
         }
+        SYNL_LAP(1);
         // ---- depthwise 3x3 + BN shift + ReLU6, split in place into the B operand of the project step ----
-        const unsigned *wp = Wlb + (size_t)G * (MT * 768);
-        u32x4 Ap[3];
+        u32x4 Ap[C::PPF + 1][3];
+        auto fetch_p = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Ap[mt % (C::PPF + 1)][p] = bload4(rs_p, l16, G * (MT * 3072) + (mt * 3 + p) * 1024);
+        };
         u32x4 Bd[4][3];
         // two channels (one packed K dword) at a time: 18 filter registers live instead of 36
 #pragma unroll
         for (int th = 0; th < 4; ++th) {
             const int t = th >> 1, hf = th & 1;
-            if (th == 3) {                              // first project fragments: in flight behind the last depthwise pass
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Ap[p] = *(const u32x4 *)((wp + p * 256) + l4);
-            }
-            const int c0 = 32 * G + 16 * t + 2 * hf;               // + 4 g per lane group
+            if (th == 3) fetch_p(0);                    // first project fragments: in flight behind the last depthwise pass
+            const int c0 = 16 * t + 2 * hf;             // + 4 g per lane group
             f32x2 w[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) w[k] = *(const f32x2 *)((Wd + c0 + k * HID) + g4);
-            const f32x2 dsh = *(const f32x2 *)((d_shift + c0) + g4);
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x2 *)&Tb[k * 32 + c0 + g4];
+            const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
             f32x2 E[4], O[4];
@@ -246,21 +294,27 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             }
             SYNL_FENCE();
         }
+        SYNL_LAP(2);
         // ---- project 1x1 (bf16 x3), K = this group ----
-        if (G + C::NS < C::NG) fetch_e(G + C::NS, 0);
+        const bool more = G + C::NS < C::NG;
+        if (C::PPF > 1) fetch_p(1);
+        if (more) {
+            if (!C::TLATE) fetch_t(G + C::NS);
+#pragma unroll
+            for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            u32x4 A[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) A[p] = Ap[p];
-            if (mt + 1 < MT) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Ap[p] = *(const u32x4 *)((wp + ((mt + 1) * 3 + p) * 256) + l4);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][r] = mac6l(A, Bd[r], acc[mt][r]);
+            if (mt + C::PPF < MT) fetch_p(mt + C::PPF);
+            mac6x4(Ap[mt % (C::PPF + 1)], Bd[0], acc[mt][0], Ap[mt % (C::PPF + 1)], Bd[1], acc[mt][1], Ap[mt % (C::PPF + 1)], Bd[2], acc[mt][2],
+                   Ap[mt % (C::PPF + 1)], Bd[3], acc[mt][3]);
             SYNL_FENCE();
         }
+        if (more) {
+            if (C::TLATE) fetch_t(G + C::NS);           // (no registers to carry the table through the project: an exposed L2 round trip per group)
+            park_t();
+        }
+        SYNL_LAP(3);
     }
 
     // ---- exchange: wave `st` keeps the output tiles mt with (mt & 1) == st and hands the others to its partner ----
@@ -276,10 +330,9 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
         for (int r = 0; r < 4; ++r) *(f32x4 *)&Red[(((st * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4] = acc[mt][r];
     }
     __syncthreads();
-    if (!real) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if ((mt & 1) != st) continue;
+        if ((mt & 1) != st || !real) continue;
         const int nch = 16 * mt + 4 * ge;
         const f32x4 psh = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
@@ -292,18 +345,24 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             *(f32x4 *)&Y[at] = v;
         }
     }
+    SYNL_LAP(4);
+    if (PROF && lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], 1ull);
+    }
 }
 
 template <class C>
 static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::FPW - 1) / C::FPW;
-    fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Alb_p, a.p_shift, a.Y, B);
+    if (a.prof) fused_block_lb_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.We3, a.Tlb, a.Alb_p, a.p_shift, a.Y, B, a.prof);
+    else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.We3, a.Tlb, a.Alb_p, a.p_shift, a.Y, B);
 }
 
-//                    CIN  HID COUT  RES
-using L8 = LbCfg<      64, 384,  64, true>;     // features.8-10
-using L11 = LbCfg<     64, 384,  96, false>;    // features.11
-using L12 = LbCfg<     96, 576,  96, true>;     // features.12, 13
+//                    CIN  HID COUT  RES  EPF PPF     (96 output channels = 96 accumulator registers: shallower prefetch or it spills)
+using L8 = LbCfg<      64, 384,  64, true,  2, 2>;     // features.8-10
+using L11 = LbCfg<     64, 384,  96, false, 1, 1>;     // features.11
+using L12 = LbCfg<     96, 576,  96, true,  1, 1>;     // features.12, 13
 
 static int lb_min_batch(int feature) {
     // below: too few workgroups to put two on every CU (the tiled kernel is faster); SYN_LB_MIN<f> overrides
@@ -314,7 +373,7 @@ static int lb_min_batch(int feature) {
 }
 
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
-    if (!a.We3 || !a.Alb_p || a.prof) return false;
+    if (!a.We3 || !a.Alb_p || !a.Tlb) return false;
     if (B < lb_min_batch(feature)) return false;
     switch (feature) {
         case 8: case 9: case 10: launch_lb<L8>(a, B, s); return true;

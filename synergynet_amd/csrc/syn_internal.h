@@ -48,6 +48,7 @@ struct FusedBlockArgs {
     const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
     const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
     const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
+    const float *Tlb = nullptr;                       // ... and its per-group constants table
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of
@@ -66,7 +67,9 @@ bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStrea
 // Alb_p [group HID/32][out tile COUT/16][piece 3][lane 64][4 dwords] for v_mfma_f32_16x16x32_bf16, lane (m = l&15, kg = l>>4):
 // row = output channel 16 mt + m, K slot e = hidden channel 32 G + (e < 4 ? 4 kg + e : 16 + 4 kg + e - 4) -- the order in which
 // the expand / depthwise stage leaves a lane group's eight channels.
+// Tlb [group][12][32] floats: rows 0-8 the scaled depthwise filter (tap-major), 9 the depthwise BN shift, 10 the expand BN shift, 11 zero.
 constexpr int lb_project_dwords(int hid, int cout) { return (hid / 32) * (cout / 16) * 768; }
+constexpr int lb_table_floats(int hid) { return (hid / 32) * 12 * 32; }
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);

@@ -58,6 +58,7 @@ struct Layer {
     size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
     size_t dst_wrm;      // PW layers of features.2-4: fragments of the row-marching kernel (fused_block_rm.hip), or 0
     size_t dst_wlb;      // project layers of features.8-13: fragments of the register-resident kernel (fused_block_lb.hip), or 0
+    size_t dst_tlb;      // expand layers of features.8-13: per hidden group [12][32] floats = depthwise filter 9 rows | depthwise shift | expand shift | 0
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -134,6 +135,8 @@ struct Net {
             if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); }     // stem_rm.hip
             L.dst_wlb = 0;
             if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
+            L.dst_tlb = 0;
+            if (L.kind == PW && L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_tlb = dst; dst += syn::lb_table_floats(L.cout); }
             if (L.kind == STEM) { L.dst_wrm = dst; dst += syn::rm_stem_dwords(); }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
@@ -439,7 +442,10 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
                 a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
             }
-            if (h->fusion >= 2 && a.We3 && Pj.dst_wlb && (h->early_rm & 128)) a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
+            if (h->fusion >= 2 && a.We3 && Pj.dst_wlb && L.dst_tlb && (h->early_rm & 128)) {
+                a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
+                a.Tlb = P + L.dst_tlb;
+            }
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
@@ -770,6 +776,17 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             pk[L.dst_scale + c] = bn_scale[c];
             pk[L.dst_shift + c] = beta[c] - mean[c] * bn_scale[c];
         }
+    }
+    for (size_t li = 0; li + 1 < n.layers.size(); ++li) {      // fused_block_lb.hip: the per-group constants in one 1.5 KB run
+        const Layer &L = n.layers[li], &D = n.layers[li + 1];
+        if (!L.dst_tlb) continue;
+        float *tb = pk.data() + L.dst_tlb;
+        for (int g = 0; g < L.cout / 32; ++g)
+            for (int c = 0; c < 32; ++c) {
+                for (int k = 0; k < 9; ++k) tb[(g * 12 + k) * 32 + c] = pk[D.dst_wpk + (size_t)k * L.cout + 32 * g + c];
+                tb[(g * 12 + 9) * 32 + c] = pk[D.dst_shift + 32 * g + c];
+                tb[(g * 12 + 10) * 32 + c] = pk[L.dst_shift + 32 * g + c];
+            }
     }
     {   // features.18 (BN scale folded in) split exactly into three bf16 pieces per weight, lane-ordered for
         // v_mfma_f32_16x16x32_bf16: [n_tile 80][k_chunk 10][piece 3][lane 64][4 dwords], lane (r16, g) holds
