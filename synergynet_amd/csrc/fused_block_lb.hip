@@ -11,14 +11,22 @@
 //     blocks r-1 / r+1 -- except row 3 <-> row 4, which is a shift by 8 lanes inside a 16-lane DPP row (row_shr:8 / row_shl:8,
 //     whose zero fill is exactly the image border) -- and the horizontal ones are row_shr:1 / row_shl:1, with the filter
 //     column zeroed on the lanes where that shift crosses x = 0 | 7;
-//   * expand: D[tile t of 16 channels][block r] = shift + We . X on the exact 3-way bf16 split (6 products); the block input is
-//     staged ONCE per face as pre-split B fragments in LDS, the weights stream from L2 straight into registers;
-//   * depthwise 3x3 + BN shift + ReLU6 on the D registers (same tap order as the other kernels), split into bf16 pieces in
-//     place: lane group g = l >> 4 holds channels 4g..4g+3 of both tiles = the 8 K slots of ONE k32 step of the project
-//     GEMM (the host packs the project weights in that K order: slot e < 4 -> channel 4g + e, else 16 + 4g + e - 4);
+//   * both GEMMs run on v_mfma_f32_16x16x32_f16 with every fp32 operand carried as TWO fp16 pieces, x = a + b (a = fp16(x),
+//     b = fp16(x - a), both toward zero: 22 significant bits) and three products a a + a b + b a (b b <= 2^-22 dropped): fp16 x fp16
+//     is exact in fp32 and the accumulation is fp32, so the result is fp32-class at HALF the matrix instructions of the 3-way
+//     bf16 split (6 products).  fp16's narrow exponent is met by power-of-two operand scales folded into the constants
+//     (synergy_abi.hip): activations x 16, weights per layer to max |w| in [2^13, 2^14);
+//   * expand: D[tile t of 16 channels][block r] = 16 Se (shift + We . X); the block input is staged ONCE per face as pre-split B
+//     fragments in LDS, the weights stream from L2 straight into registers (buffer loads: one address register);
+//   * depthwise 3x3 + BN shift + ReLU6 on the D registers (same tap order as the other kernels; filter / Se and 16 x shift come
+//     pre-scaled), split into fp16 pieces in place: lane group g = l >> 4 holds channels 4g..4g+3 of both tiles = the 8 K slots of
+//     ONE k32 step of the project GEMM (the host packs the project weights in that K order);
 //   * project: acc[out tile][block] += Wp[:, group] . D, accumulators in registers across all groups of the wave;
 //   * the two waves of a face exchange half of their partial sums through LDS at the end (stream 0 + stream 1, fixed order),
-//     add the BN shift and the residual and store NHWC.  Barriers: one after staging, two at the end.
+//     rescale, add the BN shift and the residual and store NHWC.  Barriers: one after staging, two at the end.
+//   * MFMA and VALU instructions of the two waves of a SIMD do not overlap (tools/ubench/mfma_valu_kinds.hip: t = t_mfma + t_valu
+//     for every instruction kind), so the cost of a group is the SUM of its matrix and vector instruction time: halving the
+//     products and shrinking the split (6 instead of 11 instructions per pair) is what pays, not occupancy.
 #include "syn_internal.h"
 
 #include <cstdio>
@@ -29,59 +37,45 @@ namespace syn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
-__device__ __forceinline__ float relu6l(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }
-// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
-__device__ __forceinline__ void split2l(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+// x0, x1 -> packed fp16 pieces a (high) and b (low), x = a + b to 22 bits
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
-// ... into component d of the three piece vectors
-__device__ __forceinline__ void split2v(float x0, float x1, u32x4 (&pc)[3], int d) {
-    unsigned h, m, l;
-    split2l(x0, x1, h, m, l);
-    pc[0][d] = h; pc[1][d] = m; pc[2][d] = l;
+// ... into component d of the two piece vectors
+__device__ __forceinline__ void split2v(float x0, float x1, u32x4 (&pc)[2], int d) {
+    unsigned a, b;
+    split2h(x0, x1, a, b);
+    pc[0][d] = a; pc[1][d] = b;
 }
 __device__ __forceinline__ f32x4 mfmal(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// the six partial products of weight >= 2^-16, smallest terms first (same order as the other bf16x3 kernels)
-__device__ __forceinline__ f32x4 mac6l(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
-    c = mfmal(a[2], b[0], c);
-    c = mfmal(a[0], b[2], c);
-    c = mfmal(a[1], b[1], c);
-    c = mfmal(a[1], b[0], c);
-    c = mfmal(a[0], b[1], c);
-    c = mfmal(a[0], b[0], c);
-    return c;
-}
-// (by value: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- clang 19 / ROCm 7.2)
-__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-}
-__device__ __forceinline__ f32x4 bload4f(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-}
-// four independent accumulators side by side: an MFMA on the accumulator of the previous one waits out its latency (~2x the
-// issue time of v_mfma_f32_16x16x32_bf16); round-robin over four chains keeps the pipe paced.  Product order as mac6l.
-__device__ __forceinline__ void mac6x4(const u32x4 (&a0)[3], const u32x4 (&b0)[3], f32x4 &c0, const u32x4 (&a1)[3], const u32x4 (&b1)[3], f32x4 &c1,
-                                       const u32x4 (&a2)[3], const u32x4 (&b2)[3], f32x4 &c2, const u32x4 (&a3)[3], const u32x4 (&b3)[3], f32x4 &c3) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+// the three partial products (smallest first) of four independent accumulators, round-robin
+__device__ __forceinline__ void mac3x4(const u32x4 (&a0)[2], const u32x4 (&b0)[2], f32x4 &c0, const u32x4 (&a1)[2], const u32x4 (&b1)[2], f32x4 &c1,
+                                       const u32x4 (&a2)[2], const u32x4 (&b2)[2], f32x4 &c2, const u32x4 (&a3)[2], const u32x4 (&b3)[2], f32x4 &c3) {
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < 3; ++j) {
         c0 = mfmal(a0[PA[j]], b0[PB[j]], c0);
         c1 = mfmal(a1[PA[j]], b1[PB[j]], c1);
         c2 = mfmal(a2[PA[j]], b2[PB[j]], c2);
         c3 = mfmal(a3[PA[j]], b3[PB[j]], c3);
     }
 }
+__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 bload4f(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+// (by value: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- clang 19 / ROCm 7.2)
 template <int CTRL>
 __device__ __forceinline__ float dpp1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
@@ -108,13 +102,13 @@ struct LbCfg {
     static constexpr int MT = COUT / 16;                 // output channel tiles
     static constexpr int NS = 2;                         // waves per face (hidden groups s, s + 2, ...)
     static constexpr int NW = FPW * NS, NT = NW * 64;
-    static constexpr int XF_DW = KE * 4 * 3 * 256;       // block input of one face as fragments [KE][block 4][piece 3][lane 64][4 dwords]
+    static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
     static constexpr int RED_DW = MT * 4 * 256;          // exchange buffer of one face: [stream 2][MT / 2][block 4][lane 64][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
-    static constexpr int LDS_DW = FPW * XF_DW + NW * TB_DW;
+    static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
+    static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
     static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
-    static_assert(RED_DW <= XF_DW, "the exchange buffer reuses the fragments of its face");
     static_assert(!RES || CIN == COUT, "residual only on same-width blocks");
     static_assert((FPW == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
@@ -129,8 +123,8 @@ struct LbCfg {
 
 template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/,
-                           const float *__restrict__ Tlb /*[NG][12][32]*/, const unsigned *__restrict__ Wlb /*[NG][MT][3][64][4]*/,
+void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restrict__ Weh /*[HID/16][KE][2][64][4]*/,
+                           const float *__restrict__ Tlb /*[NG][12][32]*/, const unsigned *__restrict__ Wlb /*[NG][MT][2][64][4]*/,
                            const float *__restrict__ p_shift, float *__restrict__ Y, int B, unsigned long long *prof = nullptr) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
@@ -143,7 +137,7 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
     const unsigned l4 = lane * 4, g4 = g * 4;
-    unsigned *Xf = smem + fl * C::XF_DW;
+    unsigned *Xf = smem + fl * C::FACE_DW;
     const int pix0 = 32 * (n >> 3) + (n & 7);           // pixel index of (block 0, lane column n); block r adds 8 r
 
     // ---- stage: block input of this face -> pre-split B fragments (this wave: blocks 2 st, 2 st + 1) ----
@@ -163,13 +157,14 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             for (int rr = 0; rr < 2; ++rr) {
                 f32x4 a = xv[kc][rr][0], b = xv[kc][rr][1];
                 if (!real) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
-                u32x4 pc[3];
+                a *= 16.0f; b *= 16.0f;
+                u32x4 pc[2];
                 split2v(a[0], a[1], pc, 0);
                 split2v(a[2], a[3], pc, 1);
                 split2v(b[0], b[1], pc, 2);
                 split2v(b[2], b[3], pc, 3);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *(u32x4 *)&Xf[((kc * 4 + 2 * st + rr) * 3 + p) * 256 + lane * 4] = pc[p];
+                for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[((kc * 4 + 2 * st + rr) * 2 + p) * 256 + lane * 4] = pc[p];
             }
     }
     const float mL = (n & 7) != 0 ? 1.f : 0.f, mR = (n & 7) != 7 ? 1.f : 0.f;
@@ -182,10 +177,10 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     // Per-group constants (depthwise filter and the two BN shifts of 32 channels, 1.4 KB) go through a private LDS buffer of the
     // wave: fetched (two 16-byte loads per lane) at the start of the previous group's project, written at its end -- an L2 round
     // trip per use would otherwise stand exposed five times per group with only two waves per SIMD to cover it.
-    float *Tb = reinterpret_cast<float *>(smem + C::FPW * C::XF_DW + wave * C::TB_DW);
+    float *Tb = reinterpret_cast<float *>(smem + C::FPW * C::FACE_DW + wave * C::TB_DW);
     // weights and tables through buffer loads: ONE address register (16 * lane) for every fragment, the rest is scalar -- flat
     // addressing keeps a 64-bit lane pointer per 4 KB of fragment range alive across the loop (~25 registers)
-    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(We3), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Weh), 0, 0x7fffffff, 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Wlb), 0, 0x7fffffff, 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Tlb), 0, 0x7fffffff, 0x00027000);
     const unsigned l16 = lane * 16;
@@ -200,13 +195,14 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     };
     // Weight fragments are fetched ahead of their use (expand: the next k32 step, and EPF steps of the next group during the
     // project; project: two output tiles ahead) and compiler fences keep every load of a group from being hoisted to its top.
-    u32x4 Ae[C::EPF == 1 ? 2 : KE][2][3];
+    const float c6e = Tlb[11 * 32], inv_p = Tlb[11 * 32 + 1];       // ReLU6 ceiling of the scaled expand output; accumulator -> output
+    u32x4 Ae[C::EPF == 1 ? 2 : KE][2][2];
     auto fetch_e = [&](int G, int kc) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                Ae[kc % (C::EPF == 1 ? 2 : KE)][t][p] = bload4(rs_e, l16, G * (2 * KE * 3072) + ((t * KE + kc) * 3 + p) * 1024);
+            for (int p = 0; p < 2; ++p)
+                Ae[kc % (C::EPF == 1 ? 2 : KE)][t][p] = bload4(rs_e, l16, G * (2 * KE * 2048) + ((t * KE + kc) * 2 + p) * 1024);
     };
     fetch_t(st);
 #pragma unroll
@@ -230,23 +226,23 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             constexpr int SL = C::EPF == 1 ? 2 : KE;
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {        // two blocks' fragments in flight, four accumulator chains
-                u32x4 Bx[2][3];
+                u32x4 Bx[2][2];
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) Bx[rr][p] = *(const u32x4 *)&Xf[((kc * 4 + r + rr) * 3 + p) * 256 + lane * 4];
-                mac6x4(Ae[kc % SL][0], Bx[0], D[0][r], Ae[kc % SL][1], Bx[0], D[1][r], Ae[kc % SL][0], Bx[1], D[0][r + 1], Ae[kc % SL][1], Bx[1], D[1][r + 1]);
+                    for (int p = 0; p < 2; ++p) Bx[rr][p] = *(const u32x4 *)&Xf[((kc * 4 + r + rr) * 2 + p) * 256 + lane * 4];
+                mac3x4(Ae[kc % SL][0], Bx[0], D[0][r], Ae[kc % SL][1], Bx[0], D[1][r], Ae[kc % SL][0], Bx[1], D[0][r + 1], Ae[kc % SL][1], Bx[1], D[1][r + 1]);
                 SYNL_FENCE();
             }
         }
         SYNL_LAP(1);
         // ---- depthwise 3x3 + BN shift + ReLU6, split in place into the B operand of the project step ----
-        u32x4 Ap[C::PPF + 1][3];
+        u32x4 Ap[C::PPF + 1][2];
         auto fetch_p = [&](int mt) __attribute__((always_inline)) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Ap[mt % (C::PPF + 1)][p] = bload4(rs_p, l16, G * (MT * 3072) + (mt * 3 + p) * 1024);
+            for (int p = 0; p < 2; ++p) Ap[mt % (C::PPF + 1)][p] = bload4(rs_p, l16, G * (MT * 2048) + (mt * 2 + p) * 1024);
         };
-        u32x4 Bd[4][3];
+        u32x4 Bd[4][2];
         // two channels (one packed K dword) at a time: 18 filter registers live instead of 36
 #pragma unroll
         for (int th = 0; th < 4; ++th) {
@@ -262,8 +258,8 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             f32x2 E[4], O[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                E[r][0] = relu6l(D[t][r][2 * hf]);
-                E[r][1] = relu6l(D[t][r][2 * hf + 1]);
+                E[r][0] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf], 0.0f, c6e);
+                E[r][1] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf + 1], 0.0f, c6e);
                 O[r] = dsh;
             }
             // input rows q = -1 .. 4 of the block rows (row q feeds outputs q - dy, dy = 0..2: ascending dy per output).  The pins
@@ -286,10 +282,10 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                split2v(relu6l(O[r][0]), relu6l(O[r][1]), Bd[r], th);
+                split2v(__builtin_amdgcn_fmed3f(O[r][0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[r][1], 0.0f, 96.0f), Bd[r], th);
                 if (hf) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(Bd[r][p]));
+                    for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(Bd[r][p]));
                 }
             }
             SYNL_FENCE();
@@ -306,7 +302,7 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (mt + C::PPF < MT) fetch_p(mt + C::PPF);
-            mac6x4(Ap[mt % (C::PPF + 1)], Bd[0], acc[mt][0], Ap[mt % (C::PPF + 1)], Bd[1], acc[mt][1], Ap[mt % (C::PPF + 1)], Bd[2], acc[mt][2],
+            mac3x4(Ap[mt % (C::PPF + 1)], Bd[0], acc[mt][0], Ap[mt % (C::PPF + 1)], Bd[1], acc[mt][1], Ap[mt % (C::PPF + 1)], Bd[2], acc[mt][2],
                    Ap[mt % (C::PPF + 1)], Bd[3], acc[mt][3]);
             SYNL_FENCE();
         }
@@ -339,7 +335,7 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
         for (int r = 0; r < 4; ++r) {
             const f32x4 o = *(const f32x4 *)&Red[((((1 - st) * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4];
             f32x4 v = st == 0 ? acc[mt][r] + o : o + acc[mt][r];        // stream 0 + stream 1
-            v += psh;
+            v = v * inv_p + psh;
             const size_t at = ((size_t)f * 64 + pixe + 8 * r) * COUT + nch;
             if (C::RES) v += *(const f32x4 *)&X[at];
             *(f32x4 *)&Y[at] = v;
@@ -355,8 +351,8 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
 template <class C>
 static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::FPW - 1) / C::FPW;
-    if (a.prof) fused_block_lb_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.We3, a.Tlb, a.Alb_p, a.p_shift, a.Y, B, a.prof);
-    else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.We3, a.Tlb, a.Alb_p, a.p_shift, a.Y, B);
+    if (a.prof) fused_block_lb_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y, B, a.prof);
+    else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y, B);
 }
 
 //                    CIN  HID COUT  RES  EPF PPF     (96 output channels = 96 accumulator registers: shallower prefetch or it spills)
@@ -373,7 +369,7 @@ static int lb_min_batch(int feature) {
 }
 
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
-    if (!a.We3 || !a.Alb_p || !a.Tlb) return false;
+    if (!a.Alb_e || !a.Alb_p || !a.Tlb) return false;
     if (B < lb_min_batch(feature)) return false;
     switch (feature) {
         case 8: case 9: case 10: launch_lb<L8>(a, B, s); return true;

@@ -48,6 +48,7 @@ struct FusedBlockArgs {
     const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
     const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
     const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
+    const unsigned *Alb_e = nullptr;                  // ... its expand fragments
     const float *Tlb = nullptr;                       // ... and its per-group constants table
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
@@ -63,12 +64,16 @@ bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipSt
 constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 768; }
 constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 768; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
-// 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip): expand weights as We3 below; project fragments
-// Alb_p [group HID/32][out tile COUT/16][piece 3][lane 64][4 dwords] for v_mfma_f32_16x16x32_bf16, lane (m = l&15, kg = l>>4):
-// row = output channel 16 mt + m, K slot e = hidden channel 32 G + (e < 4 ? 4 kg + e : 16 + 4 kg + e - 4) -- the order in which
-// the expand / depthwise stage leaves a lane group's eight channels.
-// Tlb [group][12][32] floats: rows 0-8 the scaled depthwise filter (tap-major), 9 the depthwise BN shift, 10 the expand BN shift, 11 zero.
-constexpr int lb_project_dwords(int hid, int cout) { return (hid / 32) * (cout / 16) * 768; }
+// 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip), both GEMMs on v_mfma_f32_16x16x32_f16 with every
+// operand as TWO fp16 pieces (x = a + b, 22 significant bits; three products a a, a b, b a) and power-of-two operand scaling
+// (synergy_abi.hip pack_backbone_mbv2).  Fragments [..][piece 2][lane 64][4 dwords], lane (m = l&15, kg = l>>4):
+//   Alb_e [hidden tile HID/16][k32 step CIN/32]: row = hidden channel 16 nt + m, K slot e = input channel 32 kc + 8 kg + e
+//   Alb_p [group HID/32][out tile COUT/16]:      row = output channel 16 mt + m, K slot e = hidden channel 32 G + (e < 4 ? 4 kg + e : 16 + 4 kg + e - 4)
+//     -- the order in which the expand / depthwise stage leaves a lane group's eight channels;
+//   Tlb [group][12][32] floats: rows 0-8 depthwise filter / Se (tap-major), 9: 16 x depthwise BN shift, 10: 16 Se x expand BN shift,
+//     row 11 of group 0: {96 Se, 1 / (16 Sp)}.
+constexpr int lb_project_dwords(int hid, int cout) { return (hid / 32) * (cout / 16) * 512; }
+constexpr int lb_expand_dwords(int cin, int hid) { return (hid / 16) * (cin / 32) * 512; }
 constexpr int lb_table_floats(int hid) { return (hid / 32) * 12 * 32; }
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)

@@ -58,7 +58,8 @@ struct Layer {
     size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
     size_t dst_wrm;      // PW layers of features.2-4: fragments of the row-marching kernel (fused_block_rm.hip), or 0
     size_t dst_wlb;      // project layers of features.8-13: fragments of the register-resident kernel (fused_block_lb.hip), or 0
-    size_t dst_tlb;      // expand layers of features.8-13: per hidden group [12][32] floats = depthwise filter 9 rows | depthwise shift | expand shift | 0
+    size_t dst_tlb;      // expand layers of features.8-13: per hidden group [12][32] floats = depthwise filter 9 rows | depthwise shift | expand shift | constants
+    size_t dst_weh;      // expand layers of features.8-13: fp16 x2 fragments of the register-resident kernel, or 0
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -136,7 +137,11 @@ struct Net {
             L.dst_wlb = 0;
             if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             L.dst_tlb = 0;
-            if (L.kind == PW && L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_tlb = dst; dst += syn::lb_table_floats(L.cout); }
+            L.dst_weh = 0;
+            if (L.kind == PW && L.relu6 && L.feature >= 8 && L.feature <= 13) {
+                L.dst_tlb = dst; dst += syn::lb_table_floats(L.cout);
+                L.dst_weh = dst; dst += syn::lb_expand_dwords(L.cin, L.cout);
+            }
             if (L.kind == STEM) { L.dst_wrm = dst; dst += syn::rm_stem_dwords(); }
             if (L.kind == STEM) {            // stem filter as bf16 x3 MFMA fragments: [n_tile 2][piece 3][lane 64][4 dwords]
                 L.dst_wb3 = dst;
@@ -444,6 +449,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             }
             if (h->fusion >= 2 && a.We3 && Pj.dst_wlb && L.dst_tlb && (h->early_rm & 128)) {
                 a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
+                a.Alb_e = reinterpret_cast<const unsigned *>(P + L.dst_weh);
                 a.Tlb = P + L.dst_tlb;
             }
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
@@ -581,6 +587,23 @@ int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 
 
 // Host-only packing of the MobileNetV2 state (BN folding, MFMA lane order, bf16 x3 split): shared by syn_load_backbone and
 // syn_pack_constants_host, so a blob packed without a device is byte-identical to what a handle exports.
+// fp32 -> fp16 bits, toward zero (what v_cvt_pkrtz_f16_f32 does to the activations), and back
+static unsigned f16_rtz(float x) {
+    unsigned u; memcpy(&u, &x, 4);
+    const unsigned sgn = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xff) - 127 + 15;
+    unsigned m = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0) return sgn;                    // fp32 zero / subnormal
+    if (e >= 31) return sgn | 0x7bffu;                          // (never reached: operands are scaled below 2^14)
+    if (e <= 0) return e < -10 ? sgn : sgn | ((m | 0x800000u) >> (14 - e));
+    return sgn | ((unsigned)e << 10) | (m >> 13);
+}
+static float f16_value(unsigned h) {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const float v = e ? ldexpf(1.0f + m / 1024.0f, e - 15) : ldexpf((float)m, -24);
+    return (h & 0x8000u) ? -v : v;
+}
+
 static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
     const Net &n = net();
     pk.assign(n.packed_count, 0.f);
@@ -684,31 +707,6 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                                 dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
         }
-        if (L.dst_wlb) {                 // register-resident 8x8 blocks: project fragments in the K order of syn_internal.h
-            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wlb);
-            auto split = [](float x, unsigned (&pc)[3]) {
-                for (int i = 0; i < 3; ++i) {
-                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
-                    float hf; memcpy(&hf, &u, 4);
-                    pc[i] = u >> 16; x -= hf;
-                }
-            };
-            const int ng = L.cin / 32, mtn = L.cout / 16;
-            for (int g = 0; g < ng; ++g)
-                for (int mt = 0; mt < mtn; ++mt)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int d = 0; d < 4; ++d) {
-                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
-                            const int nn = 16 * mt + (lane & 15), kg = lane >> 4;
-                            for (int e = 0; e < 2; ++e) {
-                                const int sl = 2 * d + e;
-                                const int c = 32 * g + (sl < 4 ? 4 * kg + sl : 16 + 4 * kg + sl - 4);
-                                split(w[(size_t)nn * L.cin + c] * bn_scale[nn], pc[e]);
-                            }
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[(((size_t)(g * mtn + mt) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
-                        }
-        }
         if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 in its K-slot order + folded shift
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
             float *fsh = pk.data() + L.dst_wrm + 2 * 3 * 256;
@@ -777,16 +775,68 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             pk[L.dst_shift + c] = beta[c] - mean[c] * bn_scale[c];
         }
     }
-    for (size_t li = 0; li + 1 < n.layers.size(); ++li) {      // fused_block_lb.hip: the per-group constants in one 1.5 KB run
-        const Layer &L = n.layers[li], &D = n.layers[li + 1];
+    for (size_t li = 0; li + 2 < n.layers.size(); ++li) {      // fused_block_lb.hip (features.8-13): fp16 x2 fragments + per-group constants
+        const Layer &L = n.layers[li], &D = n.layers[li + 1], &Pj = n.layers[li + 2];
         if (!L.dst_tlb) continue;
-        float *tb = pk.data() + L.dst_tlb;
-        for (int g = 0; g < L.cout / 32; ++g)
-            for (int c = 0; c < 32; ++c) {
-                for (int k = 0; k < 9; ++k) tb[(g * 12 + k) * 32 + c] = pk[D.dst_wpk + (size_t)k * L.cout + 32 * g + c];
-                tb[(g * 12 + 9) * 32 + c] = pk[D.dst_shift + 32 * g + c];
-                tb[(g * 12 + 10) * 32 + c] = pk[L.dst_shift + 32 * g + c];
+        // x = a + b with a = fp16(x) and b = fp16(x - a) (both toward zero) keeps 22 significant bits: fp16 x fp16 products are exact in
+        // fp32, a1 a2 + a1 b2 + b1 a2 misses b1 b2 <= 2^-22.  fp16's narrow exponent wants operands near the top of its range, so
+        // every GEMM operand is scaled by a power of two (exact), the weights per layer such that max |w| lands in [2^13, 2^14):
+        //   X16 = 16 x;  D = 16 Se (We x + shift);  E = med3(D, 0, 96 Se);  O16 = 16 dshift + sum (taps / Se) E;  B = med3(O16, 0, 96)
+        //   acc = 16 Sp (Wp o);  y = acc / (16 Sp) + pshift (+ x)
+        auto scaled = [&](const Layer &P, std::vector<float> &v) {
+            const float *w = flat + P.src_w;
+            const float *gamma = w + (size_t)P.cout * P.cin, *var = gamma + 3 * (size_t)P.cout;
+            v.resize((size_t)P.cout * P.cin);
+            float mx = 0.f;
+            for (int nn = 0; nn < P.cout; ++nn) {
+                const float sc = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
+                for (int k = 0; k < P.cin; ++k) { v[(size_t)nn * P.cin + k] = w[(size_t)nn * P.cin + k] * sc; mx = fmaxf(mx, fabsf(v[(size_t)nn * P.cin + k])); }
             }
+            int e = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &e); e = 14 - e; }            // mx * 2^e in [2^13, 2^14)
+            const float S = ldexpf(1.0f, e);
+            for (float &x : v) x *= S;
+            return S;
+        };
+        auto put = [](unsigned *dp, size_t frag, int lane, int d, float x0, float x1) {      // fragment = [piece 2][lane 64][4 dwords]
+            const unsigned a0 = f16_rtz(x0), a1 = f16_rtz(x1);
+            const unsigned b0 = f16_rtz(x0 - f16_value(a0)), b1 = f16_rtz(x1 - f16_value(a1));
+            dp[((frag * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+            dp[((frag * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+        };
+        std::vector<float> we, wp;
+        const float Se = scaled(L, we), Sp = scaled(Pj, wp);
+        const int hid = L.cout, cin = L.cin, cout = Pj.cout, ke = cin / 32, ng = hid / 32, mtn = cout / 16;
+        unsigned *de = reinterpret_cast<unsigned *>(pk.data() + L.dst_weh);        // [hidden tile 16][k32 step][piece][lane][4]: lane (m, kg) holds k = 32 kc + 8 kg + e
+        for (int nt = 0; nt < hid / 16; ++nt)
+            for (int kc = 0; kc < ke; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const size_t at = (size_t)(nt * 16 + (lane & 15)) * cin + 32 * kc + 8 * (lane >> 4) + 2 * d;
+                        put(de, (size_t)nt * ke + kc, lane, d, we[at], we[at + 1]);
+                    }
+        unsigned *dq = reinterpret_cast<unsigned *>(pk.data() + Pj.dst_wlb);       // [group][out tile][piece][lane][4], K order of syn_internal.h
+        for (int g = 0; g < ng; ++g)
+            for (int mt = 0; mt < mtn; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int nn = 16 * mt + (lane & 15), kg = lane >> 4;
+                        float x[2];
+                        for (int e = 0; e < 2; ++e) {
+                            const int sl = 2 * d + e;
+                            x[e] = wp[(size_t)nn * hid + 32 * g + (sl < 4 ? 4 * kg + sl : 16 + 4 * kg + sl - 4)];
+                        }
+                        put(dq, (size_t)g * mtn + mt, lane, d, x[0], x[1]);
+                    }
+        float *tb = pk.data() + L.dst_tlb;
+        for (int g = 0; g < ng; ++g)
+            for (int c = 0; c < 32; ++c) {
+                for (int k = 0; k < 9; ++k) tb[(g * 12 + k) * 32 + c] = pk[D.dst_wpk + (size_t)k * hid + 32 * g + c] / Se;
+                tb[(g * 12 + 9) * 32 + c] = 16.0f * pk[D.dst_shift + 32 * g + c];
+                tb[(g * 12 + 10) * 32 + c] = 16.0f * Se * pk[L.dst_shift + 32 * g + c];
+            }
+        tb[11 * 32 + 0] = 96.0f * Se;               // ReLU6 ceiling of the scaled expand output
+        tb[11 * 32 + 1] = 1.0f / (16.0f * Sp);      // project accumulator -> output
     }
     {   // features.18 (BN scale folded in) split exactly into three bf16 pieces per weight, lane-ordered for
         // v_mfma_f32_16x16x32_bf16: [n_tile 80][k_chunk 10][piece 3][lane 64][4 dwords], lane (r16, g) holds
