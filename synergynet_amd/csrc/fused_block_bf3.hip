@@ -1,17 +1,18 @@
-// Fused inverted-residual block with both 1x1 GEMMs on the bf16 matrix pipe at fp32-equivalent accuracy
+// Fused inverted-residual block with both 1x1 GEMMs on the fp16 matrix instructions at fp32-equivalent accuracy
 // (the late MobileNetV2 blocks, CIN % 32 == 0).  Same dataflow as fused_block.hip:
 //
-//   stage 1  expand   E = ReLU6(BN(X . We^T))        LDS(bf16 x3) x regs(bf16 x3) -> fp32 acc -> LDS fp32
-//   stage 2  dw 3x3   D = ReLU6(BN(dw(E)))            fp32 VALU, LDS -> LDS (split into bf16 x3 on the way out)
-//   stage 3  project  acc += D . Wp[:, chunk]^T       LDS(bf16 x3) x regs(bf16 x3) -> fp32 acc in VGPRs
+//   stage 1  expand   E = ReLU6(BN(X . We^T))        LDS(fp16 x2) x regs(fp16 x2) -> fp32 acc -> LDS fp32
+//   stage 2  dw 3x3   D = ReLU6(BN(dw(E)))            fp32 VALU, LDS -> LDS (split into fp16 x2 on the way out)
+//   stage 3  project  acc += D . Wp[:, chunk]^T       LDS(fp16 x2) x regs(fp16 x2) -> fp32 acc in VGPRs
 //
-// but every fp32 operand x of a GEMM is carried as three bf16 pieces x = h + m + l (EXACT: 8+8+8 significant bits,
-// by truncation) and each 16x16x32 block product is rebuilt from the six partial products of weight >= 2^-16:
-//   h*h + (h*m + m*h) + (m*m + h*l + l*h)        (dropped: m*l, l*m, l*l  <= 2^-24 relative)
-// bf16 x bf16 products are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the result has
-// fp32-class error (measured 1.4e-6 on the network output, same as the fp32-MFMA path) while issuing 6 MFMAs of
-// K=32 (~17 cycles each) instead of 8 fp32-input MFMAs of K=4 (32 cycles each) -- and the bf16 MFMA does not share
-// the vector pipe with VALU work, which the fp32-input MFMA does (tools/ubench/mfma_valu_overlap.hip).
+// Every fp32 operand x of a GEMM is carried as two fp16 pieces x = a + b (a = fp16(x), b = fp16(x - a), both toward zero: 11 + 11
+// significant bits) and each 16x16x32 block product is rebuilt from three partial products a a + a b + b a (dropped: b b <= 2^-22
+// relative).  fp16 x fp16 products are exact in fp32 and v_mfma_f32_16x16x32_f16 accumulates in fp32, so the result has
+// fp32-class error at HALF the matrix instructions of the exact 3-way bf16 split (6 products) this kernel used before -- which
+// matters because matrix and vector instructions of the waves of a SIMD do not overlap (tools/ubench/mfma_valu_kinds.hip).
+// fp16's narrow exponent: the weights of a layer are scaled by a power of two S to max |w| in [2^13, 2^14) (exact; low pieces stay
+// normal), the accumulators start at S x shift, ReLU6 clamps at 6 S and the inverse scale is folded into the depthwise filter
+// (expand) or applied to the accumulator (project): scl = {S, 1/S, 6 S} per layer (synergy_abi.hip).
 // Weights are split and lane-ordered offline ([n_tile][k32 chunk][piece][lane][4 dwords]); activations are split once,
 // where they are written to LDS (input tile in stage 0, depthwise output in stage 2).
 #include "syn_internal.h"
@@ -21,7 +22,8 @@ namespace syn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 __device__ __forceinline__ float relu6b(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f); }   // one v_med3 (fminf(fmaxf()) adds a canonicalising v_max)
@@ -33,24 +35,18 @@ __device__ __forceinline__ f32x4 relu6b(f32x4 v) {
 }
 constexpr int cdivb(int a, int b) { return (a + b - 1) / b; }
 constexpr int rupb(int a, int b) { return cdivb(a, b) * b; }
-// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
-__device__ __forceinline__ void split2b(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+// two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 bits
+__device__ __forceinline__ void split2b(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ f32x4 mfmab(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// the six partial products of one (channel tile, pixel tile, k32 chunk), smallest terms first
-__device__ __forceinline__ f32x4 mac6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
-    c = mfmab(a[2], b[0], c);
-    c = mfmab(a[0], b[2], c);
-    c = mfmab(a[1], b[1], c);
+// the three partial products of one (channel tile, pixel tile, k32 chunk), smallest terms first
+__device__ __forceinline__ f32x4 mac3(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x4 c) {
     c = mfmab(a[1], b[0], c);
     c = mfmab(a[0], b[1], c);
     c = mfmab(a[0], b[0], c);
@@ -84,7 +80,7 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
     static constexpr int RS = RS_ < 1 ? 1 : (RS_ > TH ? TH : RS_);
     static constexpr int RPS = cdivb(TH, RS), DW_THREADS = C4N * COLS * cdivb(TH, RPS);
     static constexpr int WDR_THREADS = 11 * HC / 4;
-    static constexpr int LDS_DWORDS = 3 * XPL + PINP * ES + 3 * DPL + 11 * HC;
+    static constexpr int LDS_DWORDS = 2 * XPL + PINP * ES + 2 * DPL + 11 * HC;
     static_assert(CIN % 32 == 0 && HC % 32 == 0 && HID % HC == 0, "k32 chunking");
     static_assert(WN * WP == NW, "wave grid");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
@@ -105,16 +101,17 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
 // wrap-around of the per-chunk prefetch.
 template <class C, bool PROF = false, int NS = 1, bool PERSIST = false>
 __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_bf3_kernel(
-    const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][3][64][4]*/, const float *__restrict__ e_shift,
-    const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][3][64][4]*/,
-    const float *__restrict__ p_shift, float *__restrict__ Y, int B,
+    const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][2][64][4]*/, const float *__restrict__ e_shift,
+    const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][2][64][4]*/,
+    const float *__restrict__ p_shift, float *__restrict__ Y, int B, const float *__restrict__ scl_e, const float *__restrict__ scl_p,
     unsigned long long *prof = nullptr) {
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
-    unsigned *Xb = smem;                                         // 3 planes [PINP][XSD]
-    float *Es = reinterpret_cast<float *>(Xb + 3 * C::XPL);      // [PINP][ES] fp32
-    unsigned *Db = reinterpret_cast<unsigned *>(Es + C::PINP * C::ES);   // 3 planes [POUTP][DSD]
-    float *Wds = reinterpret_cast<float *>(Db + 3 * C::DPL);     // [11][HC]: 9 taps | (unused) | shift
+    unsigned *Xb = smem;                                         // 2 planes [PINP][XSD]
+    float *Es = reinterpret_cast<float *>(Xb + 2 * C::XPL);      // [PINP][ES] fp32 (scaled by Se)
+    unsigned *Db = reinterpret_cast<unsigned *>(Es + C::PINP * C::ES);   // 2 planes [POUTP][DSD]
+    float *Wds = reinterpret_cast<float *>(Db + 2 * C::DPL);     // [11][HC]: 9 taps / Se | (unused) | shift
+    const float Se = scl_e[0], inv_se = scl_e[1], c6e = scl_e[2], Sp = scl_p[0], inv_sp = scl_p[1];
     constexpr int NT = C::NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,26 +125,26 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     const int nt_base = NS > 1 ? (int)blockIdx.y * NTO_S : 0;
 
     // ---- prefetch: expand weights of chunk 0 and its depthwise filter (registers) ----
-    u32x4 a1[C::JPW][C::KE][3];
+    u32x4 a1[C::JPW][C::KE][2];
     f32x4 e1h[C::JPW];
-    u32x4 a3[C::AN][C::KP][3];
+    u32x4 a3[C::AN][C::KP][2];
     f32x4 wdr = z4;
     auto fetch_a1 = [&](int hc0) {
 #pragma unroll
         for (int jj = 0; jj < C::JPW; ++jj) {
             const int job = wave + jj * C::NW;
             if (job < C::JOBS) {
-                const unsigned *wa = We3 + ((size_t)(hc0 / 16 + job % C::NT_E) * C::KE) * 768 + lane * 4;
+                const unsigned *wa = We3 + ((size_t)(hc0 / 16 + job % C::NT_E) * C::KE) * 512 + lane * 4;
 #pragma unroll
                 for (int kc = 0; kc < C::KE; ++kc)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a1[jj][kc][p] = *(const u32x4 *)(wa + (kc * 3 + p) * 256);
-                e1h[jj] = *(const f32x4 *)&e_shift[hc0 + (job % C::NT_E) * 16 + 4 * g];
+                    for (int p = 0; p < 2; ++p) a1[jj][kc][p] = *(const u32x4 *)(wa + (kc * 2 + p) * 256);
+                e1h[jj] = *(const f32x4 *)&e_shift[hc0 + (job % C::NT_E) * 16 + 4 * g] * Se;
             }
         }
         if (tid < C::WDR_THREADS) {
             const int row = tid / (C::HC / 4), c4 = tid % (C::HC / 4);
-            if (row < 9) wdr = *(const f32x4 *)&Wd[row * C::HID + hc0 + 4 * c4];
+            if (row < 9) wdr = *(const f32x4 *)&Wd[row * C::HID + hc0 + 4 * c4] * inv_se;
             else if (row == 10) wdr = *(const f32x4 *)&d_shift[hc0 + 4 * c4];
         }
     };
@@ -156,11 +153,11 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         for (int i = 0; i < AN_S; ++i) {
             int nt = wn + i * C::WN;
             nt = nt_base + (nt < NTO_S ? nt : 0);
-            const unsigned *wa = Wp3 + ((size_t)nt * (C::HID / 32) + hc0 / 32) * 768 + lane * 4;
+            const unsigned *wa = Wp3 + ((size_t)nt * (C::HID / 32) + hc0 / 32) * 512 + lane * 4;
 #pragma unroll
             for (int kc = 0; kc < C::KP; ++kc)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a3[i][kc][p] = *(const u32x4 *)(wa + (kc * 3 + p) * 256);
+                for (int p = 0; p < 2; ++p) a3[i][kc][p] = *(const u32x4 *)(wa + (kc * 2 + p) * 256);
         }
     };
     fetch_a1(0);
@@ -191,17 +188,16 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             const int c4 = it % (C::CIN / 4), p = it / (C::CIN / 4);
             const bool real = p < C::PIN && fb + p / (C::IH * C::IW) < B;
             const f32x4 v = real ? xv[ii] : z4;
-            unsigned h0, m0, l0, h1, m1, l1;
-            split2b(v[0], v[1], h0, m0, l0);
-            split2b(v[2], v[3], h1, m1, l1);
-            *(u32x2 *)&Xb[0 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){h0, h1};
-            *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){m0, m1};
-            *(u32x2 *)&Xb[2 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){l0, l1};
+            unsigned a0, b0, a1_, b1;
+            split2b(v[0], v[1], a0, b0);
+            split2b(v[2], v[3], a1_, b1);
+            *(u32x2 *)&Xb[0 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){a0, a1_};
+            *(u32x2 *)&Xb[1 * C::XPL + p * C::XSD + 2 * c4] = (u32x2){b0, b1};
         }
     };
     load_x(f0);
     if (C::POUTP > C::POUT)
-        for (int it = tid; it < 3 * (C::POUTP - C::POUT) * C::DSD; it += NT) {
+        for (int it = tid; it < 2 * (C::POUTP - C::POUT) * C::DSD; it += NT) {
             const int p = it / ((C::POUTP - C::POUT) * C::DSD), r = it % ((C::POUTP - C::POUT) * C::DSD);
             Db[p * C::DPL + C::POUT * C::DSD + r] = 0u;
         }
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
 #pragma unroll
     for (int i = 0; i < AN_S; ++i) {
         const int n = (nt_base + wn + i * C::WN) * 16 + 4 * g;
-        psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] : z4;
+        psh[i] = n < C::COUTP ? *(const f32x4 *)&p_shift[n] * Sp : z4;
     }
     const int gstep = (int)gridDim.x * C::NF;
     for (;;) {                                  // face groups of this workgroup (exactly one unless PERSIST)
@@ -236,28 +232,33 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             f32x4 ea[C::EPB];
 #pragma unroll
             for (int q = 0; q < C::EPB; ++q) ea[q] = e1h[jj];
-            auto ldb = [&](int kc, u32x4(&b)[C::EPB][3]) {
+            auto ldb = [&](int kc, u32x4(&b)[C::EPB][2]) {
 #pragma unroll
                 for (int q = 0; q < C::EPB; ++q) {
                     const int pt = pg * C::EPB + q;
                     const int row = ((pt < C::PT_IN ? pt : 0) * 16 + r16) * C::XSD + kc * 16 + 4 * g;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) b[q][p] = *(const u32x4 *)&Xb[p * C::XPL + row];
+                    for (int p = 0; p < 2; ++p) b[q][p] = *(const u32x4 *)&Xb[p * C::XPL + row];
                 }
             };
-            u32x4 bq[2][C::EPB][3];                     // pixel operands of the current / next k32 chunk (ping-pong)
+            u32x4 bq[2][C::EPB][2];                     // pixel operands of the current / next k32 chunk (ping-pong)
             ldb(0, bq[0]);
 #pragma unroll
             for (int kc = 0; kc < C::KE; ++kc) {
                 if (kc + 1 < C::KE) ldb(kc + 1, bq[(kc + 1) & 1]);
 #pragma unroll
-                for (int q = 0; q < C::EPB; ++q) ea[q] = mac6(a1[jj][kc], bq[kc & 1][q], ea[q]);
+                for (int q = 0; q < C::EPB; ++q) ea[q] = mac3(a1[jj][kc], bq[kc & 1][q], ea[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < C::EPB; ++q) {
                 const int pt = pg * C::EPB + q;
-                if (pt < C::PT_IN) *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = relu6b(ea[q]);
+                if (pt < C::PT_IN) {
+                    f32x4 e;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_fmed3f(ea[q][i], 0.0f, c6e);
+                    *(f32x4 *)&Es[(pt * 16 + r16) * C::ES + nt * 16 + 4 * g] = e;
+                }
             }
         }
         fetch_a3(hc0);
@@ -311,12 +312,11 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
                 a += rb[2][0] * w[6]; a += rb[2][1] * w[7]; a += rb[2][2] * w[8];
                 a = relu6b(a);
                 const int po = (fi * C::TH + oyl) * C::TW + oxl;
-                unsigned h0, m0, l0, h1, m1, l1;
-                split2b(a[0], a[1], h0, m0, l0);
-                split2b(a[2], a[3], h1, m1, l1);
-                *(u32x2 *)&Db[0 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){h0, h1};
-                *(u32x2 *)&Db[1 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){m0, m1};
-                *(u32x2 *)&Db[2 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){l0, l1};
+                unsigned a0, b0, a1_, b1;
+                split2b(a[0], a[1], a0, b0);
+                split2b(a[2], a[3], a1_, b1);
+                *(u32x2 *)&Db[0 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){a0, a1_};
+                *(u32x2 *)&Db[1 * C::DPL + po * C::DSD + 2 * c4] = (u32x2){b0, b1};
             }
         }
         fetch_a1(hc0 + C::HC < C::HID ? hc0 + C::HC : 0);
@@ -325,16 +325,16 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
         SYNB_LAP(4);
         // ---- stage 3: project 1x1 (bf16 x3), K = this hidden chunk, accumulators stay in registers ----
         {
-            auto ldb = [&](int kc, u32x4(&b)[C::AP][3]) {
+            auto ldb = [&](int kc, u32x4(&b)[C::AP][2]) {
 #pragma unroll
                 for (int j = 0; j < C::AP; ++j) {
                     const int pt = wp + j * C::WP;
                     const int row = ((pt < C::PT_O ? pt : 0) * 16 + r16) * C::DSD + kc * 16 + 4 * g;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
+                    for (int p = 0; p < 2; ++p) b[j][p] = *(const u32x4 *)&Db[p * C::DPL + row];
                 }
             };
-            u32x4 bq[2][C::AP][3];
+            u32x4 bq[2][C::AP][2];
             ldb(0, bq[0]);
 #pragma unroll
             for (int kc = 0; kc < C::KP; ++kc) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
 #pragma unroll
                 for (int i = 0; i < AN_S; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac6(a3[i][kc], bq[kc & 1][j], acc[i][j]);
+                    for (int j = 0; j < C::AP; ++j) acc[i][j] = mac3(a3[i][kc], bq[kc & 1][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -365,19 +365,10 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
             if (pt >= C::PT_O || po >= C::POUT) continue;
             const int f = f0 + po / (C::TH * C::TW);
             if (f >= B) continue;
-            f32x4 v = acc[i][j];
-            if (C::RES) {                                   // S == 1: output pixel index == input pixel index
-                const int row = po * C::XSD + n / 2;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const u32x2 w2 = *(const u32x2 *)&Xb[p * C::XPL + row];
-                    v[0] += __builtin_bit_cast(float, w2[0] << 16);
-                    v[1] += __builtin_bit_cast(float, w2[0] & 0xffff0000u);
-                    v[2] += __builtin_bit_cast(float, w2[1] << 16);
-                    v[3] += __builtin_bit_cast(float, w2[1] & 0xffff0000u);
-                }
-            }
-            *(f32x4 *)&Y[((size_t)f * C::TH * C::TW + po % (C::TH * C::TW)) * C::COUT + n] = v;
+            f32x4 v = acc[i][j] * inv_sp;
+            const size_t at = ((size_t)f * C::TH * C::TW + po % (C::TH * C::TW)) * C::COUT + n;
+            if (C::RES) v += *(const f32x4 *)&X[at];         // S == 1, CIN == COUT: same index (the two fp16 pieces in LDS are not the exact input)
+            *(f32x4 *)&Y[at] = v;
         }
     }
     SYNB_LAP(6);
@@ -394,22 +385,22 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
 template <class C, int NS>
 static void launch_bf3_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     const dim3 grid((B + C::NF - 1) / C::NF, NS);
-    fused_block_bf3_kernel<C, false, NS><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+    fused_block_bf3_kernel<C, false, NS><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
 }
 
 template <class C>
 static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::NF - 1) / C::NF;
     if (a.prof)
-        fused_block_bf3_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.prof);
+        fused_block_bf3_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p, a.prof);
     else {
         if constexpr (C::PERSIST) {
             if (grid > C::SLOTS) {
-                fused_block_bf3_kernel<C, false, 1, true><<<C::SLOTS, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+                fused_block_bf3_kernel<C, false, 1, true><<<C::SLOTS, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
                 return;
             }
         }
-        fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B);
+        fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
     }
 }
 
@@ -427,7 +418,7 @@ using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // feat
 constexpr int kSliceMaxGrid = 48;      // workgroups (of 4 faces) below which the late blocks are sliced over output channels
 
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
-    if (!a.We3 || !a.Wp3) return false;
+    if (!a.We3 || !a.Wp3 || !a.scl_e || !a.scl_p) return false;
     switch (feature) {
         case 5: case 6: launch_bf3<B5>(a, B, s); return true;
         case 7: launch_bf3<B7>(a, B, s); return true;

@@ -45,7 +45,8 @@ struct FusedBlockArgs {
     const float *Wp, *p_scale, *p_shift;              // project: Wpk[COUTP/16][HID/16][64][4], [COUTP], [COUTP]
     float *Y;                                         // block output NHWC
     unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
-    const unsigned *We3 = nullptr, *Wp3 = nullptr;    // bf16 x3 split weights (fused_block_bf3.hip), or null
+    const unsigned *We3 = nullptr, *Wp3 = nullptr;    // split weights: fp16 x2 for features.5-17 (fused_block_bf3.hip), bf16 x3 for features.2-4 (fused_block_early.hip), or null
+    const float *scl_e = nullptr, *scl_p = nullptr;   // features.5-17: {S, 1/S, 6 S} of the expand / project weights (device)
     const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
     const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
     const unsigned *Alb_e = nullptr;                  // ... its expand fragments

@@ -55,7 +55,8 @@ struct Layer {
     size_t src_w;        // offsets (floats) into the flat host input
     size_t dst_w, dst_scale, dst_shift;   // offsets (floats) into the packed device blob
     size_t dst_wpk;      // PW layers of fused blocks: weights in MFMA lane order (fused_block.hip)
-    size_t dst_wb3;      // PW layers of features.5-17: 3-way bf16 split, lane order of v_mfma_f32_16x16x32_bf16 (dwords)
+    size_t dst_wb3;      // PW layers of features.5-17: fp16 x2 split (features.2-4: 3-way bf16 split), lane order of v_mfma_f32_16x16x32_* (dwords)
+    size_t dst_scl;      // ... of features.5-17: {S, 1/S, 6 S, 0}, S = the power of two the fp16 pieces of the layer are scaled by
     size_t dst_wrm;      // PW layers of features.2-4: fragments of the row-marching kernel (fused_block_rm.hip), or 0
     size_t dst_wlb;      // project layers of features.8-13: fragments of the register-resident kernel (fused_block_lb.hip), or 0
     size_t dst_tlb;      // expand layers of features.8-13: per hidden group [12][32] floats = depthwise filter 9 rows | depthwise shift | expand shift | constants
@@ -116,9 +117,11 @@ struct Net {
             if (L.kind == PW) dst += (size_t)round_up(L.cout, 16) * round_up(L.cin, 16);
             else dst += wp;
             L.dst_wb3 = 0;
+            L.dst_scl = 0;
             if (L.kind == PW && L.feature >= 5 && L.feature <= 17 && L.cin % 32 == 0) {
                 L.dst_wb3 = dst;
-                dst += (size_t)round_up(L.cout, 16) * L.cin * 3 / 2;      // 3 bf16 per weight
+                dst += (size_t)round_up(L.cout, 16) * L.cin;              // 2 fp16 per weight
+                L.dst_scl = dst; dst += 4;
             }
             if (L.kind == PW && L.feature >= 2 && L.feature <= 4) {
                 // early blocks: expand K (16 / 24) zero padded to one k32 step; project K = hidden chunks of
@@ -442,6 +445,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             if (h->fusion >= 2 && L.dst_wb3 && Pj.dst_wb3) {
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
+                if (L.dst_scl && Pj.dst_scl) { a.scl_e = P + L.dst_scl; a.scl_p = P + Pj.dst_scl; }
             }
             if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
@@ -676,6 +680,28 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             // K is walked as `nch` chunks of `hc` real channels, each zero padded to `hcp` (a multiple of 32):
             // late blocks hc = hcp = cin; early expand hc = cin (16 / 24), hcp = 32; early project hc = early_block_hc
             const bool early = L.feature >= 2 && L.feature <= 4;
+            if (!early) {            // late blocks: two fp16 pieces per weight, scaled by S = 2^e to max |w| in [2^13, 2^14) (fused_block_bf3.hip)
+                float mx = 0.f;
+                for (int nn = 0; nn < L.cout; ++nn)
+                    for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
+                int ex = 0;
+                if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+                const float S = ldexpf(1.0f, ex);
+                pk[L.dst_scl] = S; pk[L.dst_scl + 1] = 1.0f / S; pk[L.dst_scl + 2] = 6.0f * S;
+                const int ntl = round_up(L.cout, 16) / 16, kch = L.cin / 32;
+                for (int nt = 0; nt < ntl; ++nt)
+                    for (int st = 0; st < kch; ++st)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int d = 0; d < 4; ++d) {
+                                const int nn = nt * 16 + (lane & 15), kk = 32 * st + 8 * (lane >> 4) + 2 * d;
+                                float x[2] = {0.f, 0.f};
+                                if (nn < L.cout) for (int e = 0; e < 2; ++e) x[e] = w[(size_t)nn * L.cin + kk + e] * bn_scale[nn] * S;
+                                const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
+                                const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
+                                dp[(((size_t)(nt * kch + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                                dp[(((size_t)(nt * kch + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+                            }
+            } else {
             const int hc = !early ? L.cin : (L.relu6 ? L.cin : syn::early_block_hc(L.cin));
             const int hcp = round_up(hc, 32), nch = L.cin / hc, spc = hcp / 32;     // k32 steps per chunk
             const int ntl = round_up(L.cout, 16) / 16, kch = nch * spc;
@@ -706,6 +732,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                             for (int pcs = 0; pcs < 3; ++pcs)
                                 dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
                         }
+            }
         }
         if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 in its K-slot order + folded shift
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
