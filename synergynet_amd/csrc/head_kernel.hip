@@ -146,36 +146,32 @@ void launch_head(const float *X, const float *Wpk, const float *scale, const flo
 
 
 // =====================================================================================
-// Same tail, but the 320 -> 1280 GEMM runs on the bf16 matrix pipe with fp32-equivalent accuracy:
-// every fp32 operand x is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 significant bits, by
-// truncation: h = x & 0xffff0000, m = (x - h) & ..., l = (x - h - m) & ...), and the product is rebuilt from the six
-// partial products that reach 2^-16 relative weight:  h*h + (h*m + m*h) + (m*m + h*l + l*h)   (dropped: m*l, l*m,
-// l*l <= 2^-24).  bf16 x bf16 products are exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in fp32, so the
-// result carries fp32-class rounding error while issuing 6 MFMAs of K=32 (~17 cycles each) instead of 8 fp32 MFMAs
-// of K=4 (32 cycles each) per 16x16x32 block -- and, unlike the fp32-input MFMA, the bf16 MFMA does not share the
-// vector pipe with VALU work.  Weights are split and lane-ordered offline; activations are split once when the
-// input tile is staged into LDS.
+// Same tail, but the 320 -> 1280 GEMM runs on v_mfma_f32_16x16x32_f16 with fp32-equivalent accuracy: every fp32 operand x is
+// carried as two fp16 pieces x = a + b (a = fp16(x), b = fp16(x - a), toward zero: 22 significant bits) and the product is rebuilt
+// from three partial products a a + a b + b a (dropped: b b <= 2^-22).  fp16 x fp16 products are exact in fp32 and the MFMA
+// accumulates in fp32.  The weights are scaled by a power of two S to the top of fp16's range (their low pieces stay normal), the
+// accumulators start at S x shift and are rescaled before ReLU6.  Weights are split and lane-ordered offline; activations are
+// split once when the input tile is staged into LDS.  (Four faces per workgroup -- half the weight traffic per face -- measured
+// slower than two, 74 vs 65 us at B = 1024: one 4-wave workgroup per CU hides less than two.)
 // =====================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int KC32 = K / 32;            // 10 k-chunks of 32
-constexpr int XSD = K / 2 + 4;          // dwords per pixel row of one bf16 plane (164: 16-byte aligned, 4 mod 64 banks)
+constexpr int XSD = K / 2 + 4;          // dwords per pixel row of one fp16 plane (164: 16-byte aligned, 4 mod 64 banks)
 constexpr int PLANE = PX * XSD;         // dwords per plane
-// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
-__device__ __forceinline__ void split2(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+// two floats -> packed fp16 pieces a (high) and b (low)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 }  // namespace
 
@@ -217,24 +213,25 @@ constexpr int kFcRounds = (kParam + 3) / 4;      // 16 rounds of 4 rows
 // head_fc_kernel finishes; NS == 1: the whole tail in this launch.
 template <int NS>
 __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
-                                                          const unsigned *__restrict__ Wb3 /*[80][10][3][64][4] dwords*/,
+                                                          const unsigned *__restrict__ Wb3 /*[80][10][2][64][4] dwords, {S, 1/S}*/,
                                                           const float *__restrict__ shift, const float *__restrict__ Wfc,
                                                           const float *__restrict__ bfc, float *__restrict__ param,
                                                           float *__restrict__ pool, int B) {
-    __shared__ __attribute__((aligned(16))) unsigned Xb[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned Xb[2 * PLANE];
     __shared__ __attribute__((aligned(16))) float Ps[NF * N];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int f0 = blockIdx.x * NF;
+    const float S = __builtin_bit_cast(float, Wb3[80 * 10 * 2 * 256]), inv_s = __builtin_bit_cast(float, Wb3[80 * 10 * 2 * 256 + 1]);
     constexpr int NTS = NTL / NS;
     static_assert(NTL % NS == 0 && NTS % 4 == 0, "whole rounds of 4 waves per slice");
     const int nt0 = NS > 1 ? (int)blockIdx.y * NTS : 0, nt_end = nt0 + NTS;
 
-    u32x4 ring[5][3];                                   // weight pieces of 5 k-chunks in flight
-    auto lda = [&](int nt, int kc, u32x4(&dst)[3]) {
-        const unsigned *w = Wb3 + ((size_t)(nt * KC32 + kc) * 3) * 256 + lane * 4;
+    u32x4 ring[5][2];                                   // weight pieces of 5 k-chunks in flight
+    auto lda = [&](int nt, int kc, u32x4(&dst)[2]) {
+        const unsigned *w = Wb3 + ((size_t)(nt * KC32 + kc) * 2) * 256 + lane * 4;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = *(const u32x4 *)(w + p * 256);
+        for (int p = 0; p < 2; ++p) dst[p] = *(const u32x4 *)(w + p * 256);
     };
 #pragma unroll
     for (int kc = 0; kc < 5; ++kc) lda(nt0 + wave, kc, ring[kc]);
@@ -258,47 +255,40 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
         for (int ii = 0; ii < XI; ++ii) {
             const int it = tid + ii * 256, c4 = it % (K / 4), p = it / (K / 4);
             const f32x4 v = f0 + (p >> 4) < B ? xv[ii] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            unsigned h0, m0, l0, h1, m1, l1;
-            split2(v[0], v[1], h0, m0, l0);
-            split2(v[2], v[3], h1, m1, l1);
-            *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){h0, h1};
-            *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){m0, m1};
-            *(u32x2 *)&Xb[2 * PLANE + p * XSD + 2 * c4] = (u32x2){l0, l1};
+            unsigned a0, b0, a1, b1;
+            split2(v[0], v[1], a0, b0);
+            split2(v[2], v[3], a1, b1);
+            *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){a0, a1};
+            *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){b0, b1};
         }
     }
     __syncthreads();
 
     for (int nt = nt0 + wave; nt < nt_end; nt += 4) {
-        const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g];
+        const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g] * S;
         f32x4 acc[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[j] = sh;
-        u32x4 bq[2][NF][3];                             // pixel operands of the current / next k-chunk (ping-pong, no copies)
-        auto ldb = [&](int kc, u32x4(&b)[NF][3]) {
+        u32x4 bq[2][NF][2];                             // pixel operands of the current / next k-chunk (ping-pong, no copies)
+        auto ldb = [&](int kc, u32x4(&b)[NF][2]) {
 #pragma unroll
             for (int j = 0; j < NF; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANE + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
+                for (int p = 0; p < 2; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANE + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
         };
         ldb(0, bq[0]);
 #pragma unroll
         for (int kc = 0; kc < KC32; ++kc) {
             if (kc + 1 < KC32) ldb(kc + 1, bq[(kc + 1) & 1]);
-            const u32x4(&bc)[NF][3] = bq[kc & 1];
-            const u32x4 ah = ring[kc % 5][0], am = ring[kc % 5][1], al = ring[kc % 5][2];
-            // six partial products, smallest first; 4 independent accumulators interleaved
+            const u32x4(&bc)[NF][2] = bq[kc & 1];
+            const u32x4 aa = ring[kc % 5][0], ab = ring[kc % 5][1];
+            // three partial products, smallest first; NF independent accumulators interleaved
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(al, bc[j][0], acc[j]);
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(ab, bc[j][0], acc[j]);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][2], acc[j]);
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(aa, bc[j][1], acc[j]);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(am, bc[j][1], acc[j]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(am, bc[j][0], acc[j]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][1], acc[j]);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_bf16(ah, bc[j][0], acc[j]);
+            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(aa, bc[j][0], acc[j]);
             // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
             if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
             else if (nt + 4 < nt_end) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
@@ -308,7 +298,7 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
         for (int j = 0; j < NF; ++j) {
             f32x4 v;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = row16_sum(r6h(acc[j][t]));
+            for (int t = 0; t < 4; ++t) v[t] = row16_sum(r6h(acc[j][t] * inv_s));
             if (r16 == 0) *(f32x4 *)&Ps[j * N + nt * 16 + 4 * g] = v * 0.0625f;
         }
     }
@@ -354,7 +344,7 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float *__restrict__ 
 void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
                         float *param, float *pool, float *scratch, int B, hipStream_t s) {
     const int grid = (B + NF - 1) / NF;
-    if (grid <= 96) {                                      // few faces: spread the 2.4 MB of weights over 5 workgroups per face pair
+    if (grid <= 96) {                                      // few faces: spread the 1.6 MB of weights over 5 workgroups per face pair
         float *pl = pool ? pool : scratch;
         head_bf16x3_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
         head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);

@@ -71,7 +71,7 @@ struct Net {
     size_t flat_count = 0;      // floats in the host flat input (incl. heads)
     size_t src_fc = 0;
     size_t packed_count = 0;    // floats in the packed device blob
-    size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_b3 = 0;   // dst_head_b3: features.18 weights as 3 bf16 pieces (dwords)
+    size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_b3 = 0;   // dst_head_b3: features.18 weights as 2 fp16 pieces (dwords) + their power-of-two scale
     size_t max_io = 0, max_hidden = 0;   // per-face activation floats (block in/out, expanded)
     double flops = 0, pw_flops = 0;
     Net() {
@@ -164,7 +164,7 @@ struct Net {
         flat_count = src;
         dst_fc_w = dst; dst += 64 * 1280;
         dst_fc_b = dst; dst += 64;
-        dst_head_b3 = dst; dst += (size_t)80 * 10 * 3 * 256;
+        dst_head_b3 = dst; dst += (size_t)80 * 10 * 2 * 256 + 4;        // fragments, then {S, 1/S}
         packed_count = dst;
         flops += 2.0 * 1280 * 62;
     }
@@ -865,31 +865,34 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
         tb[11 * 32 + 0] = 96.0f * Se;               // ReLU6 ceiling of the scaled expand output
         tb[11 * 32 + 1] = 1.0f / (16.0f * Sp);      // project accumulator -> output
     }
-    {   // features.18 (BN scale folded in) split exactly into three bf16 pieces per weight, lane-ordered for
-        // v_mfma_f32_16x16x32_bf16: [n_tile 80][k_chunk 10][piece 3][lane 64][4 dwords], lane (r16, g) holds
-        // k = 32*kc + 8*g + e, e = 0..7, two bf16 per dword (even e in the low half)
+    {   // features.18 (BN scale folded in), scaled by S = 2^e to max |w| in [2^13, 2^14) and split into two fp16 pieces per weight,
+        // lane-ordered for v_mfma_f32_16x16x32_f16: [n_tile 80][k_chunk 10][piece 2][lane 64][4 dwords], lane (r16, g) holds
+        // k = 32*kc + 8*g + e, e = 0..7, two fp16 per dword (even e in the low half); then {S, 1/S}
         const Layer &L = n.layers.back();
         const float *w = flat + L.src_w;
         const float *gamma = w + (size_t)L.cout * L.cin, *var = gamma + 3 * (size_t)L.cout;
         unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + n.dst_head_b3);
-        auto split = [](float x, unsigned (&pc)[3]) {
-            for (int i = 0; i < 3; ++i) {
-                unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
-                float hf; memcpy(&hf, &u, 4);
-                pc[i] = u >> 16; x -= hf;
-            }
-        };
+        std::vector<float> sc(L.cout);
+        float mx = 0.f;
+        for (int nn = 0; nn < L.cout; ++nn) {
+            sc[nn] = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
+            for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * sc[nn]));
+        }
+        int ex = 0;
+        if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+        const float S = ldexpf(1.0f, ex);
+        pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256] = S;
+        pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256 + 1] = 1.0f / S;
         for (int nt = 0; nt < 80; ++nt)
             for (int kc = 0; kc < 10; ++kc)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int d = 0; d < 4; ++d) {
-                        unsigned lo[3], hi[3];
                         const int nn = nt * 16 + (lane & 15), k0 = kc * 32 + 8 * (lane >> 4) + 2 * d;
-                        const float sc = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
-                        split(w[(size_t)nn * L.cin + k0] * sc, lo);
-                        split(w[(size_t)nn * L.cin + k0 + 1] * sc, hi);
-                        for (int pcs = 0; pcs < 3; ++pcs)
-                            dp[(((size_t)(nt * 10 + kc) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
+                        const float x0 = w[(size_t)nn * L.cin + k0] * sc[nn] * S, x1 = w[(size_t)nn * L.cin + k0 + 1] * sc[nn] * S;
+                        const unsigned a0 = f16_rtz(x0), a1 = f16_rtz(x1);
+                        const unsigned b0 = f16_rtz(x0 - f16_value(a0)), b1 = f16_rtz(x1 - f16_value(a1));
+                        dp[(((size_t)(nt * 10 + kc) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                        dp[(((size_t)(nt * 10 + kc) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                     }
     }
     // heads: ori[12] | shape[40] | exp[10] concatenated in that order (mobilenetv2_backbone.py:184-188)
