@@ -6,19 +6,20 @@
 // (profiles/r2).  Here the hidden activations never leave registers:
 //
 //   * one WAVE owns 32 hidden channels ("group") of one face and marches down the image row by row;
-//   * expand runs on v_mfma_f32_32x32x16_bf16 (exact 3-way bf16 split, 6 partial products) with the hidden channels as the
+//   * expand runs on v_mfma_f32_32x32x16_f16 (two fp16 pieces per operand, x = a + b to 22 bits, three partial products -- half the
+//     matrix instructions of the exact 3-way bf16 split used before; power-of-two operand scales, see below) with the hidden channels as the
 //     A rows and ONE IMAGE ROW as the 32 B columns: lane (j = l&31, h = l>>5) then holds 16 hidden channels
 //     {0-3, 8-11, 16-19, 24-27} + 4h of pixel j -- the horizontal neighbours of a pixel are the neighbouring LANES
 //     (v_mov_dpp wave_shr:1 / wave_shl:1), the vertical ones are earlier / later rows of the same lane;
 //   * the depthwise 3x3 is "scattered": a fresh expand row adds its three kernel rows into the accumulators of the (up to)
 //     three output rows it touches, so only accumulators are live, never a window of expanded rows;
-//   * a finished depthwise row is ReLU6'ed, split into its three bf16 pieces IN PLACE -- with K-slot (h, e) := register
+//   * a finished depthwise row is ReLU6'ed, split into its two fp16 pieces IN PLACE -- with K-slot (h, e) := register
 //     8s+e the D layout of one MFMA IS the B operand of the next (the host packs the project weights in that K order) --
-//     and projected (12 MFMAs) to a partial sum over this wave's 32 hidden channels;
+//     and projected (6 MFMAs) to a partial sum over this wave's 32 hidden channels;
 //   * the only LDS traffic is: the block-input row as pre-split B fragments, the per-wave partial sums and broadcast reads
 //     of the depthwise filter; ONE barrier per input row;
 //   * per unit one SERVICE wave does everything that is not the hidden pipeline: it loads the next block-input row, splits it
-//     into the bf16 fragments all compute waves read, and reduces the partial sums of a finished output row in fixed wave order
+//     into the fp16 fragments all compute waves read, and reduces the partial sums of a finished output row in fixed wave order
 //     (+ BN shift, + residual) into the NHWC store.  The compute waves run straight-line code; the service waves sit on the
 //     SIMDs that hold one compute wave fewer (waves go to SIMDs cyclically), which evens out the 5-groups-on-4-SIMDs split.
 //
@@ -34,29 +35,24 @@ namespace syn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int cdivr(int a, int b) { return (a + b - 1) / b; }
 
-// exact 3-way bf16 split of two floats, packed (x0 -> low half, x1 -> high half) per piece
-__device__ __forceinline__ void split2r(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+// two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 significant bits (both conversions toward zero)
+__device__ __forceinline__ void split2r(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ f32x16 mfma32r(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// the six partial products of weight >= 2^-16, smallest terms first (same order as the other bf16x3 kernels)
-__device__ __forceinline__ f32x16 mac6r(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
-    c = mfma32r(a[2], b[0], c);
-    c = mfma32r(a[0], b[2], c);
-    c = mfma32r(a[1], b[1], c);
+// the three partial products a a + a b + b a (b b <= 2^-22 dropped), smallest terms first
+__device__ __forceinline__ f32x16 mac3r(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) {
     c = mfma32r(a[1], b[0], c);
     c = mfma32r(a[0], b[1], c);
     c = mfma32r(a[0], b[0], c);
@@ -92,10 +88,10 @@ struct RmCfg {
     // per SIMD.
     static constexpr int NW = NG, NCW = U * NG, NT = (NCW + U) * 64;
     static constexpr int FR = NB * KS;                   // block-input fragments per input row
-    static constexpr int XP_DW = FR * 3 * 256, PART_DW = NW * NQ * 256;
+    static constexpr int XP_DW = FR * 2 * 256, PART_DW = NW * NQ * 256;
     static constexpr int PSLOTS = LEAN ? 1 : 2;
     static constexpr int UNIT_DW = 2 * XP_DW + PSLOTS * PART_DW;
-    static constexpr int APL_DW = LEAN ? NG * 2 * 3 * 256 : 0;
+    static constexpr int APL_DW = LEAN ? NG * 2 * 2 * 256 : 0;
     static constexpr int LDS_DW = U * UNIT_DW + 11 * HIDP + 32 + APL_DW;     // per unit: X fragments x2 | partial sums;  filter 9 rows + depthwise shift | expand shift | project shift | (LEAN) project fragments
     static_assert(COUT % 8 == 0 && COUT <= 32, "project tile");
     static_assert(S == 1 || H % 2 == 0, "stride-2 blocks have even input sizes");
@@ -112,10 +108,11 @@ struct RmCfg {
 
 template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
-void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][3][64][4]*/,
-                           const unsigned *__restrict__ Ap3 /*[NG][2][3][64][4]*/, const float *__restrict__ e_shift,
+void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][2][64][4]*/,
+                           const unsigned *__restrict__ Ap3 /*[NG][2][2][64][4]*/, const float *__restrict__ e_shift,
                            const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
                            const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units,
+                           const float *__restrict__ scl_e /*{S, 1/S, 6 S} of the expand weights*/, const float *__restrict__ scl_p,
                            unsigned long long *prof = nullptr) {
     // PROF: s_memtime sums of compute wave 0 per phase {(unused), expand, (unused), depthwise, finalize, barrier wait,
     // whole workgroup lifetime} and the number of row steps (syn_debug_profile_block)
@@ -129,11 +126,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     const bool service = wave_wg >= C::NCW;
     const int uw = service ? wave_wg - C::NCW : wave_wg / NW;                 // unit inside the workgroup
     const int wave = service ? 0 : wave_wg % NW;                              // hidden group inside the unit (compute waves)
-    unsigned *Xp = smem + uw * C::UNIT_DW;                                    // per unit: [2][FR][3][64][4]
+    unsigned *Xp = smem + uw * C::UNIT_DW;                                    // per unit: [2][FR][2][64][4]
     float *Part = reinterpret_cast<float *>(Xp + 2 * C::XP_DW);               // per unit: [2][NW][NQ][64][4]
     float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);        // [9][HIDP] + row 9 = depthwise BN shift, shared
     float *Esh = Filt + 10 * C::HIDP, *Psh = Esh + C::HIDP;                   // [HIDP], [32]
-    unsigned *ApL = reinterpret_cast<unsigned *>(Psh + 32);                   // LEAN: [NG][2][3][64][4] project fragments
+    unsigned *ApL = reinterpret_cast<unsigned *>(Psh + 32);                   // LEAN: [NG][2][2][64][4] project fragments
     constexpr int DSH = 9 * C::HIDP;
     const int j = lane & 31, h = lane >> 5;
     const int cb = wave * 32 + 4 * h;               // hidden channel of register quad q: cb + 8q .. +3
@@ -142,8 +139,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     // light; with the cyclic wave -> SIMD placement the light waves are the third compute wave of their SIMD.
     const int nq_live = (C::HID % 32 == 16 && wave == NW - 1) ? 2 : 4;
 
-    for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] : 0.f; }
-    for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] : 0.f; }
+    // power-of-two operand scales of the fp16 pieces (synergy_abi.hip): the expand accumulators start at Se x shift, ReLU6 clamps at
+    // 6 Se and the depthwise filter carries 1 / Se; the project sums are rescaled by 1 / Sp where the service wave reduces them
+    const float Se = scl_e[0], inv_se = scl_e[1], c6e = scl_e[2], inv_sp = scl_p[1];
+    for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] * inv_se : 0.f; }
+    for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] * Se : 0.f; }
     if (tid < 32) Psh[tid] = tid < C::COUT ? p_shift[tid] : 0.f;
     if (C::LEAN)
         for (int i = tid; i < C::APL_DW / 4; i += NT) *(u32x4 *)&ApL[4 * i] = *(const u32x4 *)&Ap3[4 * i];
@@ -164,7 +164,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
         // waits for them at the row barrier: raise their priority (their work is a fraction of a compute wave's).
         __builtin_amdgcn_s_setprio(3);
         // =====================================================================================================================
-        // service wave of unit uw: block-input rows -> bf16 x3 fragments in LDS; finished output rows: partial sums -> NHWC row
+        // service wave of unit uw: block-input rows -> fp16 x2 fragments in LDS; finished output rows: partial sums -> NHWC row
         // =====================================================================================================================
         for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
             const int unit = ub + uw;
@@ -186,17 +186,17 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             auto store_row = [&](int slot) {
 #pragma unroll
                 for (int fr = 0; fr < C::FR; ++fr) {
-                    u32x4 pc[3];
+                    u32x4 pc[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        unsigned h0, m0, l0, h1, m1, l1;
-                        split2r(xr[fr][t][0], xr[fr][t][1], h0, m0, l0);
-                        split2r(xr[fr][t][2], xr[fr][t][3], h1, m1, l1);
-                        pc[0][2 * t] = h0; pc[0][2 * t + 1] = h1; pc[1][2 * t] = m0; pc[1][2 * t + 1] = m1; pc[2][2 * t] = l0; pc[2][2 * t + 1] = l1;
+                        unsigned a0, b0, a1, b1;
+                        split2r(xr[fr][t][0], xr[fr][t][1], a0, b0);
+                        split2r(xr[fr][t][2], xr[fr][t][3], a1, b1);
+                        pc[0][2 * t] = a0; pc[0][2 * t + 1] = a1; pc[1][2 * t] = b0; pc[1][2 * t + 1] = b1;
                     }
-                    unsigned *dst = Xp + (size_t)slot * C::XP_DW + fr * 768 + lane * 4;
+                    unsigned *dst = Xp + (size_t)slot * C::XP_DW + fr * 512 + lane * 4;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
+                    for (int p = 0; p < 2; ++p) *(u32x4 *)(dst + p * 256) = pc[p];
                 }
             };
             // Global latencies get a whole row step: row y+2 and the residual of output row y-1 are requested in step y and
@@ -215,10 +215,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             auto reduce_row = [&](int yo, int pslot) {
 #pragma unroll
                 for (int q = 0; q < C::NQ; ++q) {
-                    f32x4 v = *(const f32x4 *)&Psh[8 * q + 4 * h];
                     const float *src = Part + (size_t)pslot * C::PART_DW + q * 256 + lane * 4;
+                    f32x4 v = *(const f32x4 *)src;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) v += *(const f32x4 *)(src + (size_t)w * C::NQ * 256);
+                    for (int w = 1; w < NW; ++w) v += *(const f32x4 *)(src + (size_t)w * C::NQ * 256);
+                    v = v * inv_sp + *(const f32x4 *)&Psh[8 * q + 4 * h];
                     if (C::RES) v += res[q];
                     if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
                 }
@@ -261,16 +262,16 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     // compute wave: hidden group `wave` of unit uw
     // =========================================================================================================================
     // this wave's weight fragments stay in registers for the whole (persistent) kernel
-    u32x4 ae[C::KS][3], ap[2][3];
+    u32x4 ae[C::KS][2], ap[2][2];
 #pragma unroll
     for (int s = 0; s < C::KS; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 3 + p) * 256 + lane * 4);
+        for (int p = 0; p < 2; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 2 + p) * 256 + lane * 4);
     if (!C::LEAN)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
+            for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
 
     // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
     // stores nothing (its faces are >= B)
@@ -279,7 +280,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
         const int f_in = unit * C::NF + ia;
         float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
 #pragma unroll
-        for (int b = 0; b < C::NB; ++b) ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? 6.0f : 0.0f;
+        for (int b = 0; b < C::NB; ++b) ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? c6e : 0.0f;
 
         // ---- expand one block of the row in slot `slot`: 16 hidden channels per lane, BN shift, ReLU6 (0 on padding lanes) ----
         auto expand = [&](int slot, int b, f32x16 &e, int cbo) {
@@ -291,16 +292,16 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             }
 #pragma unroll
             for (int s = 0; s < C::KS; ++s) {
-                u32x4 xb[3];
-                const unsigned *src = Xp + (size_t)slot * C::XP_DW + (b * C::KS + s) * 768 + lane * 4;
+                u32x4 xb[2];
+                const unsigned *src = Xp + (size_t)slot * C::XP_DW + (b * C::KS + s) * 512 + lane * 4;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xb[p] = *(const u32x4 *)(src + p * 256);
-                e = mac6r(ae[s], xb, e);
+                for (int p = 0; p < 2; ++p) xb[p] = *(const u32x4 *)(src + p * 256);
+                e = mac3r(ae[s], xb, e);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehi[b]);
         };
-        // ---- finished depthwise row -> ReLU6 -> bf16 x3 pieces (in place: register 8s+e = K slot e of step s) -> project
+        // ---- finished depthwise row -> ReLU6 -> fp16 x2 pieces (in place: register 8s+e = K slot e of step s) -> project
         //      partial over this wave's 32 hidden channels -> LDS ----
         auto finalize = [&](f32x16 &d, int pslot) {
             f32x16 acc;
@@ -309,21 +310,21 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (2 * s >= nq_live) break;                // padded half of the last group: its pieces and weights are zero
-                u32x4 db[3];
+                u32x4 db[2];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
-                    unsigned hh, mm, ll;
-                    split2r(v0, v1, hh, mm, ll);
-                    db[0][t] = hh; db[1][t] = mm; db[2][t] = ll;
+                    unsigned ha, hb;
+                    split2r(v0, v1, ha, hb);
+                    db[0][t] = ha; db[1][t] = hb;
                 }
                 if (C::LEAN) {
-                    u32x4 apl[3];
+                    u32x4 apl[2];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) apl[p] = *(const u32x4 *)(ApL + ((size_t)(wave * 2 + s) * 3 + p) * 256 + lane * 4);
-                    acc = mac6r(apl, db, acc);
+                    for (int p = 0; p < 2; ++p) apl[p] = *(const u32x4 *)(ApL + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
+                    acc = mac3r(apl, db, acc);
                 } else {
-                    acc = mac6r(ap[s], db, acc);
+                    acc = mac3r(ap[s], db, acc);
                 }
             }
             float *dst = Part + (size_t)pslot * C::PART_DW + (size_t)wave * C::NQ * 256 + lane * 4;
@@ -503,9 +504,9 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
     const int cap = 256 * wgs_per_cu, wgs = (n_units + C::U - 1) / C::U;  // persistent: as many workgroups as the CUs hold at once
     const int grid = wgs < cap ? wgs : cap;
     if (a.prof)
-        fused_block_rm_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.prof);
+        fused_block_rm_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.scl_e, a.scl_p, a.prof);
     else
-        fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units);
+        fused_block_rm_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.scl_e, a.scl_p);
 }
 
 // Units per workgroup: as many as fit a CU, but a batch must still fill the chip -- the kernels are persistent over units, so with
@@ -526,7 +527,7 @@ int rm_threshold(const char *env, int dflt) {
 }  // namespace
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
-    if (!a.Arm_e || !a.Arm_p) return false;
+    if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p) return false;
     // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N; SYN_RM_MIN<f>_<U> override them)
     switch (feature) {
         case 2:

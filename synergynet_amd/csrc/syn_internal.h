@@ -58,12 +58,15 @@ bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t
 constexpr int early_block_hc(int hid) { return hid % 32 == 0 ? 32 : 48; }
 bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks, row-marching schedule (fused_block_rm.hip): hidden activations stay in registers, one wave per 32 hidden channels.
-// Weight fragments for v_mfma_f32_32x32x16_bf16 (lane (i = l&31, hh = l>>5) holds 8 K slots), [group][k16 step][piece 3][lane 64][4 dwords]:
+// Weight fragments for v_mfma_f32_32x32x16_f16, two fp16 pieces per weight (scaled by the layer's power of two, scl_e / scl_p above),
+// lane (i = l&31, hh = l>>5) holds 8 K slots, [group][k16 step][piece 2][lane 64][4 dwords]:
 //   expand  Arm_e: row i = hidden channel 32g + i, slot e of step s = input channel 16s + 8hh + e        (ceil(CIN/16) steps)
 //   project Arm_p: row i = output channel i,       slot e of step s = hidden channel 32g + 16s + 8(e>>2) + 4hh + (e&3)   (2 steps)
 // -- the project K order is the register order in which the expand / depthwise stage leaves a lane's 16 channels.
-constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 768; }
-constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 768; }
+// (stem_rm.hip still takes the features.1 projection as THREE bf16 pieces in the same order: rm_project_dwords_b3.)
+constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 512; }
+constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 512; }
+constexpr int rm_project_dwords_b3(int hid) { return ((hid + 31) / 32) * 2 * 768; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip), both GEMMs on v_mfma_f32_16x16x32_f16 with every
 // operand as TWO fp16 pieces (x = a + b, 22 significant bits; three products a a, a b, b a) and power-of-two operand scaling

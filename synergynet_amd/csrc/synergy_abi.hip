@@ -135,8 +135,9 @@ struct Net {
             if (L.kind == PW && L.feature >= 2 && L.feature <= 6) {
                 L.dst_wrm = dst;
                 dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
+                if (!L.dst_scl) { L.dst_scl = dst; dst += 4; }
             }
-            if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); }     // stem_rm.hip
+            if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords_b3(L.cin); }     // stem_rm.hip
             L.dst_wlb = 0;
             if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             L.dst_tlb = 0;
@@ -445,8 +446,8 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             if (h->fusion >= 2 && L.dst_wb3 && Pj.dst_wb3) {
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
-                if (L.dst_scl && Pj.dst_scl) { a.scl_e = P + L.dst_scl; a.scl_p = P + Pj.dst_scl; }
             }
+            if (h->fusion >= 2 && L.dst_scl && Pj.dst_scl) { a.scl_e = P + L.dst_scl; a.scl_p = P + Pj.dst_scl; }
             if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
                 a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
@@ -764,7 +765,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 for (int t = 0; t < 27; ++t) sum += (double)(w[co * 27 + t] * bn_scale[co]);
                 fsh[co] = (float)((double)(beta[co] - mean[co] * bn_scale[co]) - 255.0 / 256.0 * sum);
             }
-        } else if (L.dst_wrm) {          // row-marching early blocks: v_mfma_f32_32x32x16_bf16 fragments (syn_internal.h)
+        } else if (L.dst_wrm) {          // row-marching early blocks: v_mfma_f32_32x32x16_* fragments (syn_internal.h)
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
             auto split = [](float x, unsigned (&pc)[3]) {
                 for (int i = 0; i < 3; ++i) {
@@ -774,12 +775,24 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 }
             };
             const bool expand = L.relu6 != 0;
+            const bool b3 = L.feature == 1;             // stem_rm.hip: three bf16 pieces; fused_block_rm.hip: two fp16 pieces scaled by S
+            float S = 1.0f;
+            if (!b3) {
+                float mx = 0.f;
+                for (int nn = 0; nn < L.cout; ++nn)
+                    for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
+                int ex = 0;
+                if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+                S = ldexpf(1.0f, ex);
+                pk[L.dst_scl] = S; pk[L.dst_scl + 1] = 1.0f / S; pk[L.dst_scl + 2] = 6.0f * S;
+            }
             const int hid = expand ? L.cout : L.cin, ng = (hid + 31) / 32, ks = expand ? (L.cin + 15) / 16 : 2;
             for (int g = 0; g < ng; ++g)
                 for (int st = 0; st < ks; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
                             unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            float v2[2] = {0.f, 0.f};
                             const int i = lane & 31, hh = lane >> 5;
                             for (int e = 0; e < 2; ++e) {
                                 const int sl = 2 * d + e;
@@ -792,9 +805,17 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                                     if (i < L.cout && c < L.cin) v = w[(size_t)i * L.cin + c] * bn_scale[i];
                                 }
                                 split(v, pc[e]);
+                                v2[e] = v * S;
                             }
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[(((size_t)(g * ks + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                            if (b3) {
+                                for (int pcs = 0; pcs < 3; ++pcs)
+                                    dp[(((size_t)(g * ks + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                            } else {
+                                const unsigned a0 = f16_rtz(v2[0]), a1 = f16_rtz(v2[1]);
+                                const unsigned b0 = f16_rtz(v2[0] - f16_value(a0)), b1 = f16_rtz(v2[1] - f16_value(a1));
+                                dp[(((size_t)(g * ks + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                                dp[(((size_t)(g * ks + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+                            }
                         }
         }
         for (int c = 0; c < L.cout; ++c) {
