@@ -5,16 +5,16 @@
 //
 //   * a compute wave owns one 30-column half of one face (32 lanes = 30 output columns + one neighbour column each side: the
 //     two halves overlap by two stem columns instead of exchanging them) and marches down the 60 rows;
-//   * the stem convolution is an im2col GEMM on v_mfma_f32_32x32x16_bf16: A = the 32 stem channels x 27 taps (two k16 steps),
-//     B = the raw pixel bytes as bf16 -- every integer 0..255 IS a bf16 number, so only the filter needs the exact 3-way
-//     split (3 MFMAs per step).  The normalisation is folded: (2p-255)/256 = p/128 - 255/256, i.e. the packed filter is w/128
+//   * the stem convolution is an im2col GEMM on v_mfma_f32_32x32x16_f16: A = the 32 stem channels x 27 taps (two k16 steps),
+//     B = the raw pixel bytes as fp16 -- every integer 0..255 IS an fp16 number, so only the filter is carried as two fp16
+//     pieces (22 bits, scaled by a power of two; 2 MFMAs per step).  The normalisation is folded: (2p-255)/256 = p/128 - 255/256, i.e. the packed filter is w/128
 //     (exact) and the accumulator starts at shift - 255/256 * sum(w); zero padding (0 in normalised space) is the raw value
-//     127.5 = 0x42FF, also exact in bf16.  K-slot layout chosen so that a lane's sixteen taps are two runs of consecutive
+//     127.5, also exact in fp16.  K-slot layout chosen so that a lane's sixteen taps are two runs of consecutive
 //     bytes: lane half 0 carries kernel row 0 (9 taps) + the first 5 taps of row 1, half 1 carries row 2 + the last 4 of row 1;
 //   * depthwise 3x3 scattered into three row accumulators, neighbours through wave_shr / wave_shl, filter from LDS
-//     (broadcast reads); ReLU6 -> in-place bf16 x3 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
+//     (broadcast reads); ReLU6 -> in-place fp16 x2 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
-//   * ONE service wave per workgroup keeps the image rows of all units flowing: global dwords -> bf16 -> LDS row ring
+//   * ONE service wave per workgroup keeps the image rows of all units flowing: global dwords -> fp16 -> LDS row ring
 //     (8 slots per unit), one barrier per output row.
 // fp32 crops (forward_test) keep the tiled kernel of stem_block1.hip: arbitrary floats need the 3-way split on both sides.
 #include "syn_internal.h"
@@ -27,20 +27,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
-__device__ __forceinline__ void split2s(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+// two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 significant bits
+__device__ __forceinline__ void split2s(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ f32x16 mfma32s(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ float left_of(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
@@ -49,9 +48,9 @@ __device__ __forceinline__ float right_of(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 constexpr int kImgW = 120, kHid = 60;
-constexpr int kRowEl = 384;               // bf16 elements per image-row slot: [0] unused, [1..3] left padding pixel, [4 + 3x + c], tail
+constexpr int kRowEl = 384;               // fp16 elements per image-row slot: [0] unused, [1..3] left padding pixel, [4 + 3x + c], tail
 constexpr int kSlots = 8;                 // image-row ring per unit
-constexpr unsigned kPadBf16 = 0x42FFu;    // 127.5: the raw value of a zero in normalised space
+constexpr unsigned kPadF16 = 0x57F8u;     // 127.5 as fp16: the raw value of a zero in normalised space
 }  // namespace
 
 template <int U_, int WPE_>
@@ -65,10 +64,10 @@ struct StemRmCfg {
 
 template <class C>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, 3)))
-void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][3][64][4]*/,
-                    const float *__restrict__ s_shift /*[32] folded*/, const float *__restrict__ Wd /*[9][32] scaled*/,
-                    const float *__restrict__ d_shift, const unsigned *__restrict__ Ap3 /*[1][2][3][64][4]*/,
-                    const float *__restrict__ p_shift /*[16]*/, float *__restrict__ Y /*[B,60,60,16]*/, int B) {
+void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][2][64][4]*/,
+                    const float *__restrict__ s_shift /*[32] folded, then {S, 1/S, 6 S} of the stem filter*/, const float *__restrict__ Wd /*[9][32] scaled*/,
+                    const float *__restrict__ d_shift, const unsigned *__restrict__ Ap3 /*[1][2][2][64][4]*/,
+                    const float *__restrict__ p_shift /*[16]*/, const float *__restrict__ scl_p, float *__restrict__ Y /*[B,60,60,16]*/, int B) {
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,18 +75,21 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     float *Filt = reinterpret_cast<float *>(smem + C::U * C::UNIT_DW);       // [9][32] + row 9 = depthwise shift
     float *Ssh = Filt + 10 * 32, *Psh = Ssh + 32;
     constexpr int DSH = 9 * 32;
-    for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i];
-    if (tid < 32) { Filt[DSH + tid] = d_shift[tid]; Ssh[tid] = s_shift[tid]; Psh[tid] = tid < 16 ? p_shift[tid] : 0.f; }
+    // power-of-two scales of the fp16 weight pieces: stem accumulators start at Ss x shift, ReLU6 clamps at 6 Ss, the depthwise filter
+    // carries 1 / Ss; the projection starts at Sp x shift and is rescaled before the store
+    const float Ss = s_shift[32], inv_ss = s_shift[33], c6s = s_shift[34], Sp = scl_p[0], inv_sp = scl_p[1];
+    for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i] * inv_ss;
+    if (tid < 32) { Filt[DSH + tid] = d_shift[tid]; Ssh[tid] = s_shift[tid] * Ss; Psh[tid] = tid < 16 ? p_shift[tid] * Sp : 0.f; }
     // padding row (image row -1) and the left padding pixel / tails of every ring slot: 127.5 everywhere, then the service wave only
     // ever rewrites elements 4 .. 363
-    for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadBf16 | (kPadBf16 << 16);
+    for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadF16 | (kPadF16 << 16);
     __syncthreads();
 
     if (service) {
         __builtin_amdgcn_s_setprio(3);          // every compute wave waits for this wave at the row barrier
-        // ---- image rows -> bf16 -> ring: row iy of unit u lands in slot iy & 7 ----
-        // two image rows of every unit per call: all dword loads first (one global round trip), then byte -> float -> bf16
-        // (exact: the high half of the float) and one 8-byte LDS store per dword
+        // ---- image rows -> fp16 -> ring: row iy of unit u lands in slot iy & 7 ----
+        // two image rows of every unit per call: all dword loads first (one global round trip), then byte -> float -> fp16 pairs
+        // (exact) and one 8-byte LDS store per dword
         constexpr int PER_ROW = kImgW * 3 / 4;                     // 90 dwords
         constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
         auto stage_rows = [&](int fb, int iy0) {                   // rows iy0, iy0+1 of faces fb .. fb+U-1
@@ -109,11 +111,9 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
                 const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
                 const int iy = iy0 + r;
                 if (i < TOTAL && iy < kImgW) {
-                    const unsigned b0 = __builtin_bit_cast(unsigned, (float)(v[it] & 0xff)), b1 = __builtin_bit_cast(unsigned, (float)((v[it] >> 8) & 0xff));
-                    const unsigned b2 = __builtin_bit_cast(unsigned, (float)((v[it] >> 16) & 0xff)), b3 = __builtin_bit_cast(unsigned, (float)(v[it] >> 24));
                     u32x2 o;
-                    o[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-                    o[1] = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+                    o[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)(v[it] & 0xff), (float)((v[it] >> 8) & 0xff)));
+                    o[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)((v[it] >> 16) & 0xff), (float)(v[it] >> 24)));
                     *reinterpret_cast<u32x2 *>(smem + u * C::UNIT_DW + (iy & (kSlots - 1)) * (kRowEl / 2) + 2 + 2 * d) = o;   // elements 4 + 4d ..
                 }
             }
@@ -139,20 +139,20 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     // element offset of this lane's first tap inside a row slot: column 2*hc - 1 -> 4 + 3*(2hc - 1) = 6hc + 1 (clamped for the
     // out-of-image lanes, whose result is forced to zero anyway)
     const int run0 = 6 * (col_ok ? hc : 0) + 1;
-    u32x4 as[2][3], ap[2][3];
+    u32x4 as[2][2], ap[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            as[s][p] = *(const u32x4 *)(As3 + ((size_t)s * 3 + p) * 256 + lane * 4);
-            ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)s * 3 + p) * 256 + lane * 4);
+        for (int p = 0; p < 2; ++p) {
+            as[s][p] = *(const u32x4 *)(As3 + ((size_t)s * 2 + p) * 256 + lane * 4);
+            ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)s * 2 + p) * 256 + lane * 4);
         }
     const int cb = 4 * h;
     auto opaque_cb = [&]() { int v = cb; asm volatile("" : "+v"(v)); return v; };
 
     for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
         const int f = fb + uw;
-        const float ehi = (col_ok && f < B) ? 6.0f : 0.0f;
+        const float ehi = (col_ok && f < B) ? c6s : 0.0f;
         const bool st_ok = out_lane && f < B;
         const int yofs = (30 * c + j - 1) * 16 + 4 * h;             // (column, channel quad) inside an output row; < 2^31 elements per face
 
@@ -167,25 +167,22 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                u32x4 db[3];
+                u32x4 db[2];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
-                    unsigned hh, mm, ll;
-                    split2s(v0, v1, hh, mm, ll);
-                    db[0][t] = hh; db[1][t] = mm; db[2][t] = ll;
+                    unsigned ha, hb;
+                    split2s(v0, v1, ha, hb);
+                    db[0][t] = ha; db[1][t] = hb;
                 }
-                acc = mfma32s(ap[s][2], db[0], acc);
-                acc = mfma32s(ap[s][0], db[2], acc);
-                acc = mfma32s(ap[s][1], db[1], acc);
                 acc = mfma32s(ap[s][1], db[0], acc);
                 acc = mfma32s(ap[s][0], db[1], acc);
                 acc = mfma32s(ap[s][0], db[0], acc);
             }
             if (st_ok) {
                 float *dst = Y + ((size_t)f * kHid + oy) * kHid * 16 + yofs;
-                *(f32x4 *)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]};              // channels 4h .. 4h+3
-                *(f32x4 *)(dst + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]};        // channels 8 + 4h ..
+                *(f32x4 *)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]} * inv_sp;              // channels 4h .. 4h+3
+                *(f32x4 *)(dst + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]} * inv_sp;        // channels 8 + 4h ..
             }
         };
         auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
@@ -241,7 +238,6 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                e = mfma32s(as[s][2], xb[s], e);
                 e = mfma32s(as[s][1], xb[s], e);
                 e = mfma32s(as[s][0], xb[s], e);
             }
@@ -272,21 +268,21 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
 
 template <class C>
 static void launch_stem_cfg(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
-                            const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
+                            const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
     const int wgs = (B + C::U - 1) / C::U;
     const int grid = wgs < 256 ? wgs : 256;
-    stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B);
+    stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B);
 }
 
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
-                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s) {
-    if (!img8 || !As3 || !Ap3) return false;
+                    const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
+    if (!img8 || !As3 || !Ap3 || !scl_p) return false;
     // like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
     // threshold, the spatially tiled kernel (stem_block1.hip)
     static const int min4 = getenv("SYN_RM_MIN1_4") ? atoi(getenv("SYN_RM_MIN1_4")) : 768;
     static const int min2 = getenv("SYN_RM_MIN1_2") ? atoi(getenv("SYN_RM_MIN1_2")) : 480;
-    if (B >= min4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B, s); return true; }
-    if (B >= min2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, Y, B, s); return true; }
+    if (B >= min4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    if (B >= min2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     return false;
 }
 

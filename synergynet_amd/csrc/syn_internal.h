@@ -63,10 +63,8 @@ bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipSt
 //   expand  Arm_e: row i = hidden channel 32g + i, slot e of step s = input channel 16s + 8hh + e        (ceil(CIN/16) steps)
 //   project Arm_p: row i = output channel i,       slot e of step s = hidden channel 32g + 16s + 8(e>>2) + 4hh + (e&3)   (2 steps)
 // -- the project K order is the register order in which the expand / depthwise stage leaves a lane's 16 channels.
-// (stem_rm.hip still takes the features.1 projection as THREE bf16 pieces in the same order: rm_project_dwords_b3.)
 constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 512; }
 constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 512; }
-constexpr int rm_project_dwords_b3(int hid) { return ((hid + 31) / 32) * 2 * 768; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip), both GEMMs on v_mfma_f32_16x16x32_f16 with every
 // operand as TWO fp16 pieces (x = a + b, 22 significant bits; three products a a, a b, b a) and power-of-two operand scaling
@@ -88,14 +86,16 @@ void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const 
                         const float *b0, const float *wd, const float *sd, const float *bd, const float *wp_pk,
                         const float *sp, const float *bp, float *Y, int B, hipStream_t s);
 
-// features.0 + features.1 from uint8 crops, row-marching schedule (stem_rm.hip).  As3: stem filter / 128 as fragments of
-// v_mfma_f32_32x32x16_bf16, [k16 step 2][piece 3][lane 64][4 dwords], lane (i = stem channel, hh = l>>5) K slot q = 8s + e:
+// features.0 + features.1 from uint8 crops, row-marching schedule (stem_rm.hip).  As3: stem filter / 128, scaled by the power of
+// two S and split into two fp16 pieces, as fragments of v_mfma_f32_32x32x16_f16, [k16 step 2][piece 2][lane 64][4 dwords], lane
+// (i = stem channel, hh = l>>5) K slot q = 8s + e:
 //   hh = 0: q < 9 -> tap (ky 0, m = q), 9 <= q < 14 -> (ky 1, m = q - 9);   hh = 1: q < 9 -> (ky 2, m = q), 9 <= q < 13 -> (ky 1, m = q - 4)
 //   with m = 3*kx + ci (the byte order of a pixel triple in the HWC image); the other slots are zero.
-// s_shift [32]: BN shift - 255/256 * sum of the (scaled) filter; Ap3: the 32->16 projection in rm_project order (1 group).
-constexpr int rm_stem_dwords() { return 2 * 3 * 256 + 32; }
+// s_shift [32]: BN shift - 255/256 * sum of the (scaled) filter, then {S, 1/S, 6 S}; Ap3: the 32->16 projection in rm_project order
+// (1 group), scl_p its scales.
+constexpr int rm_stem_dwords() { return 2 * 2 * 256 + 32 + 4; }
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
-                    const unsigned *Ap3, const float *p_shift, float *Y, int B, hipStream_t s);
+                    const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s);
 
 // features.18 + global average pool + the three heads fused (head_kernel.hip): NHWC [B,4,4,320] -> param [B,62].
 void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const float *scale, const float *shift,

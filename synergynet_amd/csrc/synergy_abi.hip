@@ -137,7 +137,7 @@ struct Net {
                 dst += L.relu6 ? syn::rm_expand_dwords(L.cin, L.cout) : syn::rm_project_dwords(L.cin);
                 if (!L.dst_scl) { L.dst_scl = dst; dst += 4; }
             }
-            if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords_b3(L.cin); }     // stem_rm.hip
+            if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); L.dst_scl = dst; dst += 4; }     // stem_rm.hip
             L.dst_wlb = 0;
             if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             L.dst_tlb = 0;
@@ -417,8 +417,8 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
             if (h->fusion >= 2 && img8 && (h->early_rm & 8) &&
-                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 2 * 3 * 256, P + D.dst_wpk, P + D.dst_shift,
-                                    reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, X, B, s)) {
+                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 2 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
+                                    reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s)) {
                 li += 2;
                 mark(1);
                 if (stop_feature == 1) {
@@ -735,36 +735,39 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                         }
             }
         }
-        if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 in its K-slot order + folded shift
+        if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 x S as two fp16 pieces in its K-slot order + folded shift + scales
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
-            float *fsh = pk.data() + L.dst_wrm + 2 * 3 * 256;
-            auto split = [](float x, unsigned (&pc)[3]) {
-                for (int i = 0; i < 3; ++i) {
-                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
-                    float hf; memcpy(&hf, &u, 4);
-                    pc[i] = u >> 16; x -= hf;
-                }
-            };
+            float *fsh = pk.data() + L.dst_wrm + 2 * 2 * 256;
             auto tapw = [&](int co, int ky, int m) { return w[co * 27 + (m % 3) * 9 + ky * 3 + m / 3] * bn_scale[co]; };   // m = 3*kx + ci
+            float mx = 0.f;
+            for (int co = 0; co < 32; ++co)
+                for (int t = 0; t < 27; ++t) mx = fmaxf(mx, fabsf(w[co * 27 + t] * bn_scale[co] * (1.0f / 128.0f)));
+            int ex = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+            const float S = ldexpf(1.0f, ex);
             for (int st = 0; st < 2; ++st)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int d = 0; d < 4; ++d) {
-                        unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                        float x[2];
                         const int co = lane & 31, hh = lane >> 5;
                         for (int e = 0; e < 2; ++e) {
                             const int q = 8 * st + 2 * d + e;
                             float v = 0.f;
                             if (hh == 0) { if (q < 9) v = tapw(co, 0, q); else if (q < 14) v = tapw(co, 1, q - 9); }
                             else { if (q < 9) v = tapw(co, 2, q); else if (q < 13) v = tapw(co, 1, q - 4); }
-                            split(v * (1.0f / 128.0f), pc[e]);       // power of two: exact
+                            x[e] = v * (1.0f / 128.0f) * S;           // powers of two: exact
                         }
-                        for (int pcs = 0; pcs < 3; ++pcs) dp[((size_t)(st * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                        const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
+                        const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
+                        dp[((size_t)(st * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                        dp[((size_t)(st * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                     }
             for (int co = 0; co < 32; ++co) {
                 double sum = 0;
                 for (int t = 0; t < 27; ++t) sum += (double)(w[co * 27 + t] * bn_scale[co]);
                 fsh[co] = (float)((double)(beta[co] - mean[co] * bn_scale[co]) - 255.0 / 256.0 * sum);
             }
+            fsh[32] = S; fsh[33] = 1.0f / S; fsh[34] = 6.0f * S;
         } else if (L.dst_wrm) {          // row-marching early blocks: v_mfma_f32_32x32x16_* fragments (syn_internal.h)
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
             auto split = [](float x, unsigned (&pc)[3]) {
@@ -775,7 +778,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 }
             };
             const bool expand = L.relu6 != 0;
-            const bool b3 = L.feature == 1;             // stem_rm.hip: three bf16 pieces; fused_block_rm.hip: two fp16 pieces scaled by S
+            const bool b3 = false;                      // (every row-marching kernel takes two fp16 pieces scaled by S)
             float S = 1.0f;
             if (!b3) {
                 float mx = 0.f;
