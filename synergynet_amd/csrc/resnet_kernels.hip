@@ -128,27 +128,25 @@ void launch_conv(const float *in, const float *W, const float *scale, const floa
 }
 
 // =====================================================================================
-// The same implicit GEMM on the bf16 matrix pipe with fp32-equivalent accuracy (exact 3-way bf16 operand split, six
-// partial products per K=32 block -- see fused_block_bf3.hip).  Weights are split and lane-ordered offline:
-//   W3[n_tile][tap*Cin/32 + kc][piece][lane][4 dwords],  lane (channel l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
-// Activations stay fp32 in HBM; a lane fetches its 8 consecutive input channels (two float4) and splits them in
-// registers -- that VALU work runs beside the bf16 MFMAs of the other resident waves (separate pipes).
+// The same implicit GEMM on v_mfma_f32_16x16x32_f16 with fp32-equivalent accuracy: every operand as two fp16 pieces (x = a + b,
+// 22 significant bits), three partial products per K=32 block -- see fused_block_bf3.hip.  Weights are scaled by a power of two
+// S (max |w| S in [2^13, 2^14)), split and lane-ordered offline:
+//   W3[n_tile][tap*Cin/32 + kc][piece 2][lane][4 dwords], {S, 1/S};  lane (channel l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
+// Activations stay fp32 in HBM; a lane fetches its 8 consecutive input channels (two float4) and splits them in registers.
 // Requires Cin % 32 == 0.
 // =====================================================================================
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (&pc)[3]) {
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (&pc)[2]) {
     const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const unsigned u0 = __builtin_bit_cast(unsigned, x[2 * d]), u1 = __builtin_bit_cast(unsigned, x[2 * d + 1]);
-        const float r0 = x[2 * d] - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x[2 * d + 1] - __builtin_bit_cast(float, u1 & 0xffff0000u);
-        const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-        const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-        pc[0][d] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-        pc[1][d] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        pc[2][d] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+        const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[2 * d], x[2 * d + 1]));
+        const float r0 = x[2 * d] - (float)ah[0], r1 = x[2 * d + 1] - (float)ah[1];
+        pc[0][d] = __builtin_bit_cast(unsigned, ah);
+        pc[1][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     }
 }
 
@@ -182,20 +180,21 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
     }
     const unsigned *wp[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wp[i] = W3 + (size_t)(n0 / 16 + i) * steps * 768 + lane * 4;
+    for (int i = 0; i < NT; ++i) wp[i] = W3 + (size_t)(n0 / 16 + i) * steps * 512 + lane * 4;
+    const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[j][i] = z4;
 
-    auto fetch = [&](int s, u32x4(&wf)[NT][3], f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+    auto fetch = [&](int s, u32x4(&wf)[NT][2], f32x4(&a0)[MT], f32x4(&a1)[MT]) {
         const int tap = s / KCH, kc = s - tap * KCH;
         const int ky = tap / KW, kx = tap - ky * KW;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wf[i][p] = *(const u32x4 *)(wp[i] + ((size_t)s * 3 + p) * 256);
+            for (int p = 0; p < 2; ++p) wf[i][p] = *(const u32x4 *)(wp[i] + ((size_t)s * 2 + p) * 256);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int iy = py[j] + ky, ix = px[j] + kx;
@@ -207,19 +206,19 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
         }
     };
     auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
-    u32x4 wf[NT][3], wn[NT][3];
+    u32x4 wf[NT][2], wn[NT][2];
     f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
     fetch(0, wf, c0, c1);
     for (int s = 0; s < steps; ++s) {
         if (s + 1 < steps) fetch(s + 1, wn, n0v, n1v);
-        u32x4 bp[MT][3];
+        u32x4 bp[MT][2];
 #pragma unroll
         for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pbk[6] = {0, 2, 1, 0, 1, 0};
+        for (int t = 0; t < 3; ++t) {
+            constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wf[i][p] = wn[i][p];
+            for (int p = 0; p < 2; ++p) wf[i][p] = wn[i][p];
 #pragma unroll
         for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
     }
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
     for (int i = 0; i < NT; ++i) {
         int n = n0 + i * 16 + 4 * g;
         n = n < N ? n : 0;
-        scv[i] = *(const f32x4 *)&scale[n];
+        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
         shv[i] = *(const f32x4 *)&shift[n];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -412,33 +411,33 @@ void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bi
 }
 
 // =====================================================================================
-// 7x7 / 2 stem on the bf16 matrix pipe for uint8 crops (round 2), same construction as stem_rm.hip:
-//   * raw pixel bytes ARE bf16 numbers, so only the filter is split (3 MFMAs per k16 step); (2p-255)/256 = p/128 - 255/256 is
-//     folded into filter (/128) and shift; zero padding of the normalised image = raw 127.5 (0x42FF);
+// 7x7 / 2 stem on v_mfma_f32_32x32x16_f16 for uint8 crops (round 2), same construction as stem_rm.hip:
+//   * raw pixel bytes ARE fp16 numbers, so only the filter is carried as two fp16 pieces (2 MFMAs per k16 step); (2p-255)/256 = p/128 - 255/256 is
+//     folded into filter (/128) and shift; zero padding of the normalised image = raw 127.5;
 //   * im2col K order: kernel row ky contributes 22 consecutive elements of the image row (one don't-care byte + 7 pixels x 3
 //     channels, so that every pair of K slots is a 4-byte aligned LDS dword), 7 x 22 = 154 -> ten k16 steps; lane half h holds
 //     slots 8h..8h+7 of a step.  Whether a half's pair of a step lies in the same kernel row as the other half's (+16 bytes) or
 //     in the next one (row pointer + 1, -28 bytes) is a compile-time property of the slot, so two per-lane pointer tables
 //     (rsame / rsel, rebuilt per output row from scalar ring offsets) give every ds_read_b32 an immediate offset;
-//   * a compute wave = (face, 32 of the 64 channels) holds its 120 weight-fragment registers for the whole kernel and walks the
-//     60 output rows x 2 column blocks; one service wave per workgroup converts image rows to bf16 into a 16-slot LDS ring.
+//   * a compute wave = (face, 32 of the 64 channels) holds its 80 weight-fragment registers for the whole kernel and walks the
+//     60 output rows x 2 column blocks; one service wave per workgroup converts image rows to fp16 into a 16-slot LDS ring.
 // BN + ReLU epilogue, NHWC store.  (Was: a direct VALU convolution, 1.44 ms of the 12.4 ms forward at B = 512.)
 // =====================================================================================
 namespace {
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 constexpr int kRsRowEl = 384, kRsSlots = 16, kRsPadL = 12;
-constexpr unsigned kRsPad = 0x42FFu;
+constexpr unsigned kRsPad = 0x57F8u;          // 127.5 as fp16
 __device__ __forceinline__ f32x16s mfma_rs(u32x4s a, u32x4s b, f32x16s c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a), __builtin_bit_cast(bf16x8s, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, a), __builtin_bit_cast(f16x8s, b), c, 0, 0, 0);
 }
 }  // namespace
 
 template <int U>
 __global__ __launch_bounds__((2 * U + 1) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][10][3][64][4]*/,
+void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][10][2][64][4]*/,
                              const float *__restrict__ s_shift /*[64] folded*/, float *__restrict__ out /*[B,60,60,64]*/, int B) {
     constexpr int UNIT_DW = (kRsSlots + 1) * kRsRowEl / 2, NT = (2 * U + 1) * 64;
     __shared__ __attribute__((aligned(16))) unsigned smem[U * UNIT_DW];
@@ -468,11 +467,9 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
                 const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
                 const int iy = iy0 + r;
                 if (i < TOTAL && iy < kImg) {
-                    const unsigned b0 = __builtin_bit_cast(unsigned, (float)(v[it] & 0xff)), b1 = __builtin_bit_cast(unsigned, (float)((v[it] >> 8) & 0xff));
-                    const unsigned b2 = __builtin_bit_cast(unsigned, (float)((v[it] >> 16) & 0xff)), b3 = __builtin_bit_cast(unsigned, (float)(v[it] >> 24));
                     u32x2s o;
-                    o[0] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-                    o[1] = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+                    o[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)(v[it] & 0xff), (float)((v[it] >> 8) & 0xff)));
+                    o[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)((v[it] >> 16) & 0xff), (float)(v[it] >> 24)));
                     *reinterpret_cast<u32x2s *>(smem + u * UNIT_DW + (iy & (kRsSlots - 1)) * (kRsRowEl / 2) + kRsPadL / 2 + 2 * d) = o;
                 }
             }
@@ -492,14 +489,15 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
     // ---- compute wave: channels 32G .. 32G+31 of face fb + uw ----
     const int uw = wave_wg >> 1, G = wave_wg & 1;
     const int j = lane & 31, h = lane >> 5;
-    u32x4s as[10][3];
+    u32x4s as[10][2];
 #pragma unroll
     for (int s = 0; s < 10; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) as[s][p] = *(const u32x4s *)(As3 + ((size_t)(G * 10 + s) * 3 + p) * 256 + lane * 4);
+        for (int p = 0; p < 2; ++p) as[s][p] = *(const u32x4s *)(As3 + ((size_t)(G * 10 + s) * 2 + p) * 256 + lane * 4);
+    const float Ss = s_shift[64], inv_ss = s_shift[65];
     f32x4 sh4[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sh4[q] = *(const f32x4 *)&s_shift[32 * G + 8 * q + 4 * h];
+    for (int q = 0; q < 4; ++q) sh4[q] = *(const f32x4 *)&s_shift[32 * G + 8 * q + 4 * h] * Ss;
     const char *ring = reinterpret_cast<const char *>(smem + uw * UNIT_DW);
 
     for (int fb = blockIdx.x * U; fb < B; fb += gridDim.x * U) {
@@ -534,7 +532,6 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
                         const int a1 = m0 <= 12 ? rowoff[r0] + 2 * m0 + 16 : rowoff[r0 + 1] + 2 * m0 - 28;
                         xb[t] = *reinterpret_cast<const unsigned *>(ring + lanebase + (h ? a1 : a0));
                     }
-                    e = mfma_rs(as[s][2], xb, e);
                     e = mfma_rs(as[s][1], xb, e);
                     e = mfma_rs(as[s][0], xb, e);
                 }
@@ -542,7 +539,7 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
                     float *dst = out + ((size_t)(f * 60 + oy) * 60 + col) * 64 + 32 * G + 4 * h;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *(f32x4 *)(dst + 8 * q) = (f32x4){fmaxf(e[4 * q], 0.f), fmaxf(e[4 * q + 1], 0.f), fmaxf(e[4 * q + 2], 0.f), fmaxf(e[4 * q + 3], 0.f)};
+                        *(f32x4 *)(dst + 8 * q) = (f32x4){fmaxf(e[4 * q], 0.f), fmaxf(e[4 * q + 1], 0.f), fmaxf(e[4 * q + 2], 0.f), fmaxf(e[4 * q + 3], 0.f)} * inv_ss;
                 }
             }
             __syncthreads();

@@ -120,10 +120,10 @@ void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, co
                      hipStream_t s);
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
-// 7x7 stem on the bf16 matrix pipe (uint8 crops): As3 [group 2][k16 step 10][piece 3][lane 64][4 dwords], lane (i = channel 32G + i,
+// 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,
 // hh) K slot kk = 16s + 8hh + e: kernel row ky = kk / 22, m = kk % 22 (m = 0: don't-care byte, else kx = (m-1)/3, ci = (m-1)%3), kk >= 154
-// zero; weights / 128; s_shift [64] = BN shift - 255/256 * sum of the scaled filter
-constexpr int rn_stem_dwords() { return 2 * 10 * 3 * 256 + 64; }
+// zero; weights / 128 x S (power of two) as two fp16 pieces; s_shift [64] = BN shift - 255/256 * sum of the scaled filter, then {S, 1/S}
+constexpr int rn_stem_dwords() { return 2 * 10 * 2 * 256 + 64 + 4; }
 bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s);
 void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s);
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,

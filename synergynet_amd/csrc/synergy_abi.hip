@@ -180,7 +180,7 @@ const Net &net() {
 // :139-254 (ResNet: 7x7/2 stem, 3x3/2 max-pool, layers [3,4,6,3], heads tex/ori/shape/exp -> cat(ori,shape,exp,tex)).
 struct RConv {
     int cin, cout, k, stride, pad, hin, hout;
-    size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: 3-way bf16 split, MFMA lane order (dwords)
+    size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: fp16 x2 split scaled by a power of two, MFMA lane order (dwords), then {S, 1/S}
     size_t dst_wrm = 0;                                   // stem only: fragments + folded shift of resnet_stem_mfma_kernel
 };
 struct RBlock { int c1, c2, c3, ds; };
@@ -223,7 +223,7 @@ struct ResNet50 {
             c.dst_scale = dst; dst += npad;
             c.dst_shift = dst; dst += npad;
             c.dst_w3 = 0;
-            if (c.cin % 32 == 0) { c.dst_w3 = dst; dst += (size_t)npad * c.cin * c.k * c.k * 3 / 2; }
+            if (c.cin % 32 == 0) { c.dst_w3 = dst; dst += (size_t)npad * c.cin * c.k * c.k + 4; }      // two fp16 per weight, then {S, 1/S}
             if (c.cin == 3) { c.dst_wrm = dst; dst += syn::rn_stem_dwords(); }
             flops += 2.0 * c.cin * c.k * c.k * (double)c.cout * c.hout * c.hout;
             const size_t osz = (size_t)c.cout * c.hout * c.hout;
@@ -531,7 +531,7 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     const RConv &st = n.convs[0];
     // conv1+bn1+relu (:231-233): uint8 crops on the bf16 matrix pipe (batches that give every CU a workgroup), else the direct kernel
     if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
-          syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 3 * 256, A, B, s)))
+          syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
         syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
     syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s);                                                    // maxpool (:234)
     for (const RBlock &b : n.blocks) {                     // Bottleneck.forward (:114-136)
@@ -970,34 +970,35 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                     for (int t = 0; t < taps; ++t)
                         dw[(size_t)nn * taps * c.cin + (size_t)t * c.cin + ci] = w[((size_t)nn * c.cin + ci) * taps + t];
         }
-        if (c.dst_wrm) {   // 7x7 stem for the bf16 pipe: K order / folding documented in syn_internal.h
+        if (c.dst_wrm) {   // 7x7 stem on the fp16 matrix instructions: K order / folding documented in syn_internal.h
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_wrm);
-            float *fsh = pk.data() + c.dst_wrm + 2 * 10 * 3 * 256;
-            auto split = [](float x, unsigned (&pc)[3]) {
-                for (int i = 0; i < 3; ++i) {
-                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
-                    float hf; memcpy(&hf, &u, 4);
-                    pc[i] = u >> 16; x -= hf;
-                }
-            };
+            float *fsh = pk.data() + c.dst_wrm + 2 * 10 * 2 * 256;
+            float mx = 0.f;
+            for (int co = 0; co < 64; ++co) {
+                const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
+                for (int t = 0; t < 147; ++t) mx = fmaxf(mx, fabsf(w[(size_t)co * 147 + t] * a * (1.0f / 128.0f)));
+            }
+            int ex = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+            const float S = ldexpf(1.0f, ex);
             for (int G = 0; G < 2; ++G)
                 for (int st = 0; st < 10; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            float x[2] = {0.f, 0.f};
                             const int co = 32 * G + (lane & 31), hh = lane >> 5;
                             for (int e = 0; e < 2; ++e) {
                                 const int kk = 16 * st + 8 * hh + 2 * d + e, ky = kk / 22, m = kk % 22;
-                                float v = 0.f;
                                 if (kk < 154 && m >= 1) {
                                     const int kx = (m - 1) / 3, ci = (m - 1) % 3;
                                     const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
-                                    v = w[(size_t)co * 147 + ci * 49 + ky * 7 + kx] * a * (1.0f / 128.0f);
+                                    x[e] = w[(size_t)co * 147 + ci * 49 + ky * 7 + kx] * a * (1.0f / 128.0f) * S;
                                 }
-                                split(v, pc[e]);
                             }
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[((size_t)((G * 10 + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                            const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
+                            const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
+                            dp[((size_t)((G * 10 + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                            dp[((size_t)((G * 10 + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                         }
             for (int co = 0; co < 64; ++co) {
                 const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
@@ -1005,28 +1006,29 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                 for (int t = 0; t < 147; ++t) sum += (double)(w[(size_t)co * 147 + t] * a);
                 fsh[co] = (float)((double)(beta[co] - mean[co] * a) - 255.0 / 256.0 * sum);
             }
+            fsh[64] = S; fsh[65] = 1.0f / S;
         }
-        if (c.dst_w3) {   // [N][tap*Cin + ci] -> [n_tile][tap*Cin/32 + kc][piece][lane][4 dwords]
+        if (c.dst_w3) {   // [N][tap*Cin + ci] x S -> [n_tile][tap*Cin/32 + kc][piece 2][lane][4 dwords], {S, 1/S}: S = 2^e, max |w| S in [2^13, 2^14)
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_w3);
-            auto split = [](float x, unsigned (&pc)[3]) {
-                for (int i = 0; i < 3; ++i) {
-                    unsigned u; memcpy(&u, &x, 4); u &= 0xffff0000u;
-                    float hf; memcpy(&hf, &u, 4);
-                    pc[i] = u >> 16; x -= hf;
-                }
-            };
             const int kch = c.cin / 32, steps = taps * kch, K = taps * c.cin;
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)c.cout * K; ++i) mx = fmaxf(mx, fabsf(dw[i]));
+            int ex = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+            const float S = ldexpf(1.0f, ex);
+            float *tail = pk.data() + c.dst_w3 + (size_t)(c.cout / 16) * steps * 512;
+            tail[0] = S; tail[1] = 1.0f / S;
             for (int nt = 0; nt < c.cout / 16; ++nt)
                 for (int st = 0; st < steps; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            unsigned lo[3], hi[3];
                             const int nn = nt * 16 + (lane & 15);
                             const int k0 = (st / kch) * c.cin + (st % kch) * 32 + 8 * (lane >> 4) + 2 * d;
-                            split(dw[(size_t)nn * K + k0], lo);
-                            split(dw[(size_t)nn * K + k0 + 1], hi);
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[((((size_t)nt * steps + st) * 3 + pcs) * 64 + lane) * 4 + d] = lo[pcs] | (hi[pcs] << 16);
+                            const float x0 = dw[(size_t)nn * K + k0] * S, x1 = dw[(size_t)nn * K + k0 + 1] * S;
+                            const unsigned a0 = f16_rtz(x0), a1 = f16_rtz(x1);
+                            const unsigned b0 = f16_rtz(x0 - f16_value(a0)), b1 = f16_rtz(x1 - f16_value(a1));
+                            dp[((((size_t)nt * steps + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                            dp[((((size_t)nt * steps + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                         }
         }
         for (int ch = 0; ch < c.cout; ++ch) {
