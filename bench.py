@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 from synergynet_amd import synth                      # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA peak; the exact 3-way split issues 6 bf16 MFMAs per fp32 block product
+PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak; the two-piece fp16 operand split issues 3 fp16 MFMAs per fp32 block product
+PEAK_F16X2_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0      # ceiling of fp32-equivalent work on that pipe
 PEAK_HBM_GBS = 8000.0
 
 
@@ -321,10 +322,13 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         bb_ms = e0.elapsed_time(e1) / 5
+        ach = fl / (bb_ms * 1e-3) / 1e12
         roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (syn::conv_bf3_kernel implicit-GEMM launches + stem + max-pool + heads); '
-                                         'fp32-accurate results on v_mfma_f32_16x16x32_bf16 with the exact 3-way operand split',
-                    achieved=round(fl / (bb_ms * 1e-3) / 1e12, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(fl / (bb_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                                         'fp32-accurate results on v_mfma_f32_16x16x32_f16 with every operand as two fp16 pieces (3 MFMAs per '
+                                         'block product); peak = dense fp16 MFMA peak 2500 TFLOP/s / 3',
+                    achieved=round(ach, 3), peak=round(PEAK_F16X2_TFLOPS, 1), unit='TFLOP/s', frac=round(ach / PEAK_F16X2_TFLOPS, 4), traffic=None,
+                    mfma_issue_tflops=round(3 * ach, 1), mfma_peak_fp16=PEAK_F16_MFMA_TFLOPS,
+                    frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     flops_per_launch=fl, ms_per_launch=round(bb_ms, 4))
     elif rank == 0:
         nmax = 64
@@ -354,19 +358,20 @@ def main():
                     break
                 except Exception:
                     pass
-        ceiling = PEAK_BF16_MFMA_TFLOPS / 6.0
+        ceiling = PEAK_F16X2_TFLOPS
         roof = dict(bound='mfma',
-                    kernel=f'syn::fused_block_{{rm,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
-                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; features.2-4 row-marching with the '
-                           f'hidden activations in registers, features.5-17 whole-image tiles in LDS); fp32-accurate results on '
-                           f'v_mfma_f32_{{32x32x16,16x16x32}}_bf16 with an exact 3-way bf16 split of both operands (6 MFMAs per block '
-                           f'product); algorithmic fp32 FLOPs priced against the fp32 (f32-input) MFMA peak',
-                    achieved=round(achieved, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
-                    # the pipe these kernels actually issue on: 6 bf16 MFMAs per fp32 block product -> ceiling 2500 / 6 TFLOP/s of
-                    # fp32-equivalent work; frac_of_bf16x3_ceiling is the honest "share of the pipe in use" figure and
-                    # mfma_pipe_busy the same thing from SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (profiles/, separate PMC run)
-                    bf16x3_ceiling=round(ceiling, 1), frac_of_bf16x3_ceiling=round(achieved / ceiling, 4), mfma_pipe_busy=pipe_busy,
+                    kernel=f'syn::fused_block_{{rm,lb,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
+                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; features.2-6 row-marching and features.8-13 '
+                           f'register-resident with the hidden activations in registers, the others whole-image tiles in LDS); fp32-accurate '
+                           f'results on v_mfma_f32_{{32x32x16,16x16x32}}_f16 with every operand as two fp16 pieces (3 MFMAs per block product): '
+                           f'algorithmic fp32 FLOPs priced against the dense fp16 MFMA peak / 3',
+                    achieved=round(achieved, 3), peak=round(ceiling, 1), unit='TFLOP/s',
+                    frac=round(achieved / ceiling, 4), traffic=traffic,
+                    # what the pipe sees: 3 fp16 MFMAs per fp32 block product; mfma_pipe_busy is the same share of the pipe from
+                    # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (profiles/, separate PMC run).  Matrix and vector instructions of the waves of
+                    # a SIMD do not overlap (tools/ubench/mfma_valu_kinds.hip), so frac = t_mfma / (t_mfma + t_valu + t_exposed).
+                    mfma_issue_tflops=round(3 * achieved, 1), mfma_peak_fp16=PEAK_F16_MFMA_TFLOPS, mfma_pipe_busy=pipe_busy,
+                    frac_of_fp32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     flops_per_launch=round(fam_fl / len(fam)), ms_per_launch=round(fam_ms / len(fam), 5),
                     backbone=dict(ms=round(float(avg_ms.sum()), 4), launches=n,
                                   tflops=round(float(flops.sum()) / (float(avg_ms.sum()) * 1e-3) / 1e12, 3)),
