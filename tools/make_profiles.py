@@ -47,7 +47,7 @@ for k in fetch:
     per_kernel[k] = dict(
         read_bytes=fetch[k]['FETCH_SIZE'] * 2 * 1024, write_bytes=write.get(k, {}).get('WRITE_SIZE', 0) * 1024,
         mfma_pipe_busy=ratio(m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0), simd_cycles),
-        valu_insts=v.get('SQ_INSTS_VALU'), mfma_mops_bf16=v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16'),
+        valu_insts=v.get('SQ_INSTS_VALU'), mfma_mops_f16=v.get('SQ_INSTS_VALU_MFMA_MOPS_F16'),
         valu_active_of_wave_cycles=ratio(v.get('SQ_ACTIVE_INST_VALU', 0), v.get('SQ_WAVE_CYCLES', 0)),
         lds_insts=l.get('SQ_INSTS_LDS'), lds_bank_conflict_of_active=ratio(l.get('SQ_LDS_BANK_CONFLICT', 0), l.get('SQ_LDS_IDX_ACTIVE', 0)),
         lds_array_busy=ratio(l.get('SQ_LDS_IDX_ACTIVE', 0), m.get('GRBM_GUI_ACTIVE', 0) * 32),      # 256 LDS arrays, counter summed over XCDs

@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o k -- $B --o
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50 -o k -- $B --arch resnet50 --batch 512 > $O/stats_r50.log 2>&1; echo "stats(resnet50) rc=$?"
 P="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --overlap 0"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
-            "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" \
+            "valu:SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES" \
             "lds:SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE" \
             "wait:SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVES"; do
   name=${pass%%:*}; ctrs=${pass#*:}

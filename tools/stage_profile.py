@@ -15,7 +15,7 @@ m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state
 x = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=1))).cuda()
 names = ['stage0', 'expand', 'bar1', 'dw', 'bar2', 'project', 'epilog']
 print(f'{"feature":>8s} ' + ' '.join(f'{n:>9s}' for n in names) + '     total  (shader cycles per tile, view of wave 0)')
-for f in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (2, 3, 4, 5, 7, 8, 11, 12, 14, 15, 17)):
+for f in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (2, 3, 4, 5, 7, 8, 11, 12, 14, 15, 17)):  # features.8-13 (fused_block_lb.hip): columns = staging, expand, depthwise, project, exchange+store, averaged over all waves
     out = (C.c_ulonglong * 32)()
     abi.check(abi.lib().syn_debug_profile_block(m._h, x.data_ptr(), B, f, out))
     n = max(out[7], 1)
