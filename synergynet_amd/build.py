@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(PKG, '_obj')
 LIB = os.path.join(PKG, 'libsynergy_hip.so')
-SOURCES = ['synergy_abi.hip', 'backbone_kernels.hip', 'fused_block.hip', 'fused_block_bf3.hip', 'fused_block_early.hip', 'fused_block_rm.hip', 'fused_block_lb.hip', 'stem_block1.hip', 'stem_rm.hip', 'head_kernel.hip', 'resnet_kernels.hip', 'preproc_kernels.hip', 'recon_kernels.hip', 'render_kernels.hip', 'detector_kernels.hip', 'eval_kernels.hip']
+SOURCES = ['synergy_abi.hip', 'backbone_kernels.hip', 'fused_block.hip', 'fused_block_bf3.hip', 'fused_block_early.hip', 'fused_block_rm.hip', 'fused_block_lb.hip', 'fused_block_lb4.hip', 'stem_block1.hip', 'stem_rm.hip', 'head_kernel.hip', 'resnet_kernels.hip', 'preproc_kernels.hip', 'recon_kernels.hip', 'render_kernels.hip', 'detector_kernels.hip', 'eval_kernels.hip']
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 FLAGS = CFLAGS + ['-shared']          # (kept for tools that print the full command line)
 

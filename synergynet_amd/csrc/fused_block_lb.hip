@@ -314,11 +314,22 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     }
 
     // ---- exchange: wave `st` keeps the output tiles mt with (mt & 1) == st and hands the others to its partner ----
-    __syncthreads();                                     // every wave is done reading the fragments
     float *Red = reinterpret_cast<float *>(Xf);
     int le = lane;
     asm volatile("" : "+v"(le));                         // (output addresses are computed here, not carried through the loop)
     const int ne = le & 15, ge = le >> 4, pixe = 32 * (ne >> 3) + (ne & 7);
+    // residual and BN shift of this wave's tiles: requested before the barriers, consumed after them (an L2 round trip otherwise
+    // stands between the second barrier and the stores)
+    f32x4 rs[MT / 2][4], psh[MT / 2];
+#pragma unroll
+    for (int i = 0; i < MT / 2; ++i) {
+        const int nch = 16 * (2 * i + st) + 4 * ge;
+        psh[i] = *(const f32x4 *)&p_shift[nch];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (C::RES) rs[i][r] = *(const f32x4 *)&X[((size_t)fc * 64 + pixe + 8 * r) * COUT + nch];
+    }
+    __syncthreads();                                     // every wave is done reading the fragments
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) == st) continue;
@@ -330,15 +341,13 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) != st || !real) continue;
         const int nch = 16 * mt + 4 * ge;
-        const f32x4 psh = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const f32x4 o = *(const f32x4 *)&Red[((((1 - st) * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4];
             f32x4 v = st == 0 ? acc[mt][r] + o : o + acc[mt][r];        // stream 0 + stream 1
-            v = v * inv_p + psh;
-            const size_t at = ((size_t)f * 64 + pixe + 8 * r) * COUT + nch;
-            if (C::RES) v += *(const f32x4 *)&X[at];
-            *(f32x4 *)&Y[at] = v;
+            v = v * inv_p + psh[mt >> 1];
+            if (C::RES) v += rs[mt >> 1][r];
+            *(f32x4 *)&Y[((size_t)f * 64 + pixe + 8 * r) * COUT + nch] = v;
         }
     }
     SYNL_LAP(4);

@@ -51,6 +51,7 @@ struct FusedBlockArgs {
     const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
     const unsigned *Alb_e = nullptr;                  // ... its expand fragments
     const float *Tlb = nullptr;                       // ... and its per-group constants table
+    const unsigned *Glb = nullptr;                    // features.15-17: per-group runs of fused_block_lb4.hip, or null
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of
@@ -78,6 +79,11 @@ constexpr int lb_project_dwords(int hid, int cout) { return (hid / 32) * (cout /
 constexpr int lb_expand_dwords(int cin, int hid) { return (hid / 16) * (cin / 32) * 512; }
 constexpr int lb_table_floats(int hid) { return (hid / 32) * 12 * 32; }
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// 4x4 blocks (features.15-17), fused_block_lb4.hip: the same fragments and constants, but one contiguous run per hidden group
+// Glb [group HID/32]: Alb_e fragments of the group's two hidden tiles [tile 2][k32 step][piece 2][64][4] | Alb_p fragments
+// [out tile][piece 2][64][4] | Tlb rows [12][32] floats + 128 floats of padding  -- what one LDS-DMA burst copies.
+constexpr int lb4_group_dwords(int cin, int cout) { return (2 * (cin / 32) * 512 + (cout / 16) * 512 + 512 + 1023) / 1024 * 1024; }     // padded to 4 KB
+bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 

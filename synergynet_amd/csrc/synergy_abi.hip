@@ -61,6 +61,7 @@ struct Layer {
     size_t dst_wlb;      // project layers of features.8-13: fragments of the register-resident kernel (fused_block_lb.hip), or 0
     size_t dst_tlb;      // expand layers of features.8-13: per hidden group [12][32] floats = depthwise filter 9 rows | depthwise shift | expand shift | constants
     size_t dst_weh;      // expand layers of features.8-13: fp16 x2 fragments of the register-resident kernel, or 0
+    size_t dst_glb;      // expand layers of features.15-17: per hidden group one run [We | Wp | constants] for fused_block_lb4.hip, or 0
 };
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -141,6 +142,11 @@ struct Net {
             L.dst_wlb = 0;
             if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 13) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             L.dst_tlb = 0;
+            L.dst_glb = 0;
+            if (L.kind == PW && L.relu6 && L.feature >= 15 && L.feature <= 17) {
+                const int cout_p = L.feature == 17 ? 320 : 160;
+                L.dst_glb = dst; dst += syn::lb4_group_dwords(L.cin, cout_p) * (size_t)(L.cout / 32);
+            }
             L.dst_weh = 0;
             if (L.kind == PW && L.relu6 && L.feature >= 8 && L.feature <= 13) {
                 L.dst_tlb = dst; dst += syn::lb_table_floats(L.cout);
@@ -274,7 +280,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 255;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 511;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
@@ -457,8 +463,10 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.Alb_e = reinterpret_cast<const unsigned *>(P + L.dst_weh);
                 a.Tlb = P + L.dst_tlb;
             }
+            if (h->fusion >= 2 && L.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + L.dst_glb);
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
+                (a.Glb && syn::launch_fused_block_lb4(L.feature, a, B, s)) ||
                 (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
                 syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
@@ -828,7 +836,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
     }
     for (size_t li = 0; li + 2 < n.layers.size(); ++li) {      // fused_block_lb.hip (features.8-13): fp16 x2 fragments + per-group constants
         const Layer &L = n.layers[li], &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-        if (!L.dst_tlb) continue;
+        if (!L.dst_tlb && !L.dst_glb) continue;
         // x = a + b with a = fp16(x) and b = fp16(x - a) (both toward zero) keeps 22 significant bits: fp16 x fp16 products are exact in
         // fp32, a1 a2 + a1 b2 + b1 a2 misses b1 b2 <= 2^-22.  fp16's narrow exponent wants operands near the top of its range, so
         // every GEMM operand is scaled by a power of two (exact), the weights per layer such that max |w| lands in [2^13, 2^14):
@@ -858,34 +866,55 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
         std::vector<float> we, wp;
         const float Se = scaled(L, we), Sp = scaled(Pj, wp);
         const int hid = L.cout, cin = L.cin, cout = Pj.cout, ke = cin / 32, ng = hid / 32, mtn = cout / 16;
+        // expand fragment (hidden tile nt, k32 step kc), project fragment (group g, out tile mt), constants of group g
+        auto put_e = [&](unsigned *dst, int nt, int kc) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int d = 0; d < 4; ++d) {
+                    const size_t at = (size_t)(nt * 16 + (lane & 15)) * cin + 32 * kc + 8 * (lane >> 4) + 2 * d;
+                    put(dst, 0, lane, d, we[at], we[at + 1]);
+                }
+        };
+        auto put_p = [&](unsigned *dst, int g, int mt) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int d = 0; d < 4; ++d) {
+                    const int nn = 16 * mt + (lane & 15), kg = lane >> 4;
+                    float x[2];
+                    for (int e = 0; e < 2; ++e) {
+                        const int sl = 2 * d + e;
+                        x[e] = wp[(size_t)nn * hid + 32 * g + (sl < 4 ? 4 * kg + sl : 16 + 4 * kg + sl - 4)];
+                    }
+                    put(dst, 0, lane, d, x[0], x[1]);
+                }
+        };
+        auto put_t = [&](float *tb, int g) {
+            for (int c = 0; c < 32; ++c) {
+                for (int k = 0; k < 9; ++k) tb[k * 32 + c] = pk[D.dst_wpk + (size_t)k * hid + 32 * g + c] / Se;
+                tb[9 * 32 + c] = 16.0f * pk[D.dst_shift + 32 * g + c];
+                tb[10 * 32 + c] = 16.0f * Se * pk[L.dst_shift + 32 * g + c];
+            }
+        };
+        if (L.dst_glb) {             // fused_block_lb4.hip: per group [We: tile 2][k32][piece] | [Wp: out tile][piece] | 12 x 32 constants (+ pad to 2 KB)
+            const size_t grp = syn::lb4_group_dwords(cin, cout);
+            for (int g = 0; g < ng; ++g) {
+                unsigned *base = reinterpret_cast<unsigned *>(pk.data() + L.dst_glb) + (size_t)g * grp;
+                for (int t = 0; t < 2; ++t)
+                    for (int kc = 0; kc < ke; ++kc) put_e(base + (size_t)(t * ke + kc) * 512, 2 * g + t, kc);
+                unsigned *bp = base + (size_t)2 * ke * 512;
+                for (int mt = 0; mt < mtn; ++mt) put_p(bp + (size_t)mt * 512, g, mt);
+                float *tb = reinterpret_cast<float *>(bp + (size_t)mtn * 512);
+                put_t(tb, g);
+                if (g == 0) { tb[11 * 32 + 0] = 96.0f * Se; tb[11 * 32 + 1] = 1.0f / (16.0f * Sp); }
+            }
+            continue;
+        }
         unsigned *de = reinterpret_cast<unsigned *>(pk.data() + L.dst_weh);        // [hidden tile 16][k32 step][piece][lane][4]: lane (m, kg) holds k = 32 kc + 8 kg + e
         for (int nt = 0; nt < hid / 16; ++nt)
-            for (int kc = 0; kc < ke; ++kc)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int d = 0; d < 4; ++d) {
-                        const size_t at = (size_t)(nt * 16 + (lane & 15)) * cin + 32 * kc + 8 * (lane >> 4) + 2 * d;
-                        put(de, (size_t)nt * ke + kc, lane, d, we[at], we[at + 1]);
-                    }
+            for (int kc = 0; kc < ke; ++kc) put_e(de + (size_t)(nt * ke + kc) * 512, nt, kc);
         unsigned *dq = reinterpret_cast<unsigned *>(pk.data() + Pj.dst_wlb);       // [group][out tile][piece][lane][4], K order of syn_internal.h
         for (int g = 0; g < ng; ++g)
-            for (int mt = 0; mt < mtn; ++mt)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int d = 0; d < 4; ++d) {
-                        const int nn = 16 * mt + (lane & 15), kg = lane >> 4;
-                        float x[2];
-                        for (int e = 0; e < 2; ++e) {
-                            const int sl = 2 * d + e;
-                            x[e] = wp[(size_t)nn * hid + 32 * g + (sl < 4 ? 4 * kg + sl : 16 + 4 * kg + sl - 4)];
-                        }
-                        put(dq, (size_t)g * mtn + mt, lane, d, x[0], x[1]);
-                    }
+            for (int mt = 0; mt < mtn; ++mt) put_p(dq + (size_t)(g * mtn + mt) * 512, g, mt);
         float *tb = pk.data() + L.dst_tlb;
-        for (int g = 0; g < ng; ++g)
-            for (int c = 0; c < 32; ++c) {
-                for (int k = 0; k < 9; ++k) tb[(g * 12 + k) * 32 + c] = pk[D.dst_wpk + (size_t)k * hid + 32 * g + c] / Se;
-                tb[(g * 12 + 9) * 32 + c] = 16.0f * pk[D.dst_shift + 32 * g + c];
-                tb[(g * 12 + 10) * 32 + c] = 16.0f * Se * pk[L.dst_shift + 32 * g + c];
-            }
+        for (int g = 0; g < ng; ++g) put_t(tb + (size_t)g * 12 * 32, g);
         tb[11 * 32 + 0] = 96.0f * Se;               // ReLU6 ceiling of the scaled expand output
         tb[11 * 32 + 1] = 1.0f / (16.0f * Sp);      // project accumulator -> output
     }
