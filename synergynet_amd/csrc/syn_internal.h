@@ -82,7 +82,7 @@ bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStrea
 // 4x4 blocks (features.15-17), fused_block_lb4.hip: the same fragments and constants, but one contiguous run per hidden group
 // Glb [group HID/32]: Alb_e fragments of the group's two hidden tiles [tile 2][k32 step][piece 2][64][4] | Alb_p fragments
 // [out tile][piece 2][64][4] | Tlb rows [12][32] floats + 128 floats of padding  -- what one LDS-DMA burst copies.
-constexpr int lb4_group_dwords(int cin, int cout) { return (2 * (cin / 32) * 512 + (cout / 16) * 512 + 512 + 1023) / 1024 * 1024; }     // padded to 4 KB
+constexpr int lb4_group_dwords(int cin, int cout) { return (2 * (cin / 32) * 512 + (cout / 16) * 512 + 512 + 2047) / 2048 * 2048; }     // padded to 8 KB
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
