@@ -2,6 +2,8 @@
 // backbone_nets/resnet_backbone.py:90-136 Bottleneck, :139-254 ResNet): 7x7/2 stem + BN + ReLU, 3x3/2 max-pool,
 // and one implicit-GEMM convolution kernel (any kh x kw / stride / pad, NHWC fp32) on v_mfma_f32_16x16x4_f32
 // with a fused BN (+ residual) + ReLU epilogue that serves every 1x1 and 3x3 convolution of the bottlenecks.
+#include <cstdlib>
+
 #include "syn_internal.h"
 
 namespace syn {
@@ -274,6 +276,164 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
     }
 }
 
+// Same convolution with the weight fragments shared through LDS: the four waves of a workgroup compute four M tiles of the SAME
+// 64 output channels, so each of them loading all 8 KB of fragments per k32 step put 48 KB per step through the CU's vector
+// cache (118 B/cycle wanted, 64 B/cycle there) for 96 MFMAs.  Here a chunk of KS k32 steps' fragments (NT x KS x 2 KB) is fetched
+// once per workgroup -- a quarter per wave, into registers while the previous chunk computes, then into the other half of a
+// double buffer -- and every wave reads its A operands from LDS; one barrier per chunk.
+template <int MT, int NT, int KS>
+__global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       const float *__restrict__ residual, float *__restrict__ out, int M,
+                                                       int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
+                                                       int act, int n_tiles, int m_tiles) {
+    constexpr int CH_DW = NT * KS * 2 * 256;                     // one chunk of fragments: [tile NT][step KS][piece 2][64][4]
+    constexpr int NPW = NT * KS * 2 / 4;                         // fragments per wave and chunk
+    static_assert(NT * KS * 2 % 4 == 0, "a quarter of a chunk per wave");
+    __shared__ __attribute__((aligned(16))) unsigned wl[2 * CH_DW];
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt_idx = q % n_tiles;
+    const int mt_idx = (q / n_tiles) * 8 + xcd;
+    if (mt_idx >= m_tiles) return;                               // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = (mt_idx * 4 + wave) * (MT * 16);
+    const int n0 = nt_idx * (NT * 16);
+    const int KCH = Cin >> 5, steps = KH * KW * KCH, chunks = steps / KS;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    int pb[MT], py[MT], px[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        int m = m0 + j * 16 + r16;
+        m = m < M ? m : M - 1;                                   // (a wave past the end computes on clamped rows and stores nothing)
+        const int hw = Hout * Hout;
+        pb[j] = m / hw;
+        const int r = m - pb[j] * hw;
+        py[j] = (r / Hout) * stride - pad;
+        px[j] = (r % Hout) * stride - pad;
+    }
+    const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = z4;
+
+    // this wave's share of a chunk: fragments fi = wave + 4 k, fi = (tile i, step ks, piece p) in LDS order
+    u32x4 wf[NPW];
+    auto fetch_w = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) {
+            const int fi = wave + 4 * k, i = fi / (KS * 2), ks = (fi / 2) % KS, p = fi & 1;
+            wf[k] = *(const u32x4 *)(W3 + ((size_t)(n0 / 16 + i) * steps + c * KS + ks) * 512 + p * 256 + lane * 4);
+        }
+    };
+    auto park_w = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) *(u32x4 *)&wl[buf * CH_DW + (wave + 4 * k) * 256 + lane * 4] = wf[k];
+    };
+    auto fetch_a = [&](int s, f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+        const int tap = s / KCH, kc = s - tap * KCH;
+        const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int iy = py[j] + ky, ix = px[j] + kx;
+            const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 32 + 8 * g;
+            const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
+            a0[j] = ok ? v0 : z4;
+            a1[j] = ok ? v1 : z4;
+        }
+    };
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
+    fetch_w(0);
+    fetch_a(0, c0, c1);
+    park_w(0);
+    for (int c = 0; c < chunks; ++c) {
+        __syncthreads();                                         // chunk c is in LDS, chunk c-1 is read
+        if (c + 1 < chunks) fetch_w(c + 1);
+        const unsigned *wc = wl + (c & 1) * CH_DW + lane * 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int s = c * KS + ks;
+            if (s + 1 < steps) fetch_a(s + 1, n0v, n1v);
+            u32x4 bp[MT][2];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
+            u32x4 wa[NT][2];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wa[i][p] = *(const u32x4 *)(wc + ((i * KS + ks) * 2 + p) * 256);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
+        }
+        if (c + 1 < chunks) park_w((c + 1) & 1);
+    }
+    if (m0 >= M) return;
+    // epilogue as conv_bf3_kernel: loads first (branch-free), then arithmetic, then stores
+    f32x4 scv[NT], shv[NT], rsv[MT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int n = n0 + i * 16 + 4 * g;
+        n = n < N ? n : 0;
+        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
+        shv[i] = *(const f32x4 *)&shift[n];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            int m = m0 + j * 16 + r16;
+            m = m < M ? m : 0;
+            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v = acc[j][i] * scv[i] + shv[i];
+            if (residual) v += rsv[j][i];
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+            }
+            acc[j][i] = v;
+            asm volatile("" : "+v"(acc[j][i]));
+        }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + i * 16 + 4 * g;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m0 + j * 16 + r16;
+            if (m >= M) continue;
+            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
+        }
+    }
+}
+
+template <int MT, int NT, int KS>
+static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+                              float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
+                              hipStream_t s) {
+    const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
+    const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
+    const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    conv_h2s_kernel<MT, NT, KS><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
+                                                     act, n_tiles, m_tiles);
+}
+
 template <int MT, int NT>
 static void launch_conv_bf3_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
@@ -290,6 +450,13 @@ void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, co
                      hipStream_t s) {
     const int M = B * Hout * Hout;
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
+    static const int shared = getenv("SYN_CONV_SHARED") ? atoi(getenv("SYN_CONV_SHARED")) : 1;     // 0: every wave fetches its own fragments
+    if (shared && N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
+        // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
+        if (tiles >= 1024) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+        else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+        return;
+    }
     if (tiles >= 1024) launch_conv_bf3_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
     else launch_conv_bf3_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
 }
