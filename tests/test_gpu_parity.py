@@ -242,6 +242,44 @@ def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_e
     assert torch.equal(model.forward_crops_u8(torch.roll(cd, 3, 0)), torch.roll(got, 3, 0))
 
 
+@pytest.mark.parametrize('B', [8, 776])
+def test_fp16_operand_range_extreme_crops_and_wide_weights(pack, B):
+    """The GEMMs of the default schedule run on fp16 matrix instructions with every operand as two fp16 pieces and power-of-two
+    scales.  fp16's exponent range is the risk: saturated, black and maximum-contrast crops, and a backbone whose
+    weights span more than three orders of magnitude inside a layer (rows scaled by 10^-1.5 .. 10^2, compensated in the BatchNorm statistics so
+    that the activations keep their scale), must still match the fp32 oracle -- at a batch of 8 (tiled kernels) and of 776 (row-marching
+    and register-resident kernels)."""
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = {k: v.copy() for k, v in synth.make_backbone_state(seed=31).items()}
+    rng = np.random.default_rng(5)
+    for k in list(sd):
+        if not (k.endswith('.weight') and sd[k].ndim == 4 and sd[k].shape[2] == 1 and sd[k].shape[1] > 1):
+            continue                                               # pointwise convolutions only
+        parts = k.split('.')[:-1]
+        parts[-1] = str(int(parts[-1]) + 1)                        # the BatchNorm that follows: last numeric component + 1
+        bn = '.'.join(parts)
+        scale = (10.0 ** rng.uniform(-1.5, 2, size=sd[k].shape[0])).astype(np.float32)
+        # y = BN(W x): scaling row n of W by s, the running mean by s and (var + eps) by s^2 leaves the output unchanged
+        sd[k] = sd[k] * scale[:, None, None, None]
+        sd[bn + '.running_mean'] = sd[bn + '.running_mean'] * scale
+        sd[bn + '.running_var'] = (sd[bn + '.running_var'] + 1e-5) * scale * scale - 1e-5
+    model = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd)
+    crops = synth.make_crops(B, seed=61)
+    crops[0] = 255
+    crops[1] = 0
+    crops[2] = (np.indices((120, 120)).sum(0) % 2 * 255).astype(np.uint8)[:, :, None]          # checkerboard 0 / 255
+    crops[3, :, :60] = 255; crops[3, :, 60:] = 0
+    crops[4] = rng.integers(0, 2, (120, 120, 3), dtype=np.uint8) * 255
+    got = model.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    pick = np.unique(np.r_[0, 1, 2, 3, 4, 5, B - 1])
+    want, _ = backbone_torch.mobilenet_v2_forward(sd, synth.normalize_crops(crops[pick]))
+    assert rel_max(got[pick], want.numpy()) < TOL
+
+
 def test_two_stream_pipeline_equals_sequential_calls(model):
     """synergynet_amd/streams.py: reconstruction of batch i beside the backbone of batch i+1 -- same bits as the calls in
     sequence, for every batch of a stream of different batches (buffers of a batch stay alive while it is in flight)."""
