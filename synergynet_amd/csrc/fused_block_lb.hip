@@ -94,7 +94,7 @@ template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_
 struct LbCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, FPW = FPW_;
     static constexpr int PPF = PPF_;                     // output tiles the project fragments are fetched ahead (1 | 2)
-    static constexpr bool TLATE = COUT_ > 64;            // 96 accumulator registers: the next group's table is fetched after the project, not across it
+    static constexpr bool TLATE = false;                 // (true: the next group's table is fetched after the project instead of across it: 8 registers less, was needed with three bf16 pieces)
     static constexpr int EPF = EPF_;                     // k32 steps of the NEXT group's expand fragments fetched during the project (1 | KE)
     static constexpr bool RES = RES_;
     static constexpr int KE = CIN / 32;                  // k32 steps of the expand GEMM
@@ -364,10 +364,10 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y, B);
 }
 
-//                    CIN  HID COUT  RES  EPF PPF     (96 output channels = 96 accumulator registers: shallower prefetch or it spills)
+//                    CIN  HID COUT  RES  EPF PPF
 using L8 = LbCfg<      64, 384,  64, true,  2, 2>;     // features.8-10
-using L11 = LbCfg<     64, 384,  96, false, 1, 1>;     // features.11
-using L12 = LbCfg<     96, 576,  96, true,  1, 1>;     // features.12, 13
+using L11 = LbCfg<     64, 384,  96, false, 2, 2>;     // features.11
+using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
 
 static int lb_min_batch(int feature) {
     // below: too few workgroups to put two on every CU (the tiled kernel is faster); SYN_LB_MIN<f> overrides
