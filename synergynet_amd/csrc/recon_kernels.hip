@@ -207,29 +207,29 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
 }
 
 // =====================================================================================
-// The same contraction on the bf16 matrix pipe at fp32-equivalent accuracy.
+// The same contraction on v_mfma_f32_32x32x16_f16 at fp32-equivalent accuracy.
 //
-// Both operands are carried as three bf16 pieces x = h + m + l (exact: 8+8+8 significant bits by truncation; the basis
-// is split by the host, alpha by the prologue kernel) and each block product is rebuilt from the six partial products of
-// weight >= 2^-16 with v_mfma_f32_32x32x16_bf16 (fp32 accumulation, exact products).  K = 48 runs on the MFMA (3 steps of
-// 16, 54 MFMAs of 32 cycles per face tile and wave instead of 78 fp32-input MFMAs of 64 cycles); the last two expression
-// columns are two fp32 FMAs per output in the epilogue and the mean shape u is the accumulator's start value.
+// Both operands are carried as two fp16 pieces x = a + b (a = fp16(x), b = fp16(x - a), toward zero: 22 significant bits; the
+// basis is split by the host, alpha by the prologue kernel) and each block product is rebuilt from three partial products
+// a a + a b + b a (b b <= 2^-22 dropped; fp16 x fp16 is exact in fp32, fp32 accumulation).  K = 48 runs as 3 steps of 16 = 27 MFMAs
+// per face tile and wave (the exact 3-way bf16 split used before: 54; the fp32-input MFMA: 78 of 64 cycles), plus ONE more MFMA
+// whose K slots carry the partial products of the last two expression columns and of the mean shape.  fp16's exponent range: the
+// basis (and mean shape) are scaled by one power of two Sb (host: max |.| in [2^13, 2^14)), each face's coefficient vector by its
+// own power of two Sa (prologue: max |alpha| in [2^13, 2^14)), and 1 / (Sa Sb) is folded into the face's pose matrix.
 // =====================================================================================
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
 
 namespace {
-__device__ __forceinline__ void split2r(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
-    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
-    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+__device__ __forceinline__ void split2r(float x0, float x1, unsigned &a, unsigned &b) {
+    const f16x2r ah = __builtin_bit_cast(f16x2r, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
+    a = __builtin_bit_cast(unsigned, ah);
+    b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8r, a), __builtin_bit_cast(f16x8r, b), c, 0, 0, 0);
 }
 }  // namespace
 
@@ -244,36 +244,53 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
     const bool ok = b < B;
     const float *pp = param + (size_t)(ok ? b : 0) * kParam;
     unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+    // this lane's 24 coefficients + (both halves) columns 48, 49; the face's scale Sa = 2^e with max |alpha| Sa in [2^13, 2^14)
+    float al[3][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 12 + 16 * ks + 8 * hh + e;                     // alpha_k = param[12 + k] (parse_param_62)
+            al[ks][e] = ok ? pp[k] * stdv[k] + mean[k] : 0.f;
+            amax = fmaxf(amax, fabsf(al[ks][e]));
+        }
+    const float a48 = ok ? pp[12 + 48] * stdv[12 + 48] + mean[12 + 48] : 0.f;
+    const float a49 = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
+    amax = fmaxf(amax, fmaxf(fabsf(a48), fabsf(a49)));
+    amax = fmaxf(amax, __shfl_xor(amax, 32));                            // the other half of the face's coefficients
+    int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xff) - 126;     // amax = m 2^ex, m in [0.5, 1)
+    ex = 14 - ex;
+    ex = amax > 0.f ? (ex < -14 ? -14 : (ex > 14 ? 14 : ex)) : 0;         // Sa itself must be an fp16 number (it multiplies the mean)
+    const float Sa = __builtin_bit_cast(float, (unsigned)(127 + ex) << 23);
+    const float Sb = mean[62], inv_ab = mean[63] * __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
-        u32x4 pc[3];
+        u32x4 pc[2];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int k = 12 + 16 * ks + 8 * hh + 2 * d;                 // alpha_k = param[12 + k] (parse_param_62)
-            const float a0 = ok ? pp[k] * stdv[k] + mean[k] : 0.f, a1 = ok ? pp[k + 1] * stdv[k + 1] + mean[k + 1] : 0.f;
-            unsigned h, m, lo;
-            split2r(a0, a1, h, m, lo);
-            pc[0][d] = h; pc[1][d] = m; pc[2][d] = lo;
+            unsigned a, b2;
+            split2r(al[ks][2 * d] * Sa, al[ks][2 * d + 1] * Sa, a, b2);
+            pc[0][d] = a; pc[1][d] = b2;
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *(u32x4 *)&rt[((ks * 3 + p) * 64 + l) * 4] = pc[p];
+        for (int p = 0; p < 2; ++p) *(u32x4 *)&rt[((ks * 2 + p) * 64 + l) * 4] = pc[p];
     }
-    // fourth k16 step: the two expression columns 48, 49 and the mean shape ride on ONE more MFMA -- its 16 k slots carry the
-    // six split partial products of column 48 (k0-5), of column 49 (k6-11) and the three pieces of the mean times 1.0 (k12-14):
-    //   basis side   [b48h b48h b48m b48m b48h b48l | b49h b49h b49m b49m b49h b49l | uh um ul 0]
-    //   alpha side   [a48h a48m a48h a48m a48l a48h | a49h a49m a49h a49m a49l a49h |  1  1  1 0]
+    // fourth k16 step: the two expression columns 48, 49 and the mean shape ride on ONE more MFMA -- eight of its K slots (lane half
+    // 0; the other half is zero) carry the three split partial products of column 48, of column 49 and the two pieces of the mean
+    // times Sa:
+    //   basis side   [b48a b48a b48b | b49a b49a b49b | ua ub]
+    //   alpha side   [a48a a48b a48a | a49a a49b a49a | Sa Sa]
     {
-        const float a48 = ok ? pp[12 + 48] * stdv[12 + 48] + mean[12 + 48] : 0.f;
-        const float a49 = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
-        unsigned h, m, lo;
-        split2r(a48, a49, h, m, lo);                      // low half = piece of a48, high half = piece of a49
-        const unsigned h8 = h & 0xffffu, m8 = m & 0xffffu, l8 = lo & 0xffffu, h9 = h >> 16, m9 = m >> 16, l9 = lo >> 16;
-        const unsigned one = ok ? 0x3f80u : 0u;
-        u32x4 fx;
-        if (hh == 0) fx = (u32x4){h8 | (m8 << 16), h8 | (m8 << 16), l8 | (h8 << 16), h9 | (m9 << 16)};
-        else         fx = (u32x4){h9 | (m9 << 16), l9 | (h9 << 16), one | (one << 16), one};
-        *(u32x4 *)&rt[(9 * 64 + l) * 4] = fx;
+        unsigned a, b2;
+        split2r(a48 * Sa, a49 * Sa, a, b2);                              // low half = piece of a48, high half = piece of a49
+        const unsigned a8 = a & 0xffffu, b8 = b2 & 0xffffu, a9 = a >> 16, b9 = b2 >> 16;
+        const unsigned sa16 = ok ? (__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(Sa, Sa)) & 0xffffu) : 0u;
+        u32x4 fx = {0u, 0u, 0u, 0u};
+        if (hh == 0) fx = (u32x4){a8 | (b8 << 16), a8 | (a9 << 16), b9 | (a9 << 16), sa16 | (sa16 << 16)};
+        *(u32x4 *)&rt[(6 * 64 + l) * 4] = fx;
     }
+    (void)Sb;
     if (hh == 0) {
         float r[16];
         float p12[12];
@@ -291,11 +308,11 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
             }
             float m0 = p12[4 * c + 0], m1 = p12[4 * c + 1], m2 = p12[4 * c + 2], t = p12[4 * c + 3];
             if (transform && c == 1) { m0 = -m0; m1 = -m1; m2 = -m2; t = (float)(kImg + 1) - t; }
-            r[3 * c + 0] = m0 * sc; r[3 * c + 1] = m1 * sc; r[3 * c + 2] = m2 * sc;
+            r[3 * c + 0] = m0 * sc * inv_ab; r[3 * c + 1] = m1 * sc * inv_ab; r[3 * c + 2] = m2 * sc * inv_ab;     // the MFMA result is Sa Sb x the shape
             r[9 + c] = t * sc + of;
         }
         r[12] = 0.f; r[13] = 0.f; r[14] = 0.f; r[15] = 0.f;
-        float *rr = reinterpret_cast<float *>(rt + 10 * 256) + i * 16;
+        float *rr = reinterpret_cast<float *>(rt + 7 * 256) + i * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(f32x4 *)&rr[4 * q] = (f32x4){r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
     }
@@ -324,7 +341,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
     constexpr int NTH = WPG * 64, TQ = kRecTileB3 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
-    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order, 10 fragments) | 32 x 16 fp32 records
+    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order, 7 fragments) | 32 x 16 fp32 records
     __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
@@ -337,15 +354,15 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     const int j = lane & 31, h = lane >> 5;
 
     // resident basis fragments of this vertex tile: 3 coords x (3 k16 steps x 3 pieces + the fourth-step fragment)
-    u32x4 bb[3][3][3], bx[3];
+    u32x4 bb[3][3][2], bx[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned *bc = basis3 + ((size_t)T * 3 + c) * kBasisB3;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bb[c][ks][p] = *(const u32x4 *)(bc + ((ks * 3 + p) * 64 + lane) * 4);
-        bx[c] = *(const u32x4 *)(bc + (9 * 64 + lane) * 4);
+            for (int p = 0; p < 2; ++p) bb[c][ks][p] = *(const u32x4 *)(bc + ((ks * 2 + p) * 64 + lane) * 4);
+        bx[c] = *(const u32x4 *)(bc + (6 * 64 + lane) * 4);
     }
     const int ft0 = ft_lo + split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
@@ -385,20 +402,20 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
         // ds_write_b128 per coordinate into the stage).
         f32x16 acc[3];
         {
-            const u32x4 ax = *(const u32x4 *)(ot + (9 * 64 + lane) * 4);
+            const u32x4 ax = *(const u32x4 *)(ot + (6 * 64 + lane) * 4);
             const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = mfma32(bx[c], ax, z16);     // mean + columns 48, 49
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            u32x4 aa[3];                                                     // alpha pieces of this k16 step (LDS; the SIMD's other wave covers the latency)
+            u32x4 aa[2];                                                     // alpha pieces of this k16 step (LDS; the SIMD's other wave covers the latency)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) aa[p] = *(const u32x4 *)(ot + ((ks * 3 + p) * 64 + lane) * 4);
-            // six partial products, smallest first; the three coordinate planes interleave as independent chains
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            for (int p = 0; p < 2; ++p) aa[p] = *(const u32x4 *)(ot + ((ks * 2 + p) * 64 + lane) * 4);
+            // three partial products, smallest first; the three coordinate planes interleave as independent chains
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) acc[c] = mfma32(bb[c][ks][PB[q]], aa[PA[q]], acc[c]);
         }
@@ -407,7 +424,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
                                                      // compiler's wait-count bookkeeping to be conservative about
         RLAP(2);
         {   // pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
-            const float *rec = reinterpret_cast<const float *>(ot + 10 * 256) + j * 16;
+            const float *rec = reinterpret_cast<const float *>(ot + 7 * 256) + j * 16;
             const f32x4 q0 = *(const f32x4 *)&rec[0], q1 = *(const f32x4 *)&rec[4], q2 = *(const f32x4 *)&rec[8];
             float *st = stage + (j * 3) * SS + wave * 32 + 4 * h;
 #pragma unroll

@@ -144,14 +144,15 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
                         const float *basis, int n_vert, int nvp, const float *roi,
                         int transform, float *out, int pitch /*floats between rows of out, >= n_vert*/, int B, hipStream_t s, float *rec);
 
-// Same contraction on the bf16 matrix pipe (exact 3-way split of both operands, v_mfma_f32_32x32x16_bf16).
-//   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 3][lane 64][4 dwords] for k = 0..47
-//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), then one more [lane 64][4] fragment: a fourth k16
-//           step whose slots carry the split partial products of columns 48, 49 and the mean (recon_prep_b3_kernel).
-//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces in the same lane order (faces), the matching fourth-step
-//           fragment, then 32 x 16 fp32 records M[9] | T[3] | 0 x 4.
-constexpr int kBasisB3 = (3 * 3 + 1) * 256;
-constexpr int kRecTileB3 = (3 * 3 + 1) * 256 + 32 * 16;
+// Same contraction on v_mfma_f32_32x32x16_f16 (two fp16 pieces per operand, three partial products).
+//   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 2][lane 64][4 dwords] for k = 0..47
+//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), scaled by the power of two Sb (mean62[62], 1/Sb in
+//           mean62[63]), then one more [lane 64][4] fragment: a fourth k16 step whose slots carry the split partial products of
+//           columns 48, 49 and the mean (recon_prep_b3_kernel).
+//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces (x the face's power of two Sa) in the same lane order (faces), the
+//           matching fourth-step fragment, then 32 x 16 fp32 records M[9] / (Sa Sb) | T[3] | 0 x 4.
+constexpr int kBasisB3 = (3 * 2 + 1) * 256;
+constexpr int kRecTileB3 = (3 * 2 + 1) * 256 + 32 * 16;
 constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)
 constexpr int kRecSlack = 4096;
 void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,

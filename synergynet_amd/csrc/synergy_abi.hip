@@ -349,22 +349,37 @@ void pack_basis_tiles(float *dst, int n_rows_valid, int n_tiles, const float *w_
         }
 }
 
-// bf16 x3 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3)
+// fp32 -> fp16 bits, toward zero (what v_cvt_pkrtz_f16_f32 does to the activations), and back
+static unsigned f16_rtz(float x) {
+    unsigned u; memcpy(&u, &x, 4);
+    const unsigned sgn = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xff) - 127 + 15;
+    unsigned m = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0) return sgn;                    // fp32 zero / subnormal
+    if (e >= 31) return sgn | 0x7bffu;                          // (never reached: operands are scaled below 2^14)
+    if (e <= 0) return e < -10 ? sgn : sgn | ((m | 0x800000u) >> (14 - e));
+    return sgn | ((unsigned)e << 10) | (m >> 13);
+}
+static float f16_value(unsigned h) {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const float v = e ? ldexpf(1.0f + m / 1024.0f, e - 15) : ldexpf((float)m, -24);
+    return (h & 0x8000u) ? -v : v;
+}
+
+
+// fp16 x2 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3); every entry x Sb
 void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
-                         const int64_t *rows) {
+                         const int64_t *rows, float Sb) {
     auto wfull = [&](int v, int c, int k) -> float {
         if (v >= n_rows_valid) return 0.f;
         const size_t row = rows ? (size_t)rows[3 * v + c] : (size_t)3 * v + c;
-        if (k < 40) return w_shp[row * 40 + k];
-        if (k < 50) return w_exp[row * 10 + (k - 40)];
-        return u[row];
+        if (k < 40) return w_shp[row * 40 + k] * Sb;
+        if (k < 50) return w_exp[row * 10 + (k - 40)] * Sb;
+        return u[row] * Sb;
     };
-    auto split = [](float x, unsigned (&pc)[3]) {
-        for (int i = 0; i < 3; ++i) {
-            unsigned uu; memcpy(&uu, &x, 4); uu &= 0xffff0000u;
-            float hf; memcpy(&hf, &uu, 4);
-            pc[i] = uu >> 16; x -= hf;
-        }
+    auto split = [](float x, unsigned (&pc)[2]) {
+        pc[0] = f16_rtz(x);
+        pc[1] = f16_rtz(x - f16_value(pc[0]));
     };
     for (int t = 0; t < n_tiles; ++t)
         for (int c = 0; c < 3; ++c) {
@@ -372,23 +387,24 @@ void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const flo
             for (int ks = 0; ks < 3; ++ks)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int dd = 0; dd < 4; ++dd) {
-                        unsigned lo[3], hi[3];
+                        unsigned lo[2], hi[2];
                         const int k0 = 16 * ks + 8 * (lane >> 5) + 2 * dd;
                         split(wfull(32 * t + (lane & 31), c, k0), lo);
                         split(wfull(32 * t + (lane & 31), c, k0 + 1), hi);
-                        for (int pc = 0; pc < 3; ++pc) d[((ks * 3 + pc) * 64 + lane) * 4 + dd] = lo[pc] | (hi[pc] << 16);
+                        for (int pc = 0; pc < 2; ++pc) d[((ks * 2 + pc) * 64 + lane) * 4 + dd] = lo[pc] | (hi[pc] << 16);
                     }
-            // fourth k16 step (recon_prep_b3_kernel writes the matching alpha side): columns 48, 49 and the mean as split products
+            // fourth k16 step (recon_prep_b3_kernel writes the matching alpha side): columns 48, 49 and the mean as split products,
+            // [b48a b48a b48b | b49a b49a b49b | ua ub] in lane half 0, zeros in lane half 1
             for (int lane = 0; lane < 64; ++lane) {
-                unsigned b8[3], b9[3], uu[3];
+                unsigned b8[2], b9[2], uu[2];
                 split(wfull(32 * t + (lane & 31), c, 48), b8);
                 split(wfull(32 * t + (lane & 31), c, 49), b9);
                 split(wfull(32 * t + (lane & 31), c, 50), uu);
-                unsigned *x = d + (9 * 64 + lane) * 4;
+                unsigned *x = d + (6 * 64 + lane) * 4;
                 if ((lane >> 5) == 0) {
-                    x[0] = b8[0] | (b8[0] << 16); x[1] = b8[1] | (b8[1] << 16); x[2] = b8[0] | (b8[2] << 16); x[3] = b9[0] | (b9[0] << 16);
+                    x[0] = b8[0] | (b8[0] << 16); x[1] = b8[1] | (b9[0] << 16); x[2] = b9[0] | (b9[1] << 16); x[3] = uu[0] | (uu[1] << 16);
                 } else {
-                    x[0] = b9[1] | (b9[1] << 16); x[1] = b9[0] | (b9[2] << 16); x[2] = uu[0] | (uu[1] << 16); x[3] = uu[2];
+                    x[0] = x[1] = x[2] = x[3] = 0u;
                 }
             }
         }
@@ -600,23 +616,6 @@ int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 
 
 // Host-only packing of the MobileNetV2 state (BN folding, MFMA lane order, bf16 x3 split): shared by syn_load_backbone and
 // syn_pack_constants_host, so a blob packed without a device is byte-identical to what a handle exports.
-// fp32 -> fp16 bits, toward zero (what v_cvt_pkrtz_f16_f32 does to the activations), and back
-static unsigned f16_rtz(float x) {
-    unsigned u; memcpy(&u, &x, 4);
-    const unsigned sgn = (u >> 16) & 0x8000u;
-    const int e = (int)((u >> 23) & 0xff) - 127 + 15;
-    unsigned m = u & 0x7fffffu;
-    if (((u >> 23) & 0xff) == 0) return sgn;                    // fp32 zero / subnormal
-    if (e >= 31) return sgn | 0x7bffu;                          // (never reached: operands are scaled below 2^14)
-    if (e <= 0) return e < -10 ? sgn : sgn | ((m | 0x800000u) >> (14 - e));
-    return sgn | ((unsigned)e << 10) | (m >> 13);
-}
-static float f16_value(unsigned h) {
-    const int e = (h >> 10) & 31, m = h & 1023;
-    const float v = e ? ldexpf(1.0f + m / 1024.0f, e - 15) : ldexpf((float)m, -24);
-    return (h & 0x8000u) ? -v : v;
-}
-
 static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
     const Net &n = net();
     pk.assign(n.packed_count, 0.f);
@@ -1106,9 +1105,18 @@ static void pack_basis(const float *w_shp, const float *w_exp, const float *u, c
     float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
     memcpy(ms, param_mean, sizeof(float) * 62);
     memcpy(ms + 64, param_std, sizeof(float) * 62);
+    // power-of-two scale of the fp16 pieces of the basis: max over w_shp, w_exp and u in [2^13, 2^14)
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)3 * n_vert * 40; ++i) mx = fmaxf(mx, fabsf(w_shp[i]));
+    for (size_t i = 0; i < (size_t)3 * n_vert * 10; ++i) mx = fmaxf(mx, fabsf(w_exp[i]));
+    for (size_t i = 0; i < (size_t)3 * n_vert; ++i) mx = fmaxf(mx, fabsf(u[i]));
+    int ex = 0;
+    if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+    const float Sb = ldexpf(1.0f, ex);
+    ms[62] = Sb; ms[63] = 1.0f / Sb;
     unsigned *b3 = reinterpret_cast<unsigned *>(ms + 128);
-    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr);
-    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints);
+    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr, Sb);
+    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints, Sb);
 }
 
 int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u, const float *param_mean,
