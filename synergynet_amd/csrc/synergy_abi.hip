@@ -130,7 +130,7 @@ struct Net {
                 L.dst_wb3 = dst;
                 const int hc = L.relu6 ? L.cin : syn::early_block_hc(L.cin);
                 const int steps = (L.relu6 ? 1 : L.cin / hc) * (round_up(hc, 32) / 32);
-                dst += (size_t)(round_up(L.cout, 16) / 16) * steps * 768;
+                dst += (size_t)(round_up(L.cout, 16) / 16) * steps * 512;
             }
             L.dst_wrm = 0;
             if (L.kind == PW && L.feature >= 2 && L.feature <= 6) {
@@ -709,36 +709,47 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                                 dp[(((size_t)(nt * kch + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
                                 dp[(((size_t)(nt * kch + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                             }
-            } else {
-            const int hc = !early ? L.cin : (L.relu6 ? L.cin : syn::early_block_hc(L.cin));
+            } else {                 // early blocks (fused_block_early.hip): the same two fp16 pieces and scale, their own K chunking
+            // K is walked as `nch` chunks of `hc` real channels, each zero padded to `hcp` (a multiple of 32): expand hc = cin (16 / 24),
+            // hcp = 32; project hc = early_block_hc
+            const int hc = L.relu6 ? L.cin : syn::early_block_hc(L.cin);
             const int hcp = round_up(hc, 32), nch = L.cin / hc, spc = hcp / 32;     // k32 steps per chunk
             const int ntl = round_up(L.cout, 16) / 16, kch = nch * spc;
-            if (early && L.relu6 && L.cin == 16) {
-                // features.2 expand: K = 16 is one step of v_mfma_f32_32x32x16_bf16 -> [cout/32][piece][lane][4 dwords],
+            float mx = 0.f;
+            for (int nn = 0; nn < L.cout; ++nn)
+                for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
+            int ex = 0;
+            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+            const float S = ldexpf(1.0f, ex);                      // (= the scale the row-marching fragments of this layer use: dst_scl)
+            auto put2 = [&](size_t frag, int lane, int d, float x0, float x1) {
+                const unsigned a0 = f16_rtz(x0 * S), a1 = f16_rtz(x1 * S);
+                const unsigned b0 = f16_rtz(x0 * S - f16_value(a0)), b1 = f16_rtz(x1 * S - f16_value(a1));
+                dp[((frag * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                dp[((frag * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+            };
+            if (L.relu6 && L.cin == 16) {
+                // features.2 expand: K = 16 is one step of v_mfma_f32_32x32x16_f16 -> [cout/32][piece][lane][4 dwords],
                 // lane (i = l&31 channel of the 32-tile, h = l>>5) holds k = 8h .. 8h+7 (fused_block_early.hip, K16)
                 for (int nt = 0; nt < L.cout / 32; ++nt)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
                             const int nn = nt * 32 + (lane & 31);
-                            for (int e = 0; e < 2; ++e) split(w[(size_t)nn * L.cin + 8 * (lane >> 5) + 2 * d + e] * bn_scale[nn], pc[e]);
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[(((size_t)nt * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                            const size_t at = (size_t)nn * L.cin + 8 * (lane >> 5) + 2 * d;
+                            put2(nt, lane, d, w[at] * bn_scale[nn], w[at + 1] * bn_scale[nn]);
                         }
             } else
             for (int nt = 0; nt < ntl; ++nt)
                 for (int st = 0; st < kch; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            unsigned pc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+                            float x[2] = {0.f, 0.f};
                             const int nn = nt * 16 + (lane & 15);
                             for (int e = 0; e < 2; ++e) {
                                 const int within = (st % spc) * 32 + 8 * (lane >> 4) + 2 * d + e;
                                 const int kk = (st / spc) * hc + within;
-                                if (nn < L.cout && within < hc) split(w[(size_t)nn * L.cin + kk] * bn_scale[nn], pc[e]);
+                                if (nn < L.cout && within < hc) x[e] = w[(size_t)nn * L.cin + kk] * bn_scale[nn];
                             }
-                            for (int pcs = 0; pcs < 3; ++pcs)
-                                dp[(((size_t)(nt * kch + st) * 3 + pcs) * 64 + lane) * 4 + d] = pc[0][pcs] | (pc[1][pcs] << 16);
+                            put2((size_t)nt * kch + st, lane, d, x[0], x[1]);
                         }
             }
         }
