@@ -29,9 +29,11 @@ constexpr int cdive(int a, int b) { return (a + b - 1) / b; }
 constexpr int rupe(int a, int b) { return cdive(a, b) * b; }
 // two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 significant bits (fused_block_bf3.hip)
 __device__ __forceinline__ void split2e(float x0, float x1, unsigned &a, unsigned &b) {
-    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
-    a = __builtin_bit_cast(unsigned, ah);
+    // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
+    a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
     b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 __device__ __forceinline__ f32x4 mfmae(u32x4 a, u32x4 b, f32x4 c) {

@@ -43,9 +43,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 namespace {
 // x0, x1 -> packed fp16 pieces a (high) and b (low), x = a + b to 22 bits
 __device__ __forceinline__ void split2h(float x0, float x1, unsigned &a, unsigned &b) {
-    const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-    const float r0 = x0 - (float)ah[0], r1 = x1 - (float)ah[1];
-    a = __builtin_bit_cast(unsigned, ah);
+    // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
+    a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
     b = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 // ... into component d of the two piece vectors

@@ -145,9 +145,13 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (
     const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const f16x2 ah = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x[2 * d], x[2 * d + 1]));
-        const float r0 = x[2 * d] - (float)ah[0], r1 = x[2 * d + 1] - (float)ah[1];
-        pc[0][d] = __builtin_bit_cast(unsigned, ah);
+        // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
+        const float x0 = x[2 * d], x1 = x[2 * d + 1];
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+        pc[0][d] = a;
         pc[1][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     }
 }
