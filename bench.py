@@ -344,7 +344,7 @@ def main():
         avg_ms = acc_ms / reps
         feats = list(feat[:n])
         flops = np.array(fl[:n])
-        fam = [i for i, f in enumerate(feats) if 2 <= f <= 17]            # fused inverted-residual block launches
+        fam = [i for i, f in enumerate(feats) if 2 <= f <= 17 or f >= 100]  # fused inverted-residual block launches (>= 100: a chain, 100 * first + last)
         fam_ms, fam_fl = float(avg_ms[fam].sum()), float(flops[fam].sum())
         achieved = fam_fl / (fam_ms * 1e-3) / 1e12
         traffic = pipe_busy = None

@@ -219,7 +219,7 @@ int syn_backbone_launch_count(syn_handle *h);
 /* Runs one forward with a HIP event recorded on the library's stream after every kernel launch.
  * Returns the number of launches n (<= max_launches) or a negative syn_status; for launch i:
  * feature_of_launch[i] = index into .features the launch completes (1 = fused stem + features.1,
- * 19 = pool + heads), ms_of_launch[i] = event-to-event time, flops_of_launch[i] = algorithmic FLOPs
+ * 19 = pool + heads, 100 * a + b = one launch covering .features[a] .. [b]), ms_of_launch[i] = event-to-event time, flops_of_launch[i] = algorithmic FLOPs
  * of the layers it covers for the whole batch (no halo / padding work counted).  Synchronises. */
 int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_launches,
                          int *feature_of_launch, float *ms_of_launch, double *flops_of_launch);

@@ -37,6 +37,7 @@ namespace syn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -123,13 +124,27 @@ struct LbCfg {
 // of waves into prof[7] (syn_debug_profile_block)
 #define SYNL_LAP(i) do { if (PROF) { tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; } } while (0)
 
-template <class C, bool PROF = false>
-__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restrict__ Weh /*[HID/16][KE][2][64][4]*/,
-                           const float *__restrict__ Tlb /*[NG][12][32]*/, const unsigned *__restrict__ Wlb /*[NG][MT][2][64][4]*/,
-                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, unsigned long long *prof = nullptr) {
-    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
-    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+// One block of a face chain.  FIRST: the block input comes from global memory (X); otherwise the previous stage of the chain left it
+// in LDS as fragments.  CN != void: the block output is handed to stage CN of the same kernel -- written to global memory as usual
+// (the residual source of the next block, read back past the vector cache) AND split into the B fragments of CN's expand GEMM.
+// A workgroup walks the stages of a chain at its own pace: no kernel boundary (= device-wide barrier), no launch gap and no global
+// round trip of the block input between the blocks (measured 10-16 us per boundary, tools: the `fake` variant in DESIGN 5.9).
+struct LbStageArgs {
+    const float *X;          // block input (global): staging of a FIRST stage, residual of a RES stage
+    const unsigned *Weh;     // [HID/16][KE][2][64][4]
+    const float *Tlb;        // [NG][12][32]
+    const unsigned *Wlb;     // [NG][MT][2][64][4]
+    const float *p_shift;
+    float *Y;                // block output (global)
+};
+
+template <class C, class CN, bool FIRST, bool PROF, int FACE_DW>
+__device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, int B, unsigned long long (&pt_)[5], unsigned long long &tk) {
+    unsigned long long tn = 0;
+    const float *__restrict__ X = sa.X;
+    const unsigned *__restrict__ Weh = sa.Weh, *__restrict__ Wlb = sa.Wlb;
+    const float *__restrict__ Tlb = sa.Tlb, *__restrict__ p_shift = sa.p_shift;
+    float *__restrict__ Y = sa.Y;
     constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, COUT = C::COUT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,11 +154,11 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
     const unsigned l4 = lane * 4, g4 = g * 4;
-    unsigned *Xf = smem + fl * C::FACE_DW;
+    unsigned *Xf = smem + fl * FACE_DW;
     const int pix0 = 32 * (n >> 3) + (n & 7);           // pixel index of (block 0, lane column n); block r adds 8 r
 
     // ---- stage: block input of this face -> pre-split B fragments (this wave: blocks 2 st, 2 st + 1) ----
-    {
+    if (FIRST) {
         f32x4 xv[KE][2][2];
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc)
@@ -179,7 +194,7 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     // Per-group constants (depthwise filter and the two BN shifts of 32 channels, 1.4 KB) go through a private LDS buffer of the
     // wave: fetched (two 16-byte loads per lane) at the start of the previous group's project, written at its end -- an L2 round
     // trip per use would otherwise stand exposed five times per group with only two waves per SIMD to cover it.
-    float *Tb = reinterpret_cast<float *>(smem + C::FPW * C::FACE_DW + wave * C::TB_DW);
+    float *Tb = reinterpret_cast<float *>(smem + C::FPW * FACE_DW + wave * C::TB_DW);
     // weights and tables through buffer loads: ONE address register (16 * lane) for every fragment, the rest is scalar -- flat
     // addressing keeps a 64-bit lane pointer per 4 KB of fragment range alive across the loop (~25 registers)
     const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(Weh), 0, 0x7fffffff, 0x00027000);
@@ -321,7 +336,9 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
     asm volatile("" : "+v"(le));                         // (output addresses are computed here, not carried through the loop)
     const int ne = le & 15, ge = le >> 4, pixe = 32 * (ne >> 3) + (ne & 7);
     // residual and BN shift of this wave's tiles: requested before the barriers, consumed after them (an L2 round trip otherwise
-    // stands between the second barrier and the stores)
+    // stands between the second barrier and the stores).  Inside a chain the residual is what this wave stored one stage ago, into
+    // a buffer this CU read two stages ago: the load goes past the vector cache (sc0: miss in the CU's cache, served by the XCD's L2, where the store landed).
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, 0x7fffffff, 0x00027000);
     f32x4 rs[MT / 2][4], psh[MT / 2];
 #pragma unroll
     for (int i = 0; i < MT / 2; ++i) {
@@ -329,7 +346,7 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
         psh[i] = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (C::RES) rs[i][r] = *(const f32x4 *)&X[((size_t)fc * 64 + pixe + 8 * r) * COUT + nch];
+            if (C::RES) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
     }
     __syncthreads();                                     // every wave is done reading the fragments
 #pragma unroll
@@ -339,9 +356,11 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
         for (int r = 0; r < 4; ++r) *(f32x4 *)&Red[(((st * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4] = acc[mt][r];
     }
     __syncthreads();
+    constexpr bool HANDOFF = !__is_same(CN, void);
+    f32x4 vout[MT / 2][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if ((mt & 1) != st || !real) continue;
+        if ((mt & 1) != st) continue;
         const int nch = 16 * mt + 4 * ge;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -349,27 +368,89 @@ void fused_block_lb_kernel(const float *__restrict__ X, const unsigned *__restri
             f32x4 v = st == 0 ? acc[mt][r] + o : o + acc[mt][r];        // stream 0 + stream 1
             v = v * inv_p + psh[mt >> 1];
             if (C::RES) v += rs[mt >> 1][r];
-            *(f32x4 *)&Y[((size_t)f * 64 + pixe + 8 * r) * COUT + nch] = v;
+            if (real) *(f32x4 *)&Y[((size_t)f * 64 + pixe + 8 * r) * COUT + nch] = v;
+            if (HANDOFF) vout[mt >> 1][r] = v;
         }
     }
+    if constexpr (HANDOFF) {
+        // ---- hand the block output to the next stage: x 16, split, into the fragment layout of ITS expand GEMM.  This lane holds
+        //      channels 16 mt + 4 ge .. + 3 of pixel (r, ne): k32 step mt >> 1, lane group 2 (mt & 1) + (ge >> 1), dwords 2 (ge & 1), + 1 ----
+        static_assert(CN::CIN == COUT, "the next block of the chain takes this block's output");
+        __syncthreads();                                 // everybody has read the exchange buffer (it aliases the fragments)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if ((mt & 1) != st) continue;
+            const int kc = mt >> 1, lsrc = (2 * (mt & 1) + (ge >> 1)) * 16 + ne, dw = 2 * (ge & 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 v = real ? vout[mt >> 1][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+                unsigned a0, b0, a1, b1;
+                split2h(v[0], v[1], a0, b0);
+                split2h(v[2], v[3], a1, b1);
+                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 0) * 256 + lsrc * 4 + dw] = (u32x2){a0, a1};
+                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 1) * 256 + lsrc * 4 + dw] = (u32x2){b0, b1};
+            }
+        }
+        // (the barrier after the next stage's prologue publishes the fragments)
+    }
     SYNL_LAP(4);
-    if (PROF && lane == 0) {
+}
+
+template <class C, bool PROF = false>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nullptr) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    lb_stage<C, void, true, PROF, C::FACE_DW>(smem, sa, B, pt_, tk);
+    if (PROF && (threadIdx.x & 63) == 0) {
         for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], pt_[i]);
         atomicAdd(&prof[7], 1ull);
     }
-}
-
-template <class C>
-static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
-    const int grid = (B + C::FPW - 1) / C::FPW;
-    if (a.prof) fused_block_lb_kernel<C, true><<<grid, C::NT, 0, s>>>(a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y, B, a.prof);
-    else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y, B);
 }
 
 //                    CIN  HID COUT  RES  EPF PPF
 using L8 = LbCfg<      64, 384,  64, true,  2, 2>;     // features.8-10
 using L11 = LbCfg<     64, 384,  96, false, 2, 2>;     // features.11
 using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
+
+// features.8 .. 13 of a face in ONE launch: 8, 9, 10 (64 -> 384 -> 64, residual), 11 (64 -> 384 -> 96), 12, 13 (96 -> 576 -> 96, residual)
+struct LbChainArgs { LbStageArgs s[6]; };
+constexpr int kChainFaceDw = L12::FACE_DW > L8::FACE_DW ? (L12::FACE_DW > L11::FACE_DW ? L12::FACE_DW : L11::FACE_DW) : L8::FACE_DW;
+constexpr int kChainLdsDw = L8::FPW * kChainFaceDw + L8::NW * L8::TB_DW;
+static_assert(2 * kChainLdsDw * 4 <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(L8::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_chain_lb_kernel(LbChainArgs ca, int B) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDw];
+    lb_stage<L8, L8, true, false, kChainFaceDw>(smem, ca.s[0], B, pt_, tk);
+    lb_stage<L8, L8, false, false, kChainFaceDw>(smem, ca.s[1], B, pt_, tk);
+    lb_stage<L8, L11, false, false, kChainFaceDw>(smem, ca.s[2], B, pt_, tk);
+    lb_stage<L11, L12, false, false, kChainFaceDw>(smem, ca.s[3], B, pt_, tk);
+    lb_stage<L12, L12, false, false, kChainFaceDw>(smem, ca.s[4], B, pt_, tk);
+    lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[5], B, pt_, tk);
+}
+
+template <class C>
+static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
+    const int grid = (B + C::FPW - 1) / C::FPW;
+    const LbStageArgs sa{a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y};
+    if (a.prof) fused_block_lb_kernel<C, true><<<grid, C::NT, 0, s>>>(sa, B, a.prof);
+    else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(sa, B);
+}
+
+// features.8-13 in one launch (a[i] = the arguments of features.(8 + i)); false: run them one by one
+bool launch_fused_chain_lb(const FusedBlockArgs (&a)[6], int B, hipStream_t s) {
+    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 1;
+    if (!chain || B < 768) return false;
+    LbChainArgs ca;
+    for (int i = 0; i < 6; ++i) {
+        if (!a[i].Alb_e || !a[i].Alb_p || !a[i].Tlb || a[i].prof) return false;
+        ca.s[i] = LbStageArgs{a[i].X, a[i].Alb_e, a[i].Tlb, a[i].Alb_p, a[i].p_shift, a[i].Y};
+    }
+    fused_chain_lb_kernel<<<(B + L8::FPW - 1) / L8::FPW, L8::NT, 0, s>>>(ca, B);
+    return true;
+}
 
 static int lb_min_batch(int feature) {
     // below: too few workgroups to put two on every CU (the tiled kernel is faster); SYN_LB_MIN<f> overrides

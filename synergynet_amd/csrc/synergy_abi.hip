@@ -280,7 +280,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 511;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 1023;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
@@ -458,6 +458,38 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 return SYN_OK;
             }
             continue;
+        }
+        // features.8-13 as one chain launch (fused_block_lb.hip): every workgroup carries its faces through the six blocks
+        if (h->fusion >= 2 && L.kind == PW && L.relu6 && L.feature == 8 && (h->early_rm & 128) && (h->early_rm & 512) && prof_feature < 0 &&
+            (stop_feature < 0 || stop_feature >= 13) && li + 18 <= nl) {
+            // Workgroups run through the stages unsynchronised, so a buffer must never hold two tensor layouts at once: the 64-channel
+            // tensors (input, features.8-10) ping-pong in X / Y, the 96-channel ones (features.11-13) in H1 / H2 -- a fast workgroup's
+            // 96-channel store into X would land in the 64-channel rows a slower workgroup still reads.
+            syn::FusedBlockArgs ca[6];
+            float *const bin[6] = {X, Y, X, Y, H1, H2}, *const bout[6] = {Y, X, Y, H1, H2, H1};
+            bool ok = true;
+            for (int i = 0; i < 6 && ok; ++i) {
+                float *xin = bin[i], *xout = bout[i];
+                const Layer &E = n.layers[li + 3 * i], &Dw = n.layers[li + 3 * i + 1], &Pr = n.layers[li + 3 * i + 2];
+                ok = E.kind == PW && E.relu6 && E.feature == 8 + i && E.dst_weh && E.dst_tlb && Pr.dst_wlb;
+                if (!ok) break;
+                ca[i] = syn::FusedBlockArgs{xin, P + E.dst_wpk, P + E.dst_scale, P + E.dst_shift, P + Dw.dst_wpk, P + Dw.dst_scale, P + Dw.dst_shift,
+                                            P + Pr.dst_wpk, P + Pr.dst_scale, P + Pr.dst_shift, xout};
+                ca[i].Alb_e = reinterpret_cast<const unsigned *>(P + E.dst_weh);
+                ca[i].Alb_p = reinterpret_cast<const unsigned *>(P + Pr.dst_wlb);
+                ca[i].Tlb = P + E.dst_tlb;
+            }
+            if (ok && syn::launch_fused_chain_lb(ca, B, s)) {
+                li += 17;                                   // six blocks of three layers
+                { float *t = X; X = H1; H1 = t; }           // the chain's output is the block input from here on; the old input buffer takes H1's role
+                mark(813);
+                if (stop_feature == 13) {
+                    const Layer &Lp = n.layers[li];
+                    HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    return SYN_OK;
+                }
+                continue;
+            }
         }
         // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
         if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
@@ -1326,6 +1358,11 @@ int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_l
                 bool has18 = false;
                 for (size_t j = 1; j < feats.size(); ++j) has18 |= feats[j] == 18;
                 if (!has18) fl += 2.0 * 320 * 1280 * 16;          // fused head: features.18 rides in this launch
+            }
+            else if (feats[i] >= 100) {                  // a chain launch: features first .. last = code / 100 .. code % 100
+                for (const Layer &L : n.layers)
+                    if (L.feature >= feats[i] / 100 && L.feature <= feats[i] % 100)
+                        fl += 2.0 * (L.kind == DW ? 9.0 * L.cout : (double)L.cin * L.cout) * L.hout * L.hout;
             }
             else if (i == 1 && feats[i] == 1) { for (const Layer &L : n.layers) if (L.feature <= 1) fl += 2.0 * (L.kind == STEM ? 27.0 * 32 : L.kind == DW ? 9.0 * L.cout : (double)L.cin * L.cout) * L.hout * L.hout; }
             else {
