@@ -91,28 +91,32 @@ __device__ __forceinline__ f32x2 dpp2(f32x2 v) {
     return r;
 }
 constexpr int kRowShr1 = 0x111, kRowShl1 = 0x101, kRowShr8 = 0x118, kRowShl8 = 0x108;   // lane n <- n-1 | n+1 | n-8 | n+8 of its 16-lane row, else 0
+constexpr int kRowShr4 = 0x114, kRowShr5 = 0x115;
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_ = 2>
+template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_ = 2, bool S2_ = false>
 struct LbCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, FPW = FPW_;
     static constexpr int PPF = PPF_;                     // output tiles the project fragments are fetched ahead (1 | 2)
     static constexpr bool TLATE = false;                 // (true: the next group's table is fetched after the project instead of across it: 8 registers less, was needed with three bf16 pieces)
     static constexpr int EPF = EPF_;                     // k32 steps of the NEXT group's expand fragments fetched during the project (1 | KE)
     static constexpr bool RES = RES_;
+    static constexpr bool S2 = S2_;                      // stride-2 depthwise (8x8 -> 4x4, features.14): see the pixel order below
+    static constexpr int NB = S2 ? 1 : 4;                // 16-pixel blocks of the block OUTPUT
+    static constexpr int PIXO = NB * 16;
     static constexpr int KE = CIN / 32;                  // k32 steps of the expand GEMM
     static constexpr int NG = HID / 32;                  // hidden groups
     static constexpr int MT = COUT / 16;                 // output channel tiles
     static constexpr int NS = 2;                         // waves per face (hidden groups s, s + 2, ...)
     static constexpr int NW = FPW * NS, NT = NW * 64;
     static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
-    static constexpr int RED_DW = MT * 4 * 256;          // exchange buffer of one face: [stream 2][MT / 2][block 4][lane 64][4]
+    static constexpr int RED_DW = MT * NB * 256;         // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
     static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
     static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
     static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
-    static_assert(!RES || CIN == COUT, "residual only on same-width blocks");
+    static_assert(!RES || (CIN == COUT && !S2), "residual only on same-width stride-1 blocks");
     static_assert((FPW == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
@@ -138,14 +142,14 @@ struct LbStageArgs {
     float *Y;                // block output (global)
 };
 
-template <class C, class CN, bool FIRST, bool PROF, int FACE_DW>
+template <class C, class CN, bool FIRST, bool PROF, int FACE_DW, bool STORE = true>
 __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, int B, unsigned long long (&pt_)[5], unsigned long long &tk) {
     unsigned long long tn = 0;
     const float *__restrict__ X = sa.X;
     const unsigned *__restrict__ Weh = sa.Weh, *__restrict__ Wlb = sa.Wlb;
     const float *__restrict__ Tlb = sa.Tlb, *__restrict__ p_shift = sa.p_shift;
     float *__restrict__ Y = sa.Y;
-    constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, COUT = C::COUT;
+    constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, COUT = C::COUT, NB = C::NB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = wave >> 1, st = wave & 1;
@@ -155,7 +159,13 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     const int n = lane & 15, g = lane >> 4;
     const unsigned l4 = lane * 4, g4 = g * 4;
     unsigned *Xf = smem + fl * FACE_DW;
-    const int pix0 = 32 * (n >> 3) + (n & 7);           // pixel index of (block 0, lane column n); block r adds 8 r
+    // input pixel of (block b, lane column n).  Stride 1: y = b + 4 (n >> 3), x = n & 7.  Stride 2: the blocks are the four parity
+    // classes, b = 2 (y & 1) + (x & 1), and n = 4 (y >> 1) + (x >> 1) -- output pixel (oy, ox) = lane 4 oy + ox then takes its nine
+    // taps from its own lane (rows 2 oy, 2 oy + 1 / columns 2 ox, 2 ox + 1) and from lanes n - 4 (row 2 oy - 1), n - 1 (column 2 ox - 1)
+    // and n - 5: row_shr:4 | 1 | 5, zero fill = the top border, the filter's left column zeroed where ox = 0.
+    auto pix_in = [&](int b, int nn) __attribute__((always_inline)) {
+        return C::S2 ? 16 * (nn >> 2) + 8 * (b >> 1) + 2 * (nn & 3) + (b & 1) : 32 * (nn >> 3) + (nn & 7) + 8 * b;
+    };
 
     // ---- stage: block input of this face -> pre-split B fragments (this wave: blocks 2 st, 2 st + 1) ----
     if (FIRST) {
@@ -164,7 +174,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         for (int kc = 0; kc < KE; ++kc)
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const float *src = X + ((size_t)fc * 64 + pix0 + 8 * (2 * st + rr)) * CIN + 32 * kc + 8 * g;
+                const float *src = X + ((size_t)fc * 64 + pix_in(2 * st + rr, n)) * CIN + 32 * kc + 8 * g;
                 xv[kc][rr][0] = *(const f32x4 *)src;
                 xv[kc][rr][1] = *(const f32x4 *)(src + 4);
             }
@@ -184,12 +194,12 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[((kc * 4 + 2 * st + rr) * 2 + p) * 256 + lane * 4] = pc[p];
             }
     }
-    const float mL = (n & 7) != 0 ? 1.f : 0.f, mR = (n & 7) != 7 ? 1.f : 0.f;
-    f32x4 acc[MT][4];
+    const float mL = (C::S2 ? (n & 3) : (n & 7)) != 0 ? 1.f : 0.f, mR = (C::S2 || (n & 7) != 7) ? 1.f : 0.f;
+    f32x4 acc[MT][NB];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[mt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < NB; ++r) acc[mt][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // Per-group constants (depthwise filter and the two BN shifts of 32 channels, 1.4 KB) go through a private LDS buffer of the
     // wave: fetched (two 16-byte loads per lane) at the start of the previous group's project, written at its end -- an L2 round
@@ -254,12 +264,13 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         }
         SYNL_LAP(1);
         // ---- depthwise 3x3 + BN shift + ReLU6, split in place into the B operand of the project step ----
-        u32x4 Ap[C::PPF + 1][2];
+        constexpr int RING = C::S2 ? 4 : C::PPF + 1;   // project fragment slots (stride 2: output tiles go in pairs)
+        u32x4 Ap[RING][2];
         auto fetch_p = [&](int mt) __attribute__((always_inline)) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) Ap[mt % (C::PPF + 1)][p] = bload4(rs_p, l16, G * (MT * 2048) + (mt * 2 + p) * 1024);
+            for (int p = 0; p < 2; ++p) Ap[mt % RING][p] = bload4(rs_p, l16, G * (MT * 2048) + (mt * 2 + p) * 1024);
         };
-        u32x4 Bd[4][2];
+        u32x4 Bd[NB][2];
         // two channels (one packed K dword) at a time: 18 filter registers live instead of 36
 #pragma unroll
         for (int th = 0; th < 4; ++th) {
@@ -272,13 +283,28 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
             const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
-            f32x2 E[4], O[4];
+            f32x2 E[4], O[NB];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 E[r][0] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf], 0.0f, c6e);
                 E[r][1] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf + 1], 0.0f, c6e);
-                O[r] = dsh;
             }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) O[r] = dsh;
+            if constexpr (C::S2) {
+                // blocks E[2 py + px]; taps in the filter's own order (dy, dx), the shifted ones from the odd-row / odd-column classes
+                O[0] += dpp2<kRowShr5>(E[3]) * w[0];
+                O[0] += dpp2<kRowShr4>(E[2]) * w[1];
+                O[0] += dpp2<kRowShr4>(E[3]) * w[2];
+                asm volatile("" : "+v"(O[0]));
+                O[0] += dpp2<kRowShr1>(E[1]) * w[3];
+                O[0] += E[0] * w[4];
+                O[0] += E[1] * w[5];
+                asm volatile("" : "+v"(O[0]));
+                O[0] += dpp2<kRowShr1>(E[3]) * w[6];
+                O[0] += E[2] * w[7];
+                O[0] += E[3] * w[8];
+            } else {
             // input rows q = -1 .. 4 of the block rows (row q feeds outputs q - dy, dy = 0..2: ascending dy per output).  The pins
             // chain the rows: unchained arithmetic is otherwise scheduled all rows at once.
 #pragma unroll
@@ -297,8 +323,9 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                     asm volatile("" : "+v"(O[r]));
                 }
             }
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < NB; ++r) {
                 split2v(__builtin_amdgcn_fmed3f(O[r][0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[r][1], 0.0f, 96.0f), Bd[r], th);
                 if (hf) {
 #pragma unroll
@@ -316,12 +343,26 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 #pragma unroll
             for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
         }
+        if constexpr (C::S2) {
+            static_assert(!C::S2 || (C::PPF == 2 && MT % 2 == 0), "output tiles in pairs, two tiles fetched ahead");
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt + C::PPF < MT) fetch_p(mt + C::PPF);
-            mac3x4(Ap[mt % (C::PPF + 1)], Bd[0], acc[mt][0], Ap[mt % (C::PPF + 1)], Bd[1], acc[mt][1], Ap[mt % (C::PPF + 1)], Bd[2], acc[mt][2],
-                   Ap[mt % (C::PPF + 1)], Bd[3], acc[mt][3]);
-            SYNL_FENCE();
+            for (int mt = 0; mt < MT; mt += 2) {         // one 16-pixel block: two output tiles = two accumulator chains
+                if (mt + 2 < MT) { fetch_p(mt + 2); fetch_p(mt + 3); }
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[mt][0] = mfmal(Ap[mt % RING][PA[j]], Bd[0][PB[j]], acc[mt][0]);
+                    acc[mt + 1][0] = mfmal(Ap[(mt + 1) % RING][PA[j]], Bd[0][PB[j]], acc[mt + 1][0]);
+                }
+                SYNL_FENCE();
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt + C::PPF < MT) fetch_p(mt + C::PPF);
+                mac3x4(Ap[mt % RING], Bd[0], acc[mt][0], Ap[mt % RING], Bd[1], acc[mt][1], Ap[mt % RING], Bd[2], acc[mt][2], Ap[mt % RING], Bd[3], acc[mt][3]);
+                SYNL_FENCE();
+            }
         }
         if (more) {
             if (C::TLATE) fetch_t(G + C::NS);           // (no registers to carry the table through the project: an exposed L2 round trip per group)
@@ -334,18 +375,18 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     float *Red = reinterpret_cast<float *>(Xf);
     int le = lane;
     asm volatile("" : "+v"(le));                         // (output addresses are computed here, not carried through the loop)
-    const int ne = le & 15, ge = le >> 4, pixe = 32 * (ne >> 3) + (ne & 7);
+    const int ne = le & 15, ge = le >> 4, pixe = C::S2 ? ne : 32 * (ne >> 3) + (ne & 7);      // output pixel of (block 0, lane column ne); block r adds 8 r
     // residual and BN shift of this wave's tiles: requested before the barriers, consumed after them (an L2 round trip otherwise
     // stands between the second barrier and the stores).  Inside a chain the residual is what this wave stored one stage ago, into
     // a buffer this CU read two stages ago: the load goes past the vector cache (sc0: miss in the CU's cache, served by the XCD's L2, where the store landed).
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, 0x7fffffff, 0x00027000);
-    f32x4 rs[MT / 2][4], psh[MT / 2];
+    f32x4 rs[MT / 2][NB], psh[MT / 2];
 #pragma unroll
     for (int i = 0; i < MT / 2; ++i) {
         const int nch = 16 * (2 * i + st) + 4 * ge;
         psh[i] = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NB; ++r)
             if (C::RES) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
     }
     __syncthreads();                                     // every wave is done reading the fragments
@@ -353,42 +394,45 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) == st) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *(f32x4 *)&Red[(((st * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4] = acc[mt][r];
+        for (int r = 0; r < NB; ++r) *(f32x4 *)&Red[(((st * (MT / 2) + (mt >> 1)) * NB + r) * 64 + lane) * 4] = acc[mt][r];
     }
     __syncthreads();
     constexpr bool HANDOFF = !__is_same(CN, void);
-    f32x4 vout[MT / 2][4];
+    f32x4 vout[MT / 2][NB];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) != st) continue;
         const int nch = 16 * mt + 4 * ge;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x4 o = *(const f32x4 *)&Red[((((1 - st) * (MT / 2) + (mt >> 1)) * 4 + r) * 64 + lane) * 4];
+        for (int r = 0; r < NB; ++r) {
+            const f32x4 o = *(const f32x4 *)&Red[((((1 - st) * (MT / 2) + (mt >> 1)) * NB + r) * 64 + lane) * 4];
             f32x4 v = st == 0 ? acc[mt][r] + o : o + acc[mt][r];        // stream 0 + stream 1
             v = v * inv_p + psh[mt >> 1];
             if (C::RES) v += rs[mt >> 1][r];
-            if (real) *(f32x4 *)&Y[((size_t)f * 64 + pixe + 8 * r) * COUT + nch] = v;
+            if (STORE && real) *(f32x4 *)&Y[((size_t)f * C::PIXO + pixe + 8 * r) * COUT + nch] = v;
             if (HANDOFF) vout[mt >> 1][r] = v;
         }
     }
     if constexpr (HANDOFF) {
         // ---- hand the block output to the next stage: x 16, split, into the fragment layout of ITS expand GEMM.  This lane holds
         //      channels 16 mt + 4 ge .. + 3 of pixel (r, ne): k32 step mt >> 1, lane group 2 (mt & 1) + (ge >> 1), dwords 2 (ge & 1), + 1 ----
-        static_assert(CN::CIN == COUT, "the next block of the chain takes this block's output");
+        static_assert(CN::CIN == COUT && !C::S2, "the next block of the chain takes this block's output (8x8)");
         __syncthreads();                                 // everybody has read the exchange buffer (it aliases the fragments)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if ((mt & 1) != st) continue;
-            const int kc = mt >> 1, lsrc = (2 * (mt & 1) + (ge >> 1)) * 16 + ne, dw = 2 * (ge & 1);
+            const int kc = mt >> 1, lg = (2 * (mt & 1) + (ge >> 1)) * 16, dw = 2 * (ge & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const f32x4 v = real ? vout[mt >> 1][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
                 unsigned a0, b0, a1, b1;
                 split2h(v[0], v[1], a0, b0);
                 split2h(v[2], v[3], a1, b1);
-                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 0) * 256 + lsrc * 4 + dw] = (u32x2){a0, a1};
-                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 1) * 256 + lsrc * 4 + dw] = (u32x2){b0, b1};
+                // this lane's pixel (y = r + 4 (ne >> 3), x = ne & 7) in the next stage's pixel order (stride 2: parity classes)
+                const int bn = CN::S2 ? 2 * (r & 1) + (ne & 1) : r;
+                const int nn = CN::S2 ? 4 * ((r >> 1) + 2 * (ne >> 3)) + ((ne & 7) >> 1) : ne;
+                *(u32x2 *)&Xf[((kc * 4 + bn) * 2 + 0) * 256 + (lg + nn) * 4 + dw] = (u32x2){a0, a1};
+                *(u32x2 *)&Xf[((kc * 4 + bn) * 2 + 1) * 256 + (lg + nn) * 4 + dw] = (u32x2){b0, b1};
             }
         }
         // (the barrier after the next stage's prologue publishes the fragments)
@@ -412,13 +456,17 @@ void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nul
 using L8 = LbCfg<      64, 384,  64, true,  2, 2>;     // features.8-10
 using L11 = LbCfg<     64, 384,  96, false, 2, 2>;     // features.11
 using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
+using L14 = LbCfg<     96, 576, 160, false, 1, 2, 2, true>;   // features.14 (stride 2: 8x8 -> 4x4)
 
-// features.8 .. 13 of a face in ONE launch: 8, 9, 10 (64 -> 384 -> 64, residual), 11 (64 -> 384 -> 96), 12, 13 (96 -> 576 -> 96, residual)
-struct LbChainArgs { LbStageArgs s[6]; };
+// features.8 .. 14 of a face in ONE launch: 8, 9, 10 (64 -> 384 -> 64, residual), 11 (64 -> 384 -> 96), 12, 13 (96 -> 576 -> 96, residual),
+// 14 (96 -> 576 -> 160, stride 2; features.13's output then never goes to global memory).  WITH14 = false stops after features.13.
+struct LbChainArgs { LbStageArgs s[7]; };
 constexpr int kChainFaceDw = L12::FACE_DW > L8::FACE_DW ? (L12::FACE_DW > L11::FACE_DW ? L12::FACE_DW : L11::FACE_DW) : L8::FACE_DW;
+static_assert(L14::FACE_DW <= kChainFaceDw, "features.14 reuses the chain's fragment buffers");
 constexpr int kChainLdsDw = L8::FPW * kChainFaceDw + L8::NW * L8::TB_DW;
 static_assert(2 * kChainLdsDw * 4 <= 160 * 1024, "two workgroups per CU");
 
+template <bool WITH14>
 __global__ __launch_bounds__(L8::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
@@ -428,7 +476,11 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     lb_stage<L8, L11, false, false, kChainFaceDw>(smem, ca.s[2], B, pt_, tk);
     lb_stage<L11, L12, false, false, kChainFaceDw>(smem, ca.s[3], B, pt_, tk);
     lb_stage<L12, L12, false, false, kChainFaceDw>(smem, ca.s[4], B, pt_, tk);
-    lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[5], B, pt_, tk);
+    if constexpr (WITH14) {
+        lb_stage<L12, L14, false, false, kChainFaceDw, false>(smem, ca.s[5], B, pt_, tk);
+        lb_stage<L14, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
+    } else
+        lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[5], B, pt_, tk);
 }
 
 template <class C>
@@ -439,16 +491,23 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(sa, B);
 }
 
-// features.8-13 in one launch (a[i] = the arguments of features.(8 + i)); false: run them one by one
-bool launch_fused_chain_lb(const FusedBlockArgs (&a)[6], int B, hipStream_t s) {
-    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 1;
-    if (!chain || B < 768) return false;
+// features.8 .. 8 + n_blocks - 1 in one launch (a[i] = the arguments of features.(8 + i), n_blocks = 6 | 7); false: run them one by one
+int lb_chain_blocks(int B) {
+    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 2;      // 0: off, 1: features.8-13, 2: features.8-14
+    if (!chain || B < 768) return 0;
+    return chain >= 2 ? 7 : 6;
+}
+bool launch_fused_chain_lb(const FusedBlockArgs *a, int n_blocks, int B, hipStream_t s) {
+    if (n_blocks != 6 && n_blocks != 7) return false;
     LbChainArgs ca;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < n_blocks; ++i) {
         if (!a[i].Alb_e || !a[i].Alb_p || !a[i].Tlb || a[i].prof) return false;
         ca.s[i] = LbStageArgs{a[i].X, a[i].Alb_e, a[i].Tlb, a[i].Alb_p, a[i].p_shift, a[i].Y};
     }
-    fused_chain_lb_kernel<<<(B + L8::FPW - 1) / L8::FPW, L8::NT, 0, s>>>(ca, B);
+    if (n_blocks == 6) ca.s[6] = ca.s[5];
+    const int grid = (B + L8::FPW - 1) / L8::FPW;
+    if (n_blocks == 7) fused_chain_lb_kernel<true><<<grid, L8::NT, 0, s>>>(ca, B);
+    else fused_chain_lb_kernel<false><<<grid, L8::NT, 0, s>>>(ca, B);
     return true;
 }
 
@@ -467,6 +526,7 @@ bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStrea
         case 8: case 9: case 10: launch_lb<L8>(a, B, s); return true;
         case 11: launch_lb<L11>(a, B, s); return true;
         case 12: case 13: launch_lb<L12>(a, B, s); return true;
+        case 14: launch_lb<L14>(a, B, s); return true;
         default: return false;
     }
 }
