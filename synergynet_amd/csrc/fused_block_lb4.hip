@@ -22,12 +22,14 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -81,12 +83,39 @@ struct Lb4Cfg {
 // Workgroup = 4 faces x 2 waves: wave (face, t) owns hidden tile t (16 of the group's 32 channels) through expand and depthwise,
 // hands its half of the project operand to its partner through LDS, and accumulates half of the output tiles.  Two waves per SIMD
 // issue vector instructions at 2.4 cycles each instead of a lone wave's 5 (the depthwise is the larger part of a group).
-template <class C>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_block_lb4_kernel(const float *__restrict__ X, const unsigned *__restrict__ Glb /*[NG][NKB][64][4]: We | Wp | table per group*/,
-                            const float *__restrict__ p_shift, float *__restrict__ Y, int B) {
-    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+//
+// One block = one STAGE; features.15-17 run as a chain of three stages in one launch (fused_chain_lb4_kernel): the block output goes
+// to the next stage as pre-split fragments through the weight buffer half the last group has just left, the residual of the next block
+// stays in the accumulator's registers, and the next stage's first weight group is fetched during the last group of this one --
+// no kernel boundary (10-16 us each), no global round trip of the 4x4 activations.
+struct Lb4NoNext { static constexpr int NKB = 0; };
+struct Lb4StageArgs {
+    const float *X;          // block input (global): a FIRST stage's input and residual
+    const unsigned *Glb;     // [NG][NKB][64][4]: We | Wp | table per group
+    const float *p_shift;
+    float *Y;                // block output (global): written by the last stage only
+};
+
+template <int N>
+__device__ __forceinline__ void lb4_fetch(u32x4 *pf, const unsigned *src /* + 4 lane */, int wave) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) pf[i] = *(const u32x4 *)(src + (wave + 8 * i) * 256);
+}
+template <int N>
+__device__ __forceinline__ void lb4_park(const u32x4 *pf, unsigned *dst /* + 4 lane */, int wave) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) *(u32x4 *)&dst[(wave + 8 * i) * 256] = pf[i];
+}
+
+// GRPL: dwords per half of the LDS weight double buffer (>= the group run of every stage of the kernel)
+template <class C, class CN, bool FIRST, int GRPL>
+__device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa, const unsigned *GlbNext, int B, u32x4 (&Xr)[5][2], f32x4 (&vres)[5]) {
     constexpr int KE = C::KE, MTW = C::MTW, CIN = C::CIN, COUT = C::COUT;
+    constexpr bool HANDOFF = !__is_same(CN, void);
+    static_assert(KE == 5 && C::NG % 2 == 0, "160 input channels; the double buffer's parity carries over to the next stage");
+    const float *__restrict__ X = sa.X, *__restrict__ p_shift = sa.p_shift;
+    const unsigned *__restrict__ Glb = sa.Glb;
+    float *__restrict__ Y = sa.Y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = wave >> 1, t = wave & 1;
@@ -95,27 +124,18 @@ void fused_block_lb4_kernel(const float *__restrict__ X, const unsigned *__restr
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
     const unsigned l4 = lane * 4, g4 = g * 4;
-    unsigned *Xch = smem + 2 * C::GRP_DW;
+    unsigned *Xch = smem + 2 * GRPL;
 
     // every wave copies every eighth 1 KB piece of a group's run through registers: fetched at the start of the previous group,
     // written to the other half of the double buffer at its end.  (LDS-DMA -- global_load_lds_dwordx4, no registers -- delivers
     // ~25 GB/s per CU whoever issues it: 44 KB per group took 1.8 us, longer than the group's arithmetic.)
     constexpr int NPW = C::NKB / 8;
-    u32x4 pf[NPW];
-    auto fetch = [&](int G) __attribute__((always_inline)) {
-        const unsigned *src = Glb + (size_t)G * C::GRP_DW + l4;
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) pf[i] = *(const u32x4 *)(src + (wave + 8 * i) * 256);
-    };
-    auto park = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) *(u32x4 *)&smem[buf * C::GRP_DW + (wave + 8 * i) * 256 + l4] = pf[i];
-    };
-    fetch(0);
-
-    // ---- block input of this face -> pre-split B fragments in registers (x 16; both waves of the face hold it) ----
-    u32x4 Xr[KE][2];
-    {
+    using CNX = typename std::conditional<HANDOFF, CN, Lb4NoNext>::type;
+    constexpr int NPWN = CNX::NKB / 8;
+    u32x4 pf[NPW > NPWN ? NPW : NPWN];
+    if (FIRST) {
+        lb4_fetch<NPW>(pf, Glb + l4, wave);
+        // ---- block input of this face -> pre-split B fragments in registers (x 16; both waves of the face hold it) ----
         f32x4 xv[KE][2];
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc) {
@@ -138,12 +158,13 @@ void fused_block_lb4_kernel(const float *__restrict__ X, const unsigned *__restr
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float c6e = 0.f, inv_p = 0.f;
-    park(0);
+    if (FIRST) lb4_park<NPW>(pf, smem + l4, wave);
 
     for (int G = 0; G < C::NG; ++G) {
         __syncthreads();                                 // every wave has written its pieces of group G and is done with group G-1
-        if (G + 1 < C::NG) fetch(G + 1);
-        const unsigned *We = smem + (G & 1) * C::GRP_DW, *Wp = We + C::WE_DW;
+        if (G + 1 < C::NG) lb4_fetch<NPW>(pf, Glb + (size_t)(G + 1) * C::GRP_DW + l4, wave);
+        else if (HANDOFF) lb4_fetch<NPWN>(pf, GlbNext + l4, wave);          // the next block's first group
+        const unsigned *We = smem + (G & 1) * GRPL, *Wp = We + C::WE_DW;
         const float *Tb = reinterpret_cast<const float *>(Wp + C::WP_DW);
         if (G == 0) { c6e = Tb[11 * 32]; inv_p = Tb[11 * 32 + 1]; }
         // fragments of this wave: its hidden tile's expand fragments and its output tiles' project fragments, read up front
@@ -218,33 +239,104 @@ void fused_block_lb4_kernel(const float *__restrict__ X, const unsigned *__restr
             acc[i] = mfmaq(Ap[i][0], Bd[1], acc[i]);
             acc[i] = mfmaq(Ap[i][0], Bd[0], acc[i]);
         }
-        if (G + 1 < C::NG) park((G + 1) & 1);
+        if (G + 1 < C::NG) lb4_park<NPW>(pf, smem + ((G + 1) & 1) * GRPL + l4, wave);
+        else if (HANDOFF) lb4_park<NPWN>(pf, smem + l4, wave);               // (NG is even: the next block starts in half 0 again)
     }
 
-    // ---- rescale, BN shift, residual, NHWC store: lane (n, g) holds channels 16 mt + 4 g .. + 3 of pixel n ----
-    if (!real) return;
+    // ---- rescale, BN shift, residual: lane (n, g) holds channels 16 mt + 4 g .. + 3 of pixel n.  The last stage stores NHWC; the
+    //      others keep the result as the next block's residual and hand it over as B fragments ----
+    f32x4 vout[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         const int nch = 16 * (t * MTW + i) + g4;
-        const size_t at = ((size_t)f * 16 + n) * COUT + nch;
+        const size_t at = ((size_t)fc * 16 + n) * COUT + nch;
         f32x4 v = acc[i] * inv_p + *(const f32x4 *)&p_shift[nch];
-        if (C::RES) v += *(const f32x4 *)&X[at];
-        *(f32x4 *)&Y[at] = v;
+        if constexpr (C::RES) {
+            if (FIRST) v += *(const f32x4 *)&X[at];
+            else v += vres[i];
+        }
+        if (!HANDOFF && real) *(f32x4 *)&Y[at] = v;
+        vout[i] = v;
+    }
+    if constexpr (HANDOFF) {
+        static_assert(CN::CIN == COUT && MTW == 5, "the next block takes this block's output: five output tiles per wave");
+        unsigned *HO = smem + GRPL;                      // half 1: the last group's weights, no longer read once every wave is here
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            vres[i] = vout[i];
+            // channels 16 mt + 4 g .. + 3 of pixel n: k32 step mt >> 1, lane group 2 (mt & 1) + (g >> 1), dwords 2 (g & 1), + 1
+            const int mt = t * MTW + i, kc = mt >> 1, lt = (2 * (mt & 1) + (g >> 1)) * 16 + n, dw = 2 * (g & 1);
+            const f32x4 v = real ? vout[i] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+            unsigned a0, b0, a1, b1;
+            split2q(v[0], v[1], a0, b0);
+            split2q(v[2], v[3], a1, b1);
+            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 0) * 256 + lt * 4 + dw] = (u32x2){a0, a1};
+            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 1) * 256 + lt * 4 + dw] = (u32x2){b0, b1};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < KE; ++kc)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Xr[kc][p] = *(const u32x4 *)&HO[((fl * KE + kc) * 2 + p) * 256 + l4];
+        // (half 1 is rewritten at the end of the next block's first group, two barriers from here)
     }
 }
 
 template <class C>
-static void launch_lb4(const FusedBlockArgs &a, int B, hipStream_t s) {
-    fused_block_lb4_kernel<C><<<(B + 3) / 4, 512, 0, s>>>(a.X, a.Glb, a.p_shift, a.Y, B);
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_block_lb4_kernel(Lb4StageArgs sa, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    u32x4 Xr[5][2];
+    f32x4 vres[5];
+    lb4_stage<C, void, true, C::GRP_DW>(smem, sa, nullptr, B, Xr, vres);
 }
 
 using Q15 = Lb4Cfg<160, 960, 160, true>;      // features.15, 16
 using Q17 = Lb4Cfg<160, 960, 320, false>;     // features.17
 
+// features.15, 16, 17 of four faces in one launch
+constexpr int kChain4Grp = Q17::GRP_DW > Q15::GRP_DW ? Q17::GRP_DW : Q15::GRP_DW;
+constexpr int kChain4LdsDw = 2 * kChain4Grp + Q15::XCH_DW;
+static_assert(kChain4LdsDw * 4 <= 160 * 1024 && 4 * 5 * 2 * 256 <= kChain4Grp, "LDS budget; the handed-over fragments of four faces fit one buffer half");
+struct Lb4ChainArgs { Lb4StageArgs s[3]; };
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_chain_lb4_kernel(Lb4ChainArgs ca, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChain4LdsDw];
+    u32x4 Xr[5][2];
+    f32x4 vres[5];
+    lb4_stage<Q15, Q15, true, kChain4Grp>(smem, ca.s[0], ca.s[1].Glb, B, Xr, vres);
+    lb4_stage<Q15, Q17, false, kChain4Grp>(smem, ca.s[1], ca.s[2].Glb, B, Xr, vres);
+    lb4_stage<Q17, void, false, kChain4Grp>(smem, ca.s[2], nullptr, B, Xr, vres);
+}
+
+template <class C>
+static void launch_lb4(const FusedBlockArgs &a, int B, hipStream_t s) {
+    fused_block_lb4_kernel<C><<<(B + 3) / 4, 512, 0, s>>>(Lb4StageArgs{a.X, a.Glb, a.p_shift, a.Y}, B);
+}
+
+static int lb4_min_batch() {
+    static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 768;     // fewer faces: not enough workgroups of four
+    return min_b;
+}
+
+// a[i] = the arguments of features.(15 + i); false: launch them one by one
+bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
+    static const int chain = getenv("SYN_LB4_CHAIN") ? atoi(getenv("SYN_LB4_CHAIN")) : 1;
+    if (!chain || B < lb4_min_batch()) return false;
+    Lb4ChainArgs ca;
+    for (int i = 0; i < 3; ++i) {
+        if (!a[i].Glb || a[i].prof) return false;
+        ca.s[i] = Lb4StageArgs{a[i].X, a[i].Glb, a[i].p_shift, a[i].Y};
+    }
+    fused_chain_lb4_kernel<<<(B + 3) / 4, 512, 0, s>>>(ca, B);
+    return true;
+}
+
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Glb || a.prof) return false;
-    static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 768;     // fewer faces: not enough workgroups of four
-    if (B < min_b) return false;
+    if (B < lb4_min_batch()) return false;
     switch (feature) {
         case 15: case 16: launch_lb4<Q15>(a, B, s); return true;
         case 17: launch_lb4<Q17>(a, B, s); return true;

@@ -88,6 +88,8 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int n_blocks, int B, hipStre
 // [out tile][piece 2][64][4] | Tlb rows [12][32] floats + 128 floats of padding  -- what one LDS-DMA burst copies.
 constexpr int lb4_group_dwords(int cin, int cout) { return (2 * (cin / 32) * 512 + (cout / 16) * 512 + 512 + 2047) / 2048 * 2048; }     // padded to 8 KB
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+// features.15-17 of every face in ONE launch (a[i]: features.(15 + i)); false = not applicable, launch them one by one
+bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
 bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 

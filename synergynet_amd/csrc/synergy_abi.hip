@@ -494,6 +494,31 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 continue;
             }
         }
+        // features.15-17 as one chain launch (fused_block_lb4.hip); only features.17's output goes to global memory
+        if (h->fusion >= 2 && L.kind == PW && L.relu6 && L.feature == 15 && L.dst_glb && (h->early_rm & 256) && (h->early_rm & 512) && prof_feature < 0 &&
+            (stop_feature < 0 || stop_feature >= 17) && li + 9 <= nl) {
+            syn::FusedBlockArgs ca[3];
+            bool ok = true;
+            for (int i = 0; i < 3 && ok; ++i) {
+                const Layer &E = n.layers[li + 3 * i], &Dw = n.layers[li + 3 * i + 1], &Pr = n.layers[li + 3 * i + 2];
+                ok = E.kind == PW && E.relu6 && E.feature == 15 + i && E.dst_glb;
+                if (!ok) break;
+                ca[i] = syn::FusedBlockArgs{X, P + E.dst_wpk, P + E.dst_scale, P + E.dst_shift, P + Dw.dst_wpk, P + Dw.dst_scale, P + Dw.dst_shift,
+                                            P + Pr.dst_wpk, P + Pr.dst_scale, P + Pr.dst_shift, Y};
+                ca[i].Glb = reinterpret_cast<const unsigned *>(P + E.dst_glb);
+            }
+            if (ok && syn::launch_fused_chain_lb4(ca, B, s)) {
+                li += 8;
+                { float *t = X; X = Y; Y = t; }
+                mark(1517);
+                if (stop_feature == 17) {
+                    const Layer &Lp = n.layers[li];
+                    HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                    return SYN_OK;
+                }
+                continue;
+            }
+        }
         // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
         if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];

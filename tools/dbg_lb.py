@@ -1,4 +1,4 @@
-"""GPU box: features.7-13 of the default schedule against the all-tiled schedule (SYNERGY_HIP_EARLY_RM=0) at B faces."""
+"""GPU box: features.7-17 of the default schedule against the all-tiled schedule (SYNERGY_HIP_EARLY_RM=0) at B faces."""
 import os
 import sys
 
@@ -16,7 +16,7 @@ m1 = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd)
 os.environ['SYNERGY_HIP_EARLY_RM'] = '0'
 m0 = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd)
 x = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=5))).cuda()
-shapes = {7: (8, 64), 8: (8, 64), 9: (8, 64), 10: (8, 64), 11: (8, 96), 12: (8, 96), 13: (8, 96), 14: (4, 160)}
+shapes = {7: (8, 64), 8: (8, 64), 9: (8, 64), 10: (8, 64), 11: (8, 96), 12: (8, 96), 13: (8, 96), 14: (4, 160), 15: (4, 160), 16: (4, 160), 17: (4, 320)}
 for f, (h, c) in shapes.items():
     a = torch.empty((B, h, h, c), dtype=torch.float32, device='cuda')
     b = torch.empty_like(a)
