@@ -177,11 +177,11 @@ __device__ __forceinline__ f32x4 mfma_h(u32x4 a, u32x4 b, f32x4 c) {
 }
 }  // namespace
 
-// The 62 head rows of NF faces whose pooled 1280-vectors are in `xv`: wave w computes outputs w + 4 * (rbase + r), r < NR;
+// The 62 head rows of NFK faces whose pooled 1280-vectors are in `xv`: wave w of NWV computes outputs w + NWV * (rbase + r), r < NR;
 // the next row's weights are fetched while the current one is reduced.  One function for the fused and the sliced tail,
 // so a parameter is produced by the same instruction sequence at every batch size.
-template <int NR>
-__device__ __forceinline__ void fc_rows(const f32x4 (&xv)[NF][N / 256], const float *__restrict__ Wfc, const float *__restrict__ bfc,
+template <int NR, int NFK = NF, int NWV = 4>
+__device__ __forceinline__ void fc_rows(const f32x4 (&xv)[NFK][N / 256], const float *__restrict__ Wfc, const float *__restrict__ bfc,
                                         float *__restrict__ param, int f0, int B, int rbase, int wave, int lane) {
     f32x4 wq[2][N / 256];
     auto ldw = [&](int o, f32x4(&w)[N / 256]) {
@@ -189,16 +189,16 @@ __device__ __forceinline__ void fc_rows(const f32x4 (&xv)[NF][N / 256], const fl
 #pragma unroll
         for (int i = 0; i < N / 256; ++i) w[i] = *(const f32x4 *)&wr[(i * 64 + lane) * 4];
     };
-    ldw(wave + 4 * rbase, wq[0]);
+    ldw(wave + NWV * rbase, wq[0]);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int o = wave + 4 * (rbase + r);
-        if (r + 1 < NR) ldw(o + 4, wq[(r + 1) & 1]);
+        const int o = wave + NWV * (rbase + r);
+        if (r + 1 < NR) ldw(o + NWV, wq[(r + 1) & 1]);
         if (o >= kParam) continue;
         const f32x4(&wv)[N / 256] = wq[r & 1];
         const float bo = bfc[o];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NFK; ++j) {
             float a = 0.f;
 #pragma unroll
             for (int i = 0; i < N / 256; ++i)
@@ -213,20 +213,25 @@ constexpr int kFcRounds = (kParam + 3) / 4;      // 16 rounds of 4 rows
 
 // NS > 1 (few faces): blockIdx.y owns NTL / NS of the 80 output-channel tiles, the pooled slice goes to `pool` in HBM and
 // head_fc_kernel finishes; NS == 1: the whole tail in this launch.
-template <int NS>
-__global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
+// NFK faces and NWV waves per workgroup: 2 x 4 (two workgroups per CU) for small and medium batches; 4 x 8 once the batch fills the
+// chip with four faces per CU -- every workgroup streams the 1.6 MB of weight fragments from L2, so four faces per workgroup halve
+// that traffic (0.84 -> 0.42 GB per launch at B = 1024), and eight waves keep two per SIMD (four faces on FOUR waves measured
+// slower than two: 74 vs 65 us).  The per-output arithmetic is the same in every configuration.
+template <int NS, int NFK = NF, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
                                                           const unsigned *__restrict__ Wb3 /*[80][10][2][64][4] dwords, {S, 1/S}*/,
                                                           const float *__restrict__ shift, const float *__restrict__ Wfc,
                                                           const float *__restrict__ bfc, float *__restrict__ param,
                                                           float *__restrict__ pool, int B) {
-    __shared__ __attribute__((aligned(16))) unsigned Xb[2 * PLANE];
-    __shared__ __attribute__((aligned(16))) float Ps[NF * N];
+    constexpr int PXK = NFK * 16, PLANEK = PXK * XSD, NT = NWV * 64;
+    __shared__ __attribute__((aligned(16))) unsigned Xb[2 * PLANEK];
+    __shared__ __attribute__((aligned(16))) float Ps[NFK * N];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int f0 = blockIdx.x * NF;
+    const int f0 = blockIdx.x * NFK;
     const float S = __builtin_bit_cast(float, Wb3[80 * 10 * 2 * 256]), inv_s = __builtin_bit_cast(float, Wb3[80 * 10 * 2 * 256 + 1]);
     constexpr int NTS = NTL / NS;
-    static_assert(NTL % NS == 0 && NTS % 4 == 0, "whole rounds of 4 waves per slice");
+    static_assert(NTL % NS == 0 && NTS % NWV == 0, "whole rounds of the waves per slice");
     const int nt0 = NS > 1 ? (int)blockIdx.y * NTS : 0, nt_end = nt0 + NTS;
 
     u32x4 ring[5][2];                                   // weight pieces of 5 k-chunks in flight
@@ -241,12 +246,12 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     // issued before the first is consumed, branch-free (face index clamped, value zeroed afterwards): as a plain loop with
     // `if (f < B)` around the load it compiled to ten serialised load -> s_waitcnt vmcnt(0) -> split round trips.
     {
-        constexpr int XI = PX * (K / 4) / 256;
-        static_assert(PX * (K / 4) % 256 == 0, "whole rounds");
+        constexpr int XI = PXK * (K / 4) / NT;
+        static_assert(PXK * (K / 4) % NT == 0, "whole rounds");
         f32x4 xv[XI];
 #pragma unroll
         for (int ii = 0; ii < XI; ++ii) {
-            const int it = tid + ii * 256, c4 = it % (K / 4), p = it / (K / 4);
+            const int it = tid + ii * NT, c4 = it % (K / 4), p = it / (K / 4);
             int f = f0 + (p >> 4);
             f = f < B ? f : B - 1;
             xv[ii] = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
@@ -255,49 +260,49 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
         for (int ii = 0; ii < XI; ++ii) asm volatile("" : "+v"(xv[ii]));        // (keeps the loads from being sunk to their uses)
 #pragma unroll
         for (int ii = 0; ii < XI; ++ii) {
-            const int it = tid + ii * 256, c4 = it % (K / 4), p = it / (K / 4);
+            const int it = tid + ii * NT, c4 = it % (K / 4), p = it / (K / 4);
             const f32x4 v = f0 + (p >> 4) < B ? xv[ii] : (f32x4){0.f, 0.f, 0.f, 0.f};
             unsigned a0, b0, a1, b1;
             split2(v[0], v[1], a0, b0);
             split2(v[2], v[3], a1, b1);
-            *(u32x2 *)&Xb[0 * PLANE + p * XSD + 2 * c4] = (u32x2){a0, a1};
-            *(u32x2 *)&Xb[1 * PLANE + p * XSD + 2 * c4] = (u32x2){b0, b1};
+            *(u32x2 *)&Xb[0 * PLANEK + p * XSD + 2 * c4] = (u32x2){a0, a1};
+            *(u32x2 *)&Xb[1 * PLANEK + p * XSD + 2 * c4] = (u32x2){b0, b1};
         }
     }
     __syncthreads();
 
-    for (int nt = nt0 + wave; nt < nt_end; nt += 4) {
+    for (int nt = nt0 + wave; nt < nt_end; nt += NWV) {
         const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g] * S;
-        f32x4 acc[NF];
+        f32x4 acc[NFK];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[j] = sh;
-        u32x4 bq[2][NF][2];                             // pixel operands of the current / next k-chunk (ping-pong, no copies)
-        auto ldb = [&](int kc, u32x4(&b)[NF][2]) {
+        for (int j = 0; j < NFK; ++j) acc[j] = sh;
+        u32x4 bq[2][NFK][2];                            // pixel operands of the current / next k-chunk (ping-pong, no copies)
+        auto ldb = [&](int kc, u32x4(&b)[NFK][2]) {
 #pragma unroll
-            for (int j = 0; j < NF; ++j)
+            for (int j = 0; j < NFK; ++j)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANE + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
+                for (int p = 0; p < 2; ++p) b[j][p] = *(const u32x4 *)&Xb[p * PLANEK + (j * 16 + r16) * XSD + kc * 16 + 4 * g];
         };
         ldb(0, bq[0]);
 #pragma unroll
         for (int kc = 0; kc < KC32; ++kc) {
             if (kc + 1 < KC32) ldb(kc + 1, bq[(kc + 1) & 1]);
-            const u32x4(&bc)[NF][2] = bq[kc & 1];
+            const u32x4(&bc)[NFK][2] = bq[kc & 1];
             const u32x4 aa = ring[kc % 5][0], ab = ring[kc % 5][1];
-            // three partial products, smallest first; NF independent accumulators interleaved
+            // three partial products, smallest first; NFK independent accumulators interleaved
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(ab, bc[j][0], acc[j]);
+            for (int j = 0; j < NFK; ++j) acc[j] = mfma_h(ab, bc[j][0], acc[j]);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(aa, bc[j][1], acc[j]);
+            for (int j = 0; j < NFK; ++j) acc[j] = mfma_h(aa, bc[j][1], acc[j]);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[j] = mfma_h(aa, bc[j][0], acc[j]);
+            for (int j = 0; j < NFK; ++j) acc[j] = mfma_h(aa, bc[j][0], acc[j]);
             // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
             if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
-            else if (nt + 4 < nt_end) lda(nt + 4, kc + 5 - KC32, ring[kc % 5]);
+            else if (nt + NWV < nt_end) lda(nt + NWV, kc + 5 - KC32, ring[kc % 5]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NFK; ++j) {
             f32x4 v;
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = row16_sum(r6h(acc[j][t] * inv_s));
@@ -306,24 +311,24 @@ __global__ __launch_bounds__(256) void head_bf16x3_kernel(const float *__restric
     }
     __syncthreads();
     if (NS > 1) {                                          // this slice of the pooled vectors -> HBM
-        for (int it = tid; it < NF * (NTS * 4); it += 256) {
+        for (int it = tid; it < NFK * (NTS * 4); it += NT) {
             const int j = it / (NTS * 4), c4 = nt0 * 4 + it % (NTS * 4);
             if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
         }
         return;
     }
     if (pool) {
-        for (int it = tid; it < NF * (N / 4); it += 256) {
+        for (int it = tid; it < NFK * (N / 4); it += NT) {
             const int j = it / (N / 4), c4 = it % (N / 4);
             if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
         }
     }
-    f32x4 xv[NF][N / 256];
+    f32x4 xv[NFK][N / 256];
 #pragma unroll
-    for (int j = 0; j < NF; ++j)
+    for (int j = 0; j < NFK; ++j)
 #pragma unroll
         for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
-    fc_rows<kFcRounds>(xv, Wfc, bfc, param, f0, B, 0, wave, lane);
+    fc_rows<(kParam + NWV - 1) / NWV, NFK, NWV>(xv, Wfc, bfc, param, f0, B, 0, wave, lane);
 }
 
 // second half of the sliced tail: blockIdx.y owns 4 of the 16 rounds of head rows
@@ -350,6 +355,11 @@ void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift,
         float *pl = pool ? pool : scratch;
         head_bf16x3_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
         head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);
+        return;
+    }
+    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 1024;      // four faces per CU from here on
+    if (B >= wide_min) {
+        head_bf16x3_kernel<1, 4, 8><<<(B + 3) / 4, 512, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
         return;
     }
     head_bf16x3_kernel<1><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
