@@ -526,3 +526,40 @@ def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
     p = model.forward_crops_u8(np.stack(crops))
     want = model.reconstruct(p, roi=np.asarray(rois, np.float32), dense=False).cpu().numpy()
     assert np.array_equal(np.stack(lm), want)
+
+
+_VARIANT_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from synergynet_amd import synth
+from synergynet_amd.synergy3DMM import SynergyNet
+B, s_bb, s_3d = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(s_3d), backbone_state=synth.make_backbone_state(s_bb))
+crops = torch.from_numpy(synth.make_crops(B, seed=4242)).cuda()
+np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
+'''
+
+
+@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'}],
+                         ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
+def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs):
+    """features.8-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
+    the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
+    faces per workgroup (head_kernel.hip).  Every one of these is a schedule change only: with the chain off (one launch per
+    block), with the shorter features.8-13 chain, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
+    read once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    import torch
+    from synergynet_amd import synth
+    if model._test_fusion != '2':
+        pytest.skip('the chains belong to the default schedule')
+    B = 1030
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'p.npy')
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT, root, out, str(B), str(int(golden['seeds'][0])), str(int(golden['seeds'][1]))],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = model.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4242)).cuda()).cpu().numpy()
+    assert np.array_equal(np.load(out), got)
