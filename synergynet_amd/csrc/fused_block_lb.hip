@@ -440,6 +440,259 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     SYNL_LAP(4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// features.7 (32 -> 192 -> 64, stride 2, 15x15 -> 8x8): the block in front of the chain, on the same machinery.
+//
+//   * the 15x15 input is padded to 16x16 and cut into its four parity classes c = 2 (y & 1) + (x & 1), each an 8x8 image over
+//     (i, j) = (y >> 1, x >> 1) = four 16-column blocks b with lane column n <-> (i = 2 b + (n >> 3), j = n & 7).  Output pixel
+//     (oy, ox), block ob = oy >> 1 in the same lane layout, then takes its taps from its OWN lane of the classes (rows 2 oy, 2 oy + 1 /
+//     columns 2 ox, 2 ox + 1), from lane n - 1 (column 2 ox - 1: row_shr:1, filter column zeroed at ox = 0) and from the class row above
+//     (row 2 oy - 1): lanes 8-15 of a block find it in lanes 0-7 of the same block (row_shr:8), lanes 0-7 in lanes 8-15 of the block
+//     before (row_shl:8) -- both zero-filling, so the two shifted values simply add;
+//   * the padding row / column 15 must be ZERO after expand + ReLU6: those lanes get a ReLU6 ceiling of 0 (v_med3);
+//   * the two waves of a face split the OUTPUT (wave st: output rows 4 st .. 4 st + 3 = blocks 2 st, 2 st + 1) and walk all six hidden
+//     groups: nothing to exchange at the end, each wave stores / hands over its half.  Wave 1 also expands block 1 of the two odd-row
+//     classes (the row above its first output row): 10 instead of 8 blocks per group.
+struct L7 {
+    static constexpr int CIN = 32, HID = 192, COUT = 64, NG = 6, MT = 4, H = 15, HO = 8;
+    static constexpr int FPW = 2, NW = 4, NT = 256;
+    static constexpr int XF_DW = 16 * 2 * 256;           // [class 4][block 4][piece 2][lane 64][4 dwords]
+    static constexpr int TB_DW = 12 * 32;
+    static constexpr int FACE_DW = XF_DW;
+    static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
+};
+
+template <class CN, bool PROF, int FACE_DW>
+__device__ __forceinline__ void lb7_stage(unsigned *smem, const LbStageArgs &sa, int B, unsigned long long (&pt_)[5], unsigned long long &tk) {
+    unsigned long long tn = 0;
+    const float *__restrict__ X = sa.X;
+    const float *__restrict__ Tlb = sa.Tlb, *__restrict__ p_shift = sa.p_shift;
+    float *__restrict__ Y = sa.Y;
+    constexpr int MT = L7::MT, CIN = L7::CIN, COUT = L7::COUT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fl = wave >> 1, st = wave & 1;
+    const int f = blockIdx.x * L7::FPW + fl;
+    const bool real = f < B;
+    const int fc = real ? f : B - 1;
+    const int n = lane & 15, g = lane >> 4;
+    const unsigned l4 = lane * 4, g4 = g * 4;
+    unsigned *Xf = smem + fl * FACE_DW;
+
+    // ---- stage: the 16 class blocks of this face as pre-split B fragments (x 16); wave st converts the classes of row parity st ----
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {                     // column parity px = hb
+        f32x4 xv[4][2];
+        bool ok[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int y = 2 * (2 * b + (n >> 3)) + st, x = 2 * (n & 7) + hb;
+            ok[b] = real && y < L7::H && x < L7::H;
+            const float *src = X + ((size_t)fc * (L7::H * L7::H) + (ok[b] ? y * L7::H + x : 0)) * CIN + 8 * g;
+            xv[b][0] = *(const f32x4 *)src;
+            xv[b][1] = *(const f32x4 *)(src + 4);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 a = xv[b][0], c = xv[b][1];
+            if (!ok[b]) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; c = a; }
+            a *= 16.0f; c *= 16.0f;
+            u32x4 pc[2];
+            split2v(a[0], a[1], pc, 0);
+            split2v(a[2], a[3], pc, 1);
+            split2v(c[0], c[1], pc, 2);
+            split2v(c[2], c[3], pc, 3);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[((((2 * st + hb) * 4 + b) * 2) + p) * 256 + lane * 4] = pc[p];
+        }
+    }
+    const float mL = (n & 7) != 0 ? 1.f : 0.f;
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[mt][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float *Tb = reinterpret_cast<float *>(smem + L7::FPW * FACE_DW + wave * L7::TB_DW);
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(sa.Weh), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(sa.Wlb), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Tlb), 0, 0x7fffffff, 0x00027000);
+    const unsigned l16 = lane * 16;
+    f32x4 tv[2];
+    auto fetch_t = [&](int G) __attribute__((always_inline)) {
+        tv[0] = bload4f(rs_t, l16, G * (L7::TB_DW * 4));
+        tv[1] = bload4f(rs_t, l16 & 511, G * (L7::TB_DW * 4) + 1024);
+    };
+    auto park_t = [&]() __attribute__((always_inline)) {
+        *(f32x4 *)&Tb[l4] = tv[0];
+        *(f32x4 *)&Tb[256 + (l4 & 127)] = tv[1];
+    };
+    const float c6e = Tlb[11 * 32], inv_p = Tlb[11 * 32 + 1];
+    // ReLU6 ceilings: 0 on the lanes that are padding (column 15 = odd-column classes, j = 7; row 15 = odd-row classes, block 3, i = 7)
+    const float cJ = (n & 7) != 7 ? c6e : 0.f;
+    const float cR0 = (st == 1 && n >= 8) ? 0.f : c6e, cR1 = (st == 1 && n >= 8) ? 0.f : cJ;    // second own block of the odd-row classes
+    u32x4 Ae[2][2];
+    auto fetch_e = [&](int G) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Ae[t][p] = bload4(rs_e, l16, G * 4096 + (t * 2 + p) * 1024);
+    };
+    fetch_t(0);
+    fetch_e(0);
+    park_t();
+    __syncthreads();
+    SYNL_LAP(0);
+
+    for (int G = 0; G < L7::NG; ++G) {
+        // ---- expand: D[t][class][k]: own blocks b = 2 st + k (k = 0, 1); k = 2 (wave 1, odd-row classes): block 1 ----
+        f32x4 D[2][4][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 es = *(const f32x4 *)&Tb[10 * 32 + 16 * t + g4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) D[t][c][k] = es;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x4 Bx[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) Bx[k][p] = *(const u32x4 *)&Xf[(((c * 4 + 2 * st + k) * 2) + p) * 256 + lane * 4];
+            mac3x4(Ae[0], Bx[0], D[0][c][0], Ae[1], Bx[0], D[1][c][0], Ae[0], Bx[1], D[0][c][1], Ae[1], Bx[1], D[1][c][1]);
+            SYNL_FENCE();
+        }
+        if (st == 1) {
+            u32x4 Bx[2][2];
+#pragma unroll
+            for (int c = 2; c < 4; ++c)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) Bx[c - 2][p] = *(const u32x4 *)&Xf[(((c * 4 + 1) * 2) + p) * 256 + lane * 4];
+            mac3x4(Ae[0], Bx[0], D[0][2][2], Ae[1], Bx[0], D[1][2][2], Ae[0], Bx[1], D[0][3][2], Ae[1], Bx[1], D[1][3][2]);
+            SYNL_FENCE();
+        }
+        SYNL_LAP(1);
+        // ---- depthwise 3x3 stride 2 + BN shift + ReLU6, split in place into the B operand of the project step ----
+        u32x4 Ap[3][2];
+        auto fetch_p = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Ap[mt % 3][p] = bload4(rs_p, l16, G * (MT * 2048) + (mt * 2 + p) * 1024);
+        };
+        u32x4 Bd[2][2];
+#pragma unroll
+        for (int th = 0; th < 4; ++th) {
+            const int t = th >> 1, hf = th & 1;
+            if (th == 3) fetch_p(0);
+            const int c0 = 16 * t + 2 * hf;
+            f32x2 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x2 *)&Tb[k * 32 + c0 + g4];
+            const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) w[3 * dy] *= mL;
+            auto relu = [&](const f32x4 &d, float ceil) __attribute__((always_inline)) {
+                f32x2 e;
+                e[0] = __builtin_amdgcn_fmed3f(d[2 * hf], 0.0f, ceil);
+                e[1] = __builtin_amdgcn_fmed3f(d[2 * hf + 1], 0.0f, ceil);
+                return e;
+            };
+            f32x2 up2, up3;                              // the odd-row classes' block before this wave's first block (wave 1), lanes 8-15 -> 0-7
+            if (st == 1) {
+                up2 = dpp2<kRowShl8>(relu(D[t][2][2], c6e));
+                up3 = dpp2<kRowShl8>(relu(D[t][3][2], cJ));
+            } else {
+                up2 = (f32x2){0.f, 0.f}; up3 = up2;      // (row -1: the image border)
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f32x2 E0 = relu(D[t][0][k], c6e), E1 = relu(D[t][1][k], cJ);
+                const f32x2 E2 = relu(D[t][2][k], k == 1 ? cR0 : c6e), E3 = relu(D[t][3][k], k == 1 ? cR1 : cJ);
+                // the class row above: lanes 8-15 from lanes 0-7 of this block, lanes 0-7 from lanes 8-15 of the block before
+                const f32x2 U2 = dpp2<kRowShr8>(E2) + up2, U3 = dpp2<kRowShr8>(E3) + up3;
+                f32x2 O = dsh;
+                O += dpp2<kRowShr1>(U3) * w[0];
+                O += U2 * w[1];
+                O += U3 * w[2];
+                asm volatile("" : "+v"(O));
+                O += dpp2<kRowShr1>(E1) * w[3];
+                O += E0 * w[4];
+                O += E1 * w[5];
+                asm volatile("" : "+v"(O));
+                O += dpp2<kRowShr1>(E3) * w[6];
+                O += E2 * w[7];
+                O += E3 * w[8];
+                split2v(__builtin_amdgcn_fmed3f(O[0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[1], 0.0f, 96.0f), Bd[k], th);
+                if (k == 0) { up2 = dpp2<kRowShl8>(E2); up3 = dpp2<kRowShl8>(E3); }
+            }
+            SYNL_FENCE();
+        }
+        SYNL_LAP(2);
+        // ---- project 1x1, K = this group ----
+        const bool more = G + 1 < L7::NG;
+        fetch_p(1);
+        if (more) { fetch_t(G + 1); fetch_e(G + 1); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt + 2 < MT) fetch_p(mt + 2);
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                acc[mt][0] = mfmal(Ap[mt % 3][PA[j]], Bd[0][PB[j]], acc[mt][0]);
+                acc[mt][1] = mfmal(Ap[mt % 3][PA[j]], Bd[1][PB[j]], acc[mt][1]);
+            }
+            SYNL_FENCE();
+        }
+        if (more) park_t();
+        SYNL_LAP(3);
+    }
+
+    // ---- rescale, BN shift (no residual: the block changes width and stride), NHWC store and / or hand-over ----
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int ne = le & 15, ge = le >> 4, ox = ne & 7;
+    constexpr bool HANDOFF = !__is_same(CN, void);
+    if constexpr (HANDOFF) __syncthreads();              // every wave is done reading the class fragments (the hand-over overwrites them)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int nch = 16 * mt + 4 * ge;
+        const f32x4 psh = *(const f32x4 *)&p_shift[nch];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int oy = 4 * st + 2 * k + (ne >> 3);
+            const f32x4 v = acc[mt][k] * inv_p + psh;
+            if (real) *(f32x4 *)&Y[((size_t)f * 64 + oy * 8 + ox) * COUT + nch] = v;     // (the next block's residual reads it)
+            if constexpr (HANDOFF) {
+                static_assert(CN::CIN == COUT && !CN::S2, "features.8 takes this block's output");
+                // pixel (oy, ox) in the next stage's layout: block oy & 3, lane column 8 (oy >> 2) + ox
+                const int kc = mt >> 1, lg = (2 * (mt & 1) + (ge >> 1)) * 16, dw = 2 * (ge & 1);
+                const int r = 2 * k + (ne >> 3), nn = 8 * st + ox;
+                const f32x4 vs = real ? v * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+                unsigned a0, b0, a1, b1;
+                split2h(vs[0], vs[1], a0, b0);
+                split2h(vs[2], vs[3], a1, b1);
+                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 0) * 256 + (lg + nn) * 4 + dw] = (u32x2){a0, a1};
+                *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 1) * 256 + (lg + nn) * 4 + dw] = (u32x2){b0, b1};
+            }
+        }
+    }
+    SYNL_LAP(4);
+}
+
+template <bool PROF = false>
+__global__ __launch_bounds__(L7::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_block_lb7_kernel(LbStageArgs sa, int B, unsigned long long *prof = nullptr) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+    __shared__ __attribute__((aligned(16))) unsigned smem[L7::LDS_DW];
+    lb7_stage<void, PROF, L7::FACE_DW>(smem, sa, B, pt_, tk);
+    if (PROF && (threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], pt_[i]);
+        atomicAdd(&prof[7], 1ull);
+    }
+}
+
 template <class C, bool PROF = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nullptr) {
@@ -458,29 +711,35 @@ using L11 = LbCfg<     64, 384,  96, false, 2, 2>;     // features.11
 using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
 using L14 = LbCfg<     96, 576, 160, false, 1, 2, 2, true>;   // features.14 (stride 2: 8x8 -> 4x4)
 
-// features.8 .. 14 of a face in ONE launch: 8, 9, 10 (64 -> 384 -> 64, residual), 11 (64 -> 384 -> 96), 12, 13 (96 -> 576 -> 96, residual),
-// 14 (96 -> 576 -> 160, stride 2; features.13's output then never goes to global memory).  WITH14 = false stops after features.13.
-struct LbChainArgs { LbStageArgs s[7]; };
-constexpr int kChainFaceDw = L12::FACE_DW > L8::FACE_DW ? (L12::FACE_DW > L11::FACE_DW ? L12::FACE_DW : L11::FACE_DW) : L8::FACE_DW;
-static_assert(L14::FACE_DW <= kChainFaceDw, "features.14 reuses the chain's fragment buffers");
+// features.7 .. 14 of a face in ONE launch: 7 (32 -> 192 -> 64, stride 2, 15x15 -> 8x8), 8, 9, 10 (64 -> 384 -> 64, residual),
+// 11 (64 -> 384 -> 96), 12, 13 (96 -> 576 -> 96, residual), 14 (96 -> 576 -> 160, stride 2; features.13's output then never goes to
+// global memory).  s[i] = features.(7 + i); WITH7 = false starts at features.8, WITH14 = false stops after features.13.
+struct LbChainArgs { LbStageArgs s[8]; };
+constexpr int kChainFaceDw = L7::FACE_DW;
+static_assert(L8::FACE_DW <= kChainFaceDw && L11::FACE_DW <= kChainFaceDw && L12::FACE_DW <= kChainFaceDw && L14::FACE_DW <= kChainFaceDw,
+              "every stage reuses the fragment buffers of the first");
 constexpr int kChainLdsDw = L8::FPW * kChainFaceDw + L8::NW * L8::TB_DW;
 static_assert(2 * kChainLdsDw * 4 <= 160 * 1024, "two workgroups per CU");
 
-template <bool WITH14>
+template <bool WITH7, bool WITH14>
 __global__ __launch_bounds__(L8::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDw];
-    lb_stage<L8, L8, true, false, kChainFaceDw>(smem, ca.s[0], B, pt_, tk);
-    lb_stage<L8, L8, false, false, kChainFaceDw>(smem, ca.s[1], B, pt_, tk);
-    lb_stage<L8, L11, false, false, kChainFaceDw>(smem, ca.s[2], B, pt_, tk);
-    lb_stage<L11, L12, false, false, kChainFaceDw>(smem, ca.s[3], B, pt_, tk);
-    lb_stage<L12, L12, false, false, kChainFaceDw>(smem, ca.s[4], B, pt_, tk);
-    if constexpr (WITH14) {
-        lb_stage<L12, L14, false, false, kChainFaceDw, false>(smem, ca.s[5], B, pt_, tk);
-        lb_stage<L14, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
+    if constexpr (WITH7) {
+        lb7_stage<L8, false, kChainFaceDw>(smem, ca.s[0], B, pt_, tk);
+        lb_stage<L8, L8, false, false, kChainFaceDw>(smem, ca.s[1], B, pt_, tk);
     } else
-        lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[5], B, pt_, tk);
+        lb_stage<L8, L8, true, false, kChainFaceDw>(smem, ca.s[1], B, pt_, tk);
+    lb_stage<L8, L8, false, false, kChainFaceDw>(smem, ca.s[2], B, pt_, tk);
+    lb_stage<L8, L11, false, false, kChainFaceDw>(smem, ca.s[3], B, pt_, tk);
+    lb_stage<L11, L12, false, false, kChainFaceDw>(smem, ca.s[4], B, pt_, tk);
+    lb_stage<L12, L12, false, false, kChainFaceDw>(smem, ca.s[5], B, pt_, tk);
+    if constexpr (WITH14) {
+        lb_stage<L12, L14, false, false, kChainFaceDw, false>(smem, ca.s[6], B, pt_, tk);
+        lb_stage<L14, void, false, false, kChainFaceDw>(smem, ca.s[7], B, pt_, tk);
+    } else
+        lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
 }
 
 template <class C>
@@ -491,23 +750,27 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     else fused_block_lb_kernel<C><<<grid, C::NT, 0, s>>>(sa, B);
 }
 
-// features.8 .. 8 + n_blocks - 1 in one launch (a[i] = the arguments of features.(8 + i), n_blocks = 6 | 7); false: run them one by one
-int lb_chain_blocks(int B) {
-    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 2;      // 0: off, 1: features.8-13, 2: features.8-14
-    if (!chain || B < 768) return 0;
-    return chain >= 2 ? 7 : 6;
+// The chain launch: mode 0 = off (one launch per block), 1 = features.8-13, 2 = features.8-14, 3 = features.7-14 (SYN_LB_CHAIN; default 3)
+int lb_chain_mode(int B) {
+    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
+    if (chain <= 0 || B < 768) return 0;
+    return chain > 3 ? 3 : chain;
 }
-bool launch_fused_chain_lb(const FusedBlockArgs *a, int n_blocks, int B, hipStream_t s) {
-    if (n_blocks != 6 && n_blocks != 7) return false;
+// a[i] = the arguments of features.(first + i), first = 7 | 8, first + n_blocks - 1 = 13 | 14; false: not applicable
+bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int B, hipStream_t s) {
+    const int last = first + n_blocks - 1;
+    if ((first != 7 && first != 8) || (last != 13 && last != 14) || (first == 7 && last != 14)) return false;
     LbChainArgs ca;
     for (int i = 0; i < n_blocks; ++i) {
         if (!a[i].Alb_e || !a[i].Alb_p || !a[i].Tlb || a[i].prof) return false;
-        ca.s[i] = LbStageArgs{a[i].X, a[i].Alb_e, a[i].Tlb, a[i].Alb_p, a[i].p_shift, a[i].Y};
+        ca.s[first - 7 + i] = LbStageArgs{a[i].X, a[i].Alb_e, a[i].Tlb, a[i].Alb_p, a[i].p_shift, a[i].Y};
     }
-    if (n_blocks == 6) ca.s[6] = ca.s[5];
+    if (first == 8) ca.s[0] = ca.s[1];
+    if (last == 13) ca.s[7] = ca.s[6];
     const int grid = (B + L8::FPW - 1) / L8::FPW;
-    if (n_blocks == 7) fused_chain_lb_kernel<true><<<grid, L8::NT, 0, s>>>(ca, B);
-    else fused_chain_lb_kernel<false><<<grid, L8::NT, 0, s>>>(ca, B);
+    if (first == 7) fused_chain_lb_kernel<true, true><<<grid, L8::NT, 0, s>>>(ca, B);
+    else if (last == 14) fused_chain_lb_kernel<false, true><<<grid, L8::NT, 0, s>>>(ca, B);
+    else fused_chain_lb_kernel<false, false><<<grid, L8::NT, 0, s>>>(ca, B);
     return true;
 }
 
@@ -523,6 +786,13 @@ bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStrea
     if (!a.Alb_e || !a.Alb_p || !a.Tlb) return false;
     if (B < lb_min_batch(feature)) return false;
     switch (feature) {
+        case 7: {
+            const LbStageArgs sa{a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y};
+            const int grid = (B + L7::FPW - 1) / L7::FPW;
+            if (a.prof) fused_block_lb7_kernel<true><<<grid, L7::NT, 0, s>>>(sa, B, a.prof);
+            else fused_block_lb7_kernel<false><<<grid, L7::NT, 0, s>>>(sa, B);
+            return true;
+        }
         case 8: case 9: case 10: launch_lb<L8>(a, B, s); return true;
         case 11: launch_lb<L11>(a, B, s); return true;
         case 12: case 13: launch_lb<L12>(a, B, s); return true;

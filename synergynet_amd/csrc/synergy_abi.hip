@@ -140,7 +140,7 @@ struct Net {
             }
             if (L.kind == PW && L.feature == 1) { L.dst_wrm = dst; dst += syn::rm_project_dwords(L.cin); L.dst_scl = dst; dst += 4; }     // stem_rm.hip
             L.dst_wlb = 0;
-            if (L.kind == PW && !L.relu6 && L.feature >= 8 && L.feature <= 14) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
+            if (L.kind == PW && !L.relu6 && L.feature >= 7 && L.feature <= 14) { L.dst_wlb = dst; dst += syn::lb_project_dwords(L.cin, L.cout); }
             L.dst_tlb = 0;
             L.dst_glb = 0;
             if (L.kind == PW && L.relu6 && L.feature >= 15 && L.feature <= 17) {
@@ -148,7 +148,7 @@ struct Net {
                 L.dst_glb = dst; dst += syn::lb4_group_dwords(L.cin, cout_p) * (size_t)(L.cout / 32);
             }
             L.dst_weh = 0;
-            if (L.kind == PW && L.relu6 && L.feature >= 8 && L.feature <= 14) {
+            if (L.kind == PW && L.relu6 && L.feature >= 7 && L.feature <= 14) {
                 L.dst_tlb = dst; dst += syn::lb_table_floats(L.cout);
                 L.dst_weh = dst; dst += syn::lb_expand_dwords(L.cin, L.cout);
             }
@@ -459,22 +459,26 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             }
             continue;
         }
-        // features.8-14 (or 8-13) as one chain launch (fused_block_lb.hip): every workgroup carries its faces through the blocks
-        const int chain_n = (h->fusion >= 2 && L.kind == PW && L.relu6 && L.feature == 8 && (h->early_rm & 128) && (h->early_rm & 512) && prof_feature < 0)
-                                ? syn::lb_chain_blocks(B) : 0;
-        if (chain_n && (stop_feature < 0 || stop_feature >= 7 + chain_n) && li + 3 * chain_n <= nl &&
-            n.max_hidden >= 2048 + 3 * (size_t)64 * 96) {
-            // Workgroups run through the stages unsynchronised, so a buffer must never hold two tensor layouts at once: the 64-channel
-            // tensors (input, features.8-10) ping-pong in X / Y, the 96-channel ones (features.11-13) in two slices of H1 and the 4x4x160
-            // output of features.14 in a third -- a fast workgroup's 96-channel store into X would land in the 64-channel rows a slower
-            // workgroup still reads.  (features.13 is not stored when features.14 follows in the chain.)
-            syn::FusedBlockArgs ca[7];
-            float *const Ha = H1 + (size_t)B * 2048, *const Hb = Ha + (size_t)B * 64 * 96, *const Hc = Hb + (size_t)B * 64 * 96;   // (the head's scratch rows stay free)
-            float *const bin[7] = {X, Y, X, Y, Ha, Hb, Ha}, *const bout[7] = {Y, X, Y, Ha, Hb, Ha, Hc};
+        // features.7-14 (or 8-14, 8-13) as one chain launch (fused_block_lb.hip): every workgroup carries its faces through the blocks
+        const int chain_mode = (h->fusion >= 2 && L.kind == PW && L.relu6 && (L.feature == 7 || L.feature == 8) && (h->early_rm & 128) && (h->early_rm & 512) &&
+                                prof_feature < 0) ? syn::lb_chain_mode(B) : 0;
+        const int chain_first = chain_mode == 3 ? 7 : 8, chain_last = chain_mode == 1 ? 13 : 14, chain_n = chain_last - chain_first + 1;
+        if (chain_mode && L.feature == chain_first && (stop_feature < 0 || stop_feature >= chain_last) && li + 3 * chain_n <= nl &&
+            n.max_hidden >= 2048 + 2 * (size_t)64 * 96 + 16 * 160 + 64 * 64) {
+            // Workgroups run through the stages unsynchronised, so a buffer must never hold two tensor layouts at once -- a fast workgroup's
+            // 96-channel store into X would land in the 64-channel rows a slower workgroup still reads.  X keeps the chain input; the
+            // 64-channel 8x8 tensors (features.7-10) ping-pong in Y and one slice of H1 (chain from features.8: X and Y), the 96-channel
+            // ones (features.11, 12; features.13 is not stored when features.14 follows) in two more, the 4x4x160 output in a fourth.
+            syn::FusedBlockArgs ca[8];
+            float *const Ha = H1 + (size_t)B * 2048, *const Hb = Ha + (size_t)B * 64 * 96, *const Hc = Hb + (size_t)B * 64 * 96,   // (the head's scratch rows stay free)
+                  *const Hd = Hc + (size_t)B * 16 * 160;
+            float *const bin7[8] = {X, Y, Hd, Y, Hd, Ha, Hb, Ha}, *const bout7[8] = {Y, Hd, Y, Hd, Ha, Hb, Ha, Hc};
+            float *const bin8[7] = {X, Y, X, Y, Ha, Hb, Ha}, *const bout8[7] = {Y, X, Y, Ha, Hb, Ha, Hc};
+            float *const *bin = chain_first == 7 ? bin7 : bin8, *const *bout = chain_first == 7 ? bout7 : bout8;
             bool ok = true;
             for (int i = 0; i < chain_n && ok; ++i) {
                 const Layer &E = n.layers[li + 3 * i], &Dw = n.layers[li + 3 * i + 1], &Pr = n.layers[li + 3 * i + 2];
-                ok = E.kind == PW && E.relu6 && E.feature == 8 + i && E.dst_weh && E.dst_tlb && Pr.dst_wlb;
+                ok = E.kind == PW && E.relu6 && E.feature == chain_first + i && E.dst_weh && E.dst_tlb && Pr.dst_wlb;
                 if (!ok) break;
                 ca[i] = syn::FusedBlockArgs{bin[i], P + E.dst_wpk, P + E.dst_scale, P + E.dst_shift, P + Dw.dst_wpk, P + Dw.dst_scale, P + Dw.dst_shift,
                                             P + Pr.dst_wpk, P + Pr.dst_scale, P + Pr.dst_shift, bout[i]};
@@ -482,11 +486,11 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 ca[i].Alb_p = reinterpret_cast<const unsigned *>(P + Pr.dst_wlb);
                 ca[i].Tlb = P + E.dst_tlb;
             }
-            if (ok && syn::launch_fused_chain_lb(ca, chain_n, B, s)) {
+            if (ok && syn::launch_fused_chain_lb(ca, chain_first, chain_n, B, s)) {
                 li += 3 * chain_n - 1;
                 X = bout[chain_n - 1];                      // (a slice of H1 from here on)
-                mark(800 + 7 + chain_n);
-                if (stop_feature == 7 + chain_n) {
+                mark(100 * chain_first + chain_last);
+                if (stop_feature == chain_last) {
                     const Layer &Lp = n.layers[li];
                     HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
                     return SYN_OK;

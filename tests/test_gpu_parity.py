@@ -540,13 +540,13 @@ np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
 '''
 
 
-@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'}],
+@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'}],
                          ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
 def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs):
-    """features.8-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
+    """features.7-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
     the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
     faces per workgroup (head_kernel.hip).  Every one of these is a schedule change only: with the chain off (one launch per
-    block), with the shorter features.8-13 chain, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
+    block), with the shorter features.8-13 / 8-14 chains, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
     read once per process, hence the subprocess."""
     import subprocess
     import sys
