@@ -360,9 +360,10 @@ def main():
                     pass
         ceiling = PEAK_F16X2_TFLOPS
         roof = dict(bound='mfma',
-                    kernel=f'syn::fused_block_{{rm,lb,bf3}}_kernel (expand 1x1 -> dw 3x3 -> project 1x1 per launch; {len(fam)} launches per '
-                           f'forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; features.2-6 row-marching and features.8-13 '
-                           f'register-resident with the hidden activations in registers, the others whole-image tiles in LDS); fp32-accurate '
+                    kernel=f'syn::fused_block_rm_kernel, syn::fused_chain_lb_kernel, syn::fused_chain_lb4_kernel (expand 1x1 -> dw 3x3 -> project 1x1 '
+                           f'per block; {len(fam)} launches per forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; '
+                           f'features.2-6 row-marching, features.7-14 and 15-17 register-resident chains of blocks in one launch each (launch code '
+                           f'100 * first + last), hidden activations never leave registers); fp32-accurate '
                            f'results on v_mfma_f32_{{32x32x16,16x16x32}}_f16 with every operand as two fp16 pieces (3 MFMAs per block product): '
                            f'algorithmic fp32 FLOPs priced against the dense fp16 MFMA peak / 3',
                     achieved=round(achieved, 3), peak=round(ceiling, 1), unit='TFLOP/s',
