@@ -337,7 +337,9 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         SYNL_LAP(2);
         // ---- project 1x1 (bf16 x3), K = this group ----
         const bool more = G + C::NS < C::NG;
-        if (C::PPF > 1) fetch_p(1);
+#pragma unroll
+        for (int i = 1; i < C::PPF; ++i)
+            if (i < MT) fetch_p(i);
         if (more) {
             if (!C::TLATE) fetch_t(G + C::NS);
 #pragma unroll
@@ -706,8 +708,14 @@ void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nul
 }
 
 //                    CIN  HID COUT  RES  EPF PPF
-using L8 = LbCfg<      64, 384,  64, true,  2, 2>;     // features.8-10
-using L11 = LbCfg<     64, 384,  96, false, 2, 2>;     // features.11
+#ifndef SYN_L8_PPF
+#define SYN_L8_PPF 3
+#endif
+#ifndef SYN_L11_PPF
+#define SYN_L11_PPF 3
+#endif
+using L8 = LbCfg<      64, 384,  64, true,  2, SYN_L8_PPF>;     // features.8-10
+using L11 = LbCfg<     64, 384,  96, false, 2, SYN_L11_PPF>;     // features.11
 using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
 using L14 = LbCfg<     96, 576, 160, false, 1, 2, 2, true>;   // features.14 (stride 2: 8x8 -> 4x4)
 
