@@ -70,7 +70,7 @@ __device__ __forceinline__ float from_right(float v) {
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false>
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false, int WREG_ = 0>
 struct RmCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
@@ -78,6 +78,9 @@ struct RmCfg {
     // the project weight fragments live in LDS instead of 24 registers, and the partial sums have ONE slot -- a second barrier per
     // step, which the compute waves pass only after the service wave has read the previous row's sums (it arrives long before).
     static constexpr bool LEAN = LEAN_;
+    // WREG (stride 1): register quads whose depthwise filter (9 x 4 values per lane) stays in registers for the whole kernel instead of
+    // being re-read from LDS every row step (10 of the 48 ds_read_b128 of a step per quad; the LDS arrays are busy 55-60 % of these kernels)
+    static constexpr int WREG = WREG_;
     static constexpr int KS = cdivr(CIN, 16);            // k16 steps of the expand GEMM
     static constexpr int NG = cdivr(HID, 32);            // hidden groups of 32 channels = compute waves of a unit
     static constexpr int HIDP = NG * 32;
@@ -100,6 +103,7 @@ struct RmCfg {
     static_assert(S == 1 ? (NF == 1 ? H + 2 <= 32 : 2 * H + 2 <= 32) : (NF == 1 ? H / 2 + 1 <= 32 : H / 2 + 1 <= 16), "one image row per 32-lane block");
     static_assert(!RES || (S == 1 && CIN == COUT), "residual only on stride-1 same-width blocks");
     static_assert(!LEAN || S == 1, "LEAN is implemented for the stride-1 march");
+    static_assert(WREG == 0 || (S == 1 && WREG <= 4), "the register-held filter is implemented for the stride-1 march");
     static_assert(S == 2 || H % 3 == 0, "row ring unrolled by 3");
     static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
 };
@@ -275,6 +279,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
 
+    f32x4 wreg[C::WREG > 0 ? C::WREG : 1][9], wbase[C::WREG > 0 ? C::WREG : 1];
+#pragma unroll
+    for (int q = 0; q < C::WREG; ++q) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wreg[q][k] = *(const f32x4 *)(Filt + cb + 8 * q + k * C::HIDP);
+        wbase[q] = *(const f32x4 *)(Filt + cb + 8 * q + DSH);
+    }
     // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
     // stores nothing (its faces are >= B)
     for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
@@ -349,6 +360,16 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
         };
+        // the same with the filter quads in registers (wr[3 * ky + kx])
+        auto taps3r = [&](f32x16 &d, int q, const f32x4 *wr, const f32x4 &base, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b0 = init ? base[t] : d[4 * q + t];
+                d[4 * q + t] = __builtin_fmaf(r4[t], wr[3 * ky + 2][t], __builtin_fmaf(c4[t], wr[3 * ky + 1][t], __builtin_fmaf(l4[t], wr[3 * ky][t], b0)));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
+        };
         // two taps (U blocks of the stride-2 layout: this lane and its right neighbour) / one tap (V blocks)
         auto taps2 = [&](f32x16 &d, int q, const float *wq, int ta, int tb, const f32x4 &c4, const f32x4 &r4, bool init) {
             const f32x4 wa = *(const f32x4 *)(wq + ta * C::HIDP), wb = *(const f32x4 *)(wq + tb * C::HIDP);
@@ -397,9 +418,15 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { c4[t] = e[4 * q + t]; l4[t] = from_left(c4[t]); r4[t] = from_right(c4[t]); }
                     const float *wq = Filt + cbo + 8 * q;
-                    taps3(dn, q, wq, 0, l4, c4, r4, true);
-                    taps3(dc, q, wq, 1, l4, c4, r4, false);
-                    taps3(dm, q, wq, 2, l4, c4, r4, false);
+                    if (q < C::WREG) {
+                        taps3r(dn, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 0, l4, c4, r4, true);
+                        taps3r(dc, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 1, l4, c4, r4, false);
+                        taps3r(dm, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 2, l4, c4, r4, false);
+                    } else {
+                        taps3(dn, q, wq, 0, l4, c4, r4, true);
+                        taps3(dc, q, wq, 1, l4, c4, r4, false);
+                        taps3(dm, q, wq, 2, l4, c4, r4, false);
+                    }
                     __builtin_amdgcn_sched_barrier(0);          // one register quad at a time
                 }
                 SYNR_LAP(3);
@@ -517,7 +544,10 @@ static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per
 // which split a face over many workgroups, are faster and the launcher declines.
 //                       CIN  HID COUT  H  S NF  RES   waves/SIMD  units/workgroup
 template <int U> using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, (U == 4 ? 4 : 3), U>;    // features.2   60 -> 30      U x (3 + 1) waves
-template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U>;                   // features.3   30            U x (5 + 1) waves
+#ifndef SYN_R3_WREG
+#define SYN_R3_WREG 1
+#endif
+template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG>;                   // features.3   30            U x (5 + 1) waves
 template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
 template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true>;             // features.5/6 15            U x (6 + 1) waves, two faces per unit, 4 per SIMD
 
