@@ -94,6 +94,8 @@ struct Lb4StageArgs {
     const unsigned *Glb;     // [NG][NKB][64][4]: We | Wp | table per group
     const float *p_shift;
     float *Y;                // block output (global): written by the last stage only
+    float *part = nullptr;   // hidden-sliced schedule: partial sums [slice][B][16][COUT] (raw accumulators)
+    int g0 = 0, g1 = 0;      // hidden groups [g0, g1) of this workgroup's slice (g1 = 0: all); slice = blockIdx.y
 };
 
 template <int N>
@@ -108,7 +110,10 @@ __device__ __forceinline__ void lb4_park(const u32x4 *pf, unsigned *dst /* + 4 l
 }
 
 // GRPL: dwords per half of the LDS weight double buffer (>= the group run of every stage of the kernel)
-template <class C, class CN, bool FIRST, int GRPL>
+// PARTIAL (small batches): the workgroup (blockIdx.x = four faces, blockIdx.y = slice) walks only the hidden groups of its slice and
+// stores its raw accumulators; lb4_reduce_kernel adds the slices in fixed order, rescales, adds BN shift and residual.  A batch of 128
+// faces is then 32 x 6 workgroups of five groups each instead of 32 workgroups walking all thirty.
+template <class C, class CN, bool FIRST, int GRPL, bool PARTIAL = false>
 __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa, const unsigned *GlbNext, int B, u32x4 (&Xr)[5][2], f32x4 (&vres)[5]) {
     constexpr int KE = C::KE, MTW = C::MTW, CIN = C::CIN, COUT = C::COUT;
     constexpr bool HANDOFF = !__is_same(CN, void);
@@ -133,8 +138,10 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     using CNX = typename std::conditional<HANDOFF, CN, Lb4NoNext>::type;
     constexpr int NPWN = CNX::NKB / 8;
     u32x4 pf[NPW > NPWN ? NPW : NPWN];
+    const int gsl = PARTIAL ? (sa.g1 - sa.g0) : C::NG;   // groups per slice (all slices the same)
+    const int gb = PARTIAL ? (int)blockIdx.y * gsl : 0, ge = gb + gsl;
     if (FIRST) {
-        lb4_fetch<NPW>(pf, Glb + l4, wave);
+        lb4_fetch<NPW>(pf, Glb + (size_t)gb * C::GRP_DW + l4, wave);
         // ---- block input of this face -> pre-split B fragments in registers (x 16; both waves of the face hold it) ----
         f32x4 xv[KE][2];
 #pragma unroll
@@ -160,13 +167,16 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     float c6e = 0.f, inv_p = 0.f;
     if (FIRST) lb4_park<NPW>(pf, smem + l4, wave);
 
-    for (int G = 0; G < C::NG; ++G) {
+    {   // ReLU6 ceiling of the scaled expand output, accumulator -> output: constants of the block, kept in group 0's table
+        const float *t0 = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW);
+        c6e = t0[11 * 32]; inv_p = t0[11 * 32 + 1];
+    }
+    for (int G = gb; G < ge; ++G) {
         __syncthreads();                                 // every wave has written its pieces of group G and is done with group G-1
-        if (G + 1 < C::NG) lb4_fetch<NPW>(pf, Glb + (size_t)(G + 1) * C::GRP_DW + l4, wave);
+        if (G + 1 < ge) lb4_fetch<NPW>(pf, Glb + (size_t)(G + 1) * C::GRP_DW + l4, wave);
         else if (HANDOFF) lb4_fetch<NPWN>(pf, GlbNext + l4, wave);          // the next block's first group
-        const unsigned *We = smem + (G & 1) * GRPL, *Wp = We + C::WE_DW;
+        const unsigned *We = smem + ((G - gb) & 1) * GRPL, *Wp = We + C::WE_DW;
         const float *Tb = reinterpret_cast<const float *>(Wp + C::WP_DW);
-        if (G == 0) { c6e = Tb[11 * 32]; inv_p = Tb[11 * 32 + 1]; }
         // fragments of this wave: its hidden tile's expand fragments and its output tiles' project fragments, read up front
         u32x4 Ae[KE][2], Ap[MTW][2];
 #pragma unroll
@@ -239,8 +249,16 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
             acc[i] = mfmaq(Ap[i][0], Bd[1], acc[i]);
             acc[i] = mfmaq(Ap[i][0], Bd[0], acc[i]);
         }
-        if (G + 1 < C::NG) lb4_park<NPW>(pf, smem + ((G + 1) & 1) * GRPL + l4, wave);
+        if (G + 1 < ge) lb4_park<NPW>(pf, smem + ((G + 1 - gb) & 1) * GRPL + l4, wave);
         else if (HANDOFF) lb4_park<NPWN>(pf, smem + l4, wave);               // (NG is even: the next block starts in half 0 again)
+    }
+    if constexpr (PARTIAL) {                             // raw accumulators of this slice -> [slice][B][16][COUT]
+        if (real) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+                *(f32x4 *)&sa.part[(((size_t)blockIdx.y * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4] = acc[i];
+        }
+        return;
     }
 
     // ---- rescale, BN shift, residual: lane (n, g) holds channels 16 mt + 4 g .. + 3 of pixel n.  The last stage stores NHWC; the
@@ -283,13 +301,30 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     }
 }
 
-template <class C>
+template <class C, bool PARTIAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_block_lb4_kernel(Lb4StageArgs sa, int B) {
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
     u32x4 Xr[5][2];
     f32x4 vres[5];
-    lb4_stage<C, void, true, C::GRP_DW>(smem, sa, nullptr, B, Xr, vres);
+    lb4_stage<C, void, true, C::GRP_DW, PARTIAL>(smem, sa, nullptr, B, Xr, vres);
+}
+
+// y = (slice 0 + slice 1 + ... in this order) / (16 Sp) + BN shift (+ x): one thread per four channels of a pixel
+template <class C>
+__global__ __launch_bounds__(256) void lb4_reduce_kernel(const float *__restrict__ part, int S, const unsigned *__restrict__ Glb,
+                                                         const float *__restrict__ p_shift, const float *__restrict__ X,
+                                                         float *__restrict__ Y, int B) {
+    constexpr int C4 = C::COUT / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * 16 * C4;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    const float inv_p = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW)[11 * 32 + 1];
+    f32x4 a = *(const f32x4 *)&part[(size_t)idx * 4];
+    for (int sl = 1; sl < S; ++sl) a += *(const f32x4 *)&part[((size_t)sl * total + idx) * 4];
+    f32x4 v = a * inv_p + *(const f32x4 *)&p_shift[4 * c4];
+    if (C::RES) v += *(const f32x4 *)&X[(size_t)idx * 4];
+    *(f32x4 *)&Y[(size_t)idx * 4] = v;
 }
 
 using Q15 = Lb4Cfg<160, 960, 160, true>;      // features.15, 16
@@ -316,6 +351,23 @@ static void launch_lb4(const FusedBlockArgs &a, int B, hipStream_t s) {
     fused_block_lb4_kernel<C><<<(B + 3) / 4, 512, 0, s>>>(Lb4StageArgs{a.X, a.Glb, a.p_shift, a.Y}, B);
 }
 
+// small batches: S slices of the hidden groups per four faces (S divides the 30 groups; >= ~192 workgroups), partial sums in `scratch`
+template <class C>
+static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
+    if (!a.scratch) return false;
+    const int wg = (B + 3) / 4;
+    static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
+    int S = 30;
+    for (int d : divs) if (wg * d >= 192) { S = d; break; }
+    if ((size_t)S * B * 16 * C::COUT > a.scratch_floats) return false;
+    Lb4StageArgs sa{a.X, a.Glb, a.p_shift, a.Y};
+    sa.part = a.scratch; sa.g0 = 0; sa.g1 = C::NG / S;
+    fused_block_lb4_kernel<C, true><<<dim3(wg, S), 512, 0, s>>>(sa, B);
+    const long total = (long)B * 16 * (C::COUT / 4);
+    lb4_reduce_kernel<C><<<(int)((total + 255) / 256), 256, 0, s>>>(a.scratch, S, a.Glb, a.p_shift, a.X, a.Y, B);
+    return true;
+}
+
 static int lb4_min_batch() {
     static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 768;     // fewer faces: not enough workgroups of four
     return min_b;
@@ -336,7 +388,15 @@ bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
 
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Glb || a.prof) return false;
-    if (B < lb4_min_batch()) return false;
+    if (B < lb4_min_batch()) {
+        static const int sl_min = getenv("SYN_LB4_SLICED_MIN") ? atoi(getenv("SYN_LB4_SLICED_MIN")) : 32;      // below: the tiled kernel's own sliced schedule
+        if (B < sl_min) return false;
+        switch (feature) {
+            case 15: case 16: return launch_lb4_sliced<Q15>(a, B, s);
+            case 17: return launch_lb4_sliced<Q17>(a, B, s);
+            default: return false;
+        }
+    }
     switch (feature) {
         case 15: case 16: launch_lb4<Q15>(a, B, s); return true;
         case 17: launch_lb4<Q17>(a, B, s); return true;

@@ -52,6 +52,8 @@ struct FusedBlockArgs {
     const unsigned *Alb_e = nullptr;                  // ... its expand fragments
     const float *Tlb = nullptr;                       // ... and its per-group constants table
     const unsigned *Glb = nullptr;                    // features.15-17: per-group runs of fused_block_lb4.hip, or null
+    float *scratch = nullptr;                         // workspace for schedules that keep partial sums (hidden-sliced small batches), or null
+    size_t scratch_floats = 0;
 };
 bool launch_fused_block(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // early blocks (features.2-4) on the bf16 matrix pipe (fused_block_early.hip).  Their hidden width is walked in chunks of

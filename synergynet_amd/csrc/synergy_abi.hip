@@ -544,6 +544,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 a.Tlb = P + L.dst_tlb;
             }
             if (h->fusion >= 2 && L.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + L.dst_glb);
+            a.scratch = H2; a.scratch_floats = (size_t)B * n.max_hidden;       // (the per-layer schedule's second hidden buffer: free here)
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.Glb && syn::launch_fused_block_lb4(L.feature, a, B, s)) ||

@@ -215,11 +215,12 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
     assert torch.equal(got, ref[idx.cuda()])
 
 
-@pytest.mark.parametrize('B', [200, 224, 352, 353, 480, 511, 768, 769, 1030, 2307])
+@pytest.mark.parametrize('B', [33, 128, 200, 224, 352, 353, 480, 511, 768, 769, 1030, 2307])
 def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_early, backbone_sd, B):
     """The early blocks switch kernels with the batch size (tiled below a few hundred faces, row-marching with 1, 2 or 4 units
     per workgroup above: fused_block_rm.hip / stem_rm.hip launchers; B = 2307: more units than persistent workgroups, i.e. several
-    rounds per workgroup).  On DISTINCT faces, at batch sizes on both sides of every
+    rounds per workgroup; B = 33 ... 511 also run features.15-17 in the hidden-sliced schedule of fused_block_lb4.hip: partial sums of
+    six / three / two slices of the hidden groups, added by a second kernel).  On DISTINCT faces, at batch sizes on both sides of every
     threshold (incl. odd sizes: features.4 marches two faces per unit, the last unit of an odd batch is half empty): every face
     equals the all-tiled schedule to fp32 rounding, and a spot check of faces against the oracle."""
     import torch
