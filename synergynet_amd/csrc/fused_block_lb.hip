@@ -140,9 +140,13 @@ struct LbStageArgs {
     const unsigned *Wlb;     // [NG][MT][2][64][4]
     const float *p_shift;
     float *Y;                // block output (global)
+    float *part = nullptr;   // hidden-sliced schedule (small batches): partial sums [slice][B][pixels][COUT] (raw accumulators)
+    int gsl = 0;             // ... hidden groups per slice; slice = blockIdx.y
 };
 
-template <class C, class CN, bool FIRST, bool PROF, int FACE_DW, bool STORE = true>
+// PARTIAL (small batches, single block per launch): the workgroup (blockIdx.x = two faces, blockIdx.y = slice) walks only the hidden groups
+// of its slice and stores the raw sums of its two streams; lb_reduce_kernel adds the slices in fixed order, rescales, adds BN shift and residual.
+template <class C, class CN, bool FIRST, bool PROF, int FACE_DW, bool STORE = true, bool PARTIAL = false>
 __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, int B, unsigned long long (&pt_)[5], unsigned long long &tk) {
     unsigned long long tn = 0;
     const float *__restrict__ X = sa.X;
@@ -231,14 +235,15 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
             for (int p = 0; p < 2; ++p)
                 Ae[kc % (C::EPF == 1 ? 2 : KE)][t][p] = bload4(rs_e, l16, G * (2 * KE * 2048) + ((t * KE + kc) * 2 + p) * 1024);
     };
-    fetch_t(st);
+    const int gb = PARTIAL ? (int)blockIdx.y * sa.gsl : 0, gend = PARTIAL ? gb + sa.gsl : C::NG;     // this workgroup's hidden groups
+    fetch_t(gb + st);
 #pragma unroll
-    for (int kc = 0; kc < C::EPF; ++kc) fetch_e(st, kc);
+    for (int kc = 0; kc < C::EPF; ++kc) fetch_e(gb + st, kc);
     park_t();
     __syncthreads();
     SYNL_LAP(0);
 
-    for (int G = st; G < C::NG; G += C::NS) {
+    for (int G = gb + st; G < gend; G += C::NS) {
         // ---- expand 1x1 (bf16 x3) + BN shift + ReLU6: D[t][r], channels 32 G + 16 t + 4 g + i of pixel (r, n) ----
         f32x4 D[2][4];
 #pragma unroll
@@ -336,7 +341,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         }
         SYNL_LAP(2);
         // ---- project 1x1 (bf16 x3), K = this group ----
-        const bool more = G + C::NS < C::NG;
+        const bool more = G + C::NS < gend;
 #pragma unroll
         for (int i = 1; i < C::PPF; ++i)
             if (i < MT) fetch_p(i);
@@ -389,7 +394,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         psh[i] = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
         for (int r = 0; r < NB; ++r)
-            if (C::RES) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
+            if (C::RES && !PARTIAL) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
     }
     __syncthreads();                                     // every wave is done reading the fragments
 #pragma unroll
@@ -409,6 +414,10 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         for (int r = 0; r < NB; ++r) {
             const f32x4 o = *(const f32x4 *)&Red[((((1 - st) * (MT / 2) + (mt >> 1)) * NB + r) * 64 + lane) * 4];
             f32x4 v = st == 0 ? acc[mt][r] + o : o + acc[mt][r];        // stream 0 + stream 1
+            if constexpr (PARTIAL) {
+                if (real) *(f32x4 *)&sa.part[(((size_t)blockIdx.y * B + f) * C::PIXO + pixe + 8 * r) * COUT + nch] = v;
+                continue;
+            }
             v = v * inv_p + psh[mt >> 1];
             if (C::RES) v += rs[mt >> 1][r];
             if (STORE && real) *(f32x4 *)&Y[((size_t)f * C::PIXO + pixe + 8 * r) * COUT + nch] = v;
@@ -695,12 +704,12 @@ void fused_block_lb7_kernel(LbStageArgs sa, int B, unsigned long long *prof = nu
     }
 }
 
-template <class C, bool PROF = false>
+template <class C, bool PROF = false, bool PARTIAL = false>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nullptr) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
-    lb_stage<C, void, true, PROF, C::FACE_DW>(smem, sa, B, pt_, tk);
+    lb_stage<C, void, true, PROF, C::FACE_DW, true, PARTIAL>(smem, sa, B, pt_, tk);
     if (PROF && (threadIdx.x & 63) == 0) {
         for (int i = 0; i < 5; ++i) atomicAdd(&prof[i], pt_[i]);
         atomicAdd(&prof[7], 1ull);
@@ -750,6 +759,40 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
         lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
 }
 
+// y = (slice 0 + slice 1 + ... in this order) / (16 Sp) + BN shift (+ x): one thread per four channels of a pixel
+template <class C>
+__global__ __launch_bounds__(256) void lb_reduce_kernel(const float *__restrict__ part, int S, const float *__restrict__ Tlb,
+                                                        const float *__restrict__ p_shift, const float *__restrict__ X,
+                                                        float *__restrict__ Y, int B) {
+    constexpr int C4 = C::COUT / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * C::PIXO * C4;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    const float inv_p = Tlb[11 * 32 + 1];
+    f32x4 a = *(const f32x4 *)&part[(size_t)idx * 4];
+    for (int sl = 1; sl < S; ++sl) a += *(const f32x4 *)&part[((size_t)sl * total + idx) * 4];
+    f32x4 v = a * inv_p + *(const f32x4 *)&p_shift[4 * c4];
+    if (C::RES) v += *(const f32x4 *)&X[(size_t)idx * 4];
+    *(f32x4 *)&Y[(size_t)idx * 4] = v;
+}
+
+// small batches: S slices of the hidden groups per two faces (>= ~256 workgroups, at least two groups per slice), partial sums in `scratch`
+template <class C>
+static bool launch_lb_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
+    if (!a.scratch || a.prof) return false;
+    const int wg = (B + C::FPW - 1) / C::FPW;
+    int S = 0;
+    for (int d = 2; d <= C::NG / 2; ++d)
+        if (C::NG % d == 0) { S = d; if (wg * d >= 256) break; }
+    if (S < 2 || (size_t)S * B * C::PIXO * C::COUT > a.scratch_floats) return false;
+    LbStageArgs sa{a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y};
+    sa.part = a.scratch; sa.gsl = C::NG / S;
+    fused_block_lb_kernel<C, false, true><<<dim3(wg, S), C::NT, 0, s>>>(sa, B);
+    const long total = (long)B * C::PIXO * (C::COUT / 4);
+    lb_reduce_kernel<C><<<(int)((total + 255) / 256), 256, 0, s>>>(a.scratch, S, a.Tlb, a.p_shift, a.X, a.Y, B);
+    return true;
+}
+
 template <class C>
 static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::FPW - 1) / C::FPW;
@@ -792,7 +835,22 @@ static int lb_min_batch(int feature) {
 
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Alb_e || !a.Alb_p || !a.Tlb) return false;
-    if (B < lb_min_batch(feature)) return false;
+    if (B < lb_min_batch(feature)) {
+        // small batches: hidden-sliced (SYN_LB_SLICED: bit f - 7 enables features.f).  Measured (us, tiled -> sliced): B = 128: features.12 / 13 / 14
+        // 42 / 40 / 25 -> 25 / 29 / 21, features.8-11 20-22 -> 17-20; B = 512: 47 / 46 / 30 -> 42 / 42 / 31, but features.8-11 24-28 -> 27-32:
+        // the narrow blocks only up to 192 faces.
+        static const int sliced = getenv("SYN_LB_SLICED") ? atoi(getenv("SYN_LB_SLICED")) : 0xFE;
+        static const int sl_min = getenv("SYN_LB_SLICED_MIN") ? atoi(getenv("SYN_LB_SLICED_MIN")) : 32;
+        static const int narrow_max = getenv("SYN_LB_SLICED_NARROW_MAX") ? atoi(getenv("SYN_LB_SLICED_NARROW_MAX")) : 192;
+        if (B < sl_min || !((sliced >> (feature - 7)) & 1) || (feature < 12 && B > narrow_max)) return false;
+        switch (feature) {
+            case 8: case 9: case 10: return launch_lb_sliced<L8>(a, B, s);
+            case 11: return launch_lb_sliced<L11>(a, B, s);
+            case 12: case 13: return launch_lb_sliced<L12>(a, B, s);
+            case 14: return launch_lb_sliced<L14>(a, B, s);
+            default: return false;
+        }
+    }
     switch (feature) {
         case 7: {
             const LbStageArgs sa{a.X, a.Alb_e, a.Tlb, a.Alb_p, a.p_shift, a.Y};
