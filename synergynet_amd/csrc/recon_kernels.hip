@@ -505,7 +505,7 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
-    static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 3072;
+    static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 1664;   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
     static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
     // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
     auto run = [&](int lo, int hi, bool fast) {
