@@ -804,7 +804,8 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 // The chain launch: mode 0 = off (one launch per block), 1 = features.8-13, 2 = features.8-14, 3 = features.7-14 (SYN_LB_CHAIN; default 3)
 int lb_chain_mode(int B) {
     static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
-    if (chain <= 0 || B < 768) return 0;
+    static const int chain_min = getenv("SYN_LB_CHAIN_MIN") ? atoi(getenv("SYN_LB_CHAIN_MIN")) : 384;      // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
+    if (chain <= 0 || B < chain_min) return 0;
     return chain > 3 ? 3 : chain;
 }
 // a[i] = the arguments of features.(first + i), first = 7 | 8, first + n_blocks - 1 = 13 | 14; false: not applicable

@@ -369,7 +369,7 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
 }
 
 static int lb4_min_batch() {
-    static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 768;     // fewer faces: not enough workgroups of four
+    static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
     return min_b;
 }
 

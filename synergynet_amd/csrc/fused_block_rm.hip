@@ -560,10 +560,12 @@ int rm_threshold(const char *env, int dflt) {
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p) return false;
-    // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N; SYN_RM_MIN<f>_<U> override them)
+    // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N; SYN_RM_MIN<f>_<U> override them).  The kernels are
+    // persistent over 256 workgroups: 513 faces is where the smaller configuration needs a second round of workgroups (B = 640, us: features.2
+    // 123 -> 91, features.4 74 -> 52, features.5/6 51 / 49 -> 43 / 42 with the larger one; at B = 512 the smaller one wins: 66 / 42 / 36 vs 88 / 50 / 41)
     switch (feature) {
         case 2:
-            if (B >= rm_threshold("SYN_RM_MIN2_4", 768)) { launch_rm<R2<4>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN2_4", 513)) { launch_rm<R2<4>>(a, B, s, 1); return true; }
             if (B >= rm_threshold("SYN_RM_MIN2_2", 352)) { launch_rm<R2<2>>(a, B, s, 1); return true; }
             return false;
         case 3:
@@ -571,12 +573,12 @@ bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStrea
             if (B >= rm_threshold("SYN_RM_MIN3_1", 200)) { launch_rm<R3<1>>(a, B, s, 1); return true; }
             return false;
         case 4:
-            if (B >= rm_threshold("SYN_RM_MIN4_2", 768)) { launch_rm<R4<2>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN4_2", 513)) { launch_rm<R4<2>>(a, B, s, 1); return true; }
             if (B >= rm_threshold("SYN_RM_MIN4_1", 480)) { launch_rm<R4<1>>(a, B, s, 1); return true; }
             return false;
         case 5:
         case 6:
-            if (B >= rm_threshold("SYN_RM_MIN5_2", 768)) { launch_rm<R5<2>>(a, B, s, 1); return true; }
+            if (B >= rm_threshold("SYN_RM_MIN5_2", 513)) { launch_rm<R5<2>>(a, B, s, 1); return true; }
             return false;
         default: return false;
     }

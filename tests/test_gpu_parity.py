@@ -215,7 +215,7 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
     assert torch.equal(got, ref[idx.cuda()])
 
 
-@pytest.mark.parametrize('B', [33, 128, 200, 224, 352, 353, 480, 511, 768, 769, 1030, 2307])
+@pytest.mark.parametrize('B', [33, 128, 200, 224, 352, 353, 383, 385, 480, 511, 513, 575, 577, 640, 768, 769, 1030, 2307])
 def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_early, backbone_sd, B):
     """The early blocks switch kernels with the batch size (tiled below a few hundred faces, row-marching with 1, 2 or 4 units
     per workgroup above: fused_block_rm.hip / stem_rm.hip launchers; B = 2307: more units than persistent workgroups, i.e. several
