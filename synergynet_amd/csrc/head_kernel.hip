@@ -357,7 +357,7 @@ void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift,
         head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);
         return;
     }
-    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 1024;      // four faces per CU from here on
+    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;       // (B = 640 / 768 / 896: 60 / 62 / 61 -> 47 / 48 / 48 us; B = 512: the two-face workgroups, 49 us)
     if (B >= wide_min) {
         head_bf16x3_kernel<1, 4, 8><<<(B + 3) / 4, 512, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
         return;
