@@ -725,7 +725,7 @@ void fused_block_lb_kernel(LbStageArgs sa, int B, unsigned long long *prof = nul
 #endif
 using L8 = LbCfg<      64, 384,  64, true,  2, SYN_L8_PPF>;     // features.8-10
 using L11 = LbCfg<     64, 384,  96, false, 2, SYN_L11_PPF>;     // features.11
-using L12 = LbCfg<     96, 576,  96, true,  1, 2>;     // features.12, 13
+using L12 = LbCfg<     96, 576,  96, true,  1, 3>;     // features.12, 13
 using L14 = LbCfg<     96, 576, 160, false, 1, 2, 2, true>;   // features.14 (stride 2: 8x8 -> 4x4)
 
 // features.7 .. 14 of a face in ONE launch: 7 (32 -> 192 -> 64, stride 2, 15x15 -> 8x8), 8, 9, 10 (64 -> 384 -> 64, residual),
