@@ -1,4 +1,7 @@
-// Register-resident fused inverted-residual block for the 8x8 MobileNetV2 blocks (features.8-13).
+// Register-resident fused inverted-residual blocks for the 8x8 MobileNetV2 blocks (features.8-13), the two stride-2 blocks around them
+// (features.7: 15x15 -> 8x8, lb7_stage; features.14: 8x8 -> 4x4, LbCfg::S2) and the CHAIN kernel that runs features.7-14 of a face in one
+// launch (fused_chain_lb_kernel: a block = one stage, the block output handed to the next stage as MFMA fragments through LDS); for
+// small batches the same stage hidden-sliced over several workgroups (PARTIAL + lb_reduce_kernel).
 // Reference: backbone_nets/mobilenetv2_backbone.py:45-74 (InvertedResidual.forward), :33-42 (ConvBNReLU).
 //
 // The tiled kernel (fused_block_bf3.hip) walks the hidden width in chunks behind two workgroup barriers per chunk and moves
