@@ -144,3 +144,30 @@ def test_synthetic_assets_are_deterministic():
     p, q = synth.make_3dmm(9, n_vert=300), synth.make_3dmm(9, n_vert=300)
     assert all(np.array_equal(p[k], q[k]) for k in p)
     assert len(set(int(v) // 3 for v in p['keypoints'])) == 68
+
+
+def test_documented_knobs_exist_in_the_sources():
+    """Every environment knob INTEGRATION.md / DESIGN.md name (SYN_* / SYNERGY_HIP_*) is read somewhere in the library, the bench or the tools --
+    a renamed knob must not survive in the documentation."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ''
+    for pat in ('synergynet_amd/csrc/*', 'synergynet_amd/*.py', 'bench.py', 'tools/*', '__graft_entry__.py', 'tests/*.py'):
+        for f in glob.glob(os.path.join(root, pat)):
+            if os.path.isfile(f) and not f.endswith(('.so', '.o')):
+                try:
+                    src += open(f, errors='replace').read()
+                except OSError:
+                    pass
+    missing = []
+    for doc in ('INTEGRATION.md', 'DESIGN.md'):
+        text = open(os.path.join(root, doc)).read()
+        for knob in sorted(set(re.findall(r'\b(SYN(?:ERGY_HIP)?_[A-Z0-9_]*[A-Z0-9])\b', text))):
+            stem = re.sub(r'_?<[^>]*>.*$', '', knob)
+            if knob.endswith('_MIN') and knob + '<' in text:          # SYN_LB_MIN<f>: the feature number is appended at run time
+                stem = knob
+            if stem not in src:
+                missing.append(f'{doc}: {knob}')
+    assert not missing, missing
