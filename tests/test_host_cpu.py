@@ -171,3 +171,24 @@ def test_documented_knobs_exist_in_the_sources():
             if stem not in src:
                 missing.append(f'{doc}: {knob}')
     assert not missing, missing
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r2/bench_b1024.json is a bench.py line from the GPU box: the fields the driver and the judge read must be there and consistent
+    (whole-job value = faces per step / step time, roofline fraction = achieved / peak, a bounded CPU baseline with its core count)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, 'profiles', 'r2', 'bench_b1024.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+              'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    B = d['config']['global_batch']
+    assert abs(d['value'] - B / d['ms_per_step'] * 1e3) / d['value'] < 1e-3
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and 0 < r['frac'] < 1
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
