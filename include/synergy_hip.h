@@ -67,6 +67,23 @@ size_t syn_backbone_flat_count(void);
  * per-channel scale/shift and the weights are repacked for the kernels. */
 int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats);
 
+/* Range safety of the fp16 arithmetic.  Every GEMM of the default schedule carries its fp32 operands as two fp16 pieces (22-bit
+ * significand, fp32 accumulation); fp16's exponent range is 2^-14 .. 65504, and the reference loads ARBITRARY checkpoints
+ * (synergy3DMM.py:156-164).  syn_load_backbone therefore bounds, from the folded constants alone, every tensor that is split at run
+ * time (interval arithmetic: hidden activations are in [0,6] after ReLU6, project outputs and residual sums follow from the weights)
+ * and checks every packed weight row; a block whose bound does not fit runs the tiled fp16 kernel at input scale 1 or the exact
+ * fp32-MFMA kernel instead (csrc/synergy_abi.hip analyze_mbv2_ranges).  The verdict travels with exported constants.
+ * syn_numerics_report: one text line per .features[] index into buf (NUL terminated, truncated to n); returns the number of
+ * blocks that do NOT run the default kernel (0 = the whole network is inside the fp16 window), or a negative syn_status. */
+int syn_numerics_report(syn_handle *h, char *buf, size_t n);
+
+/* ResNet-50 (ReLU, no static activation bound): the fp16 convolutions are guarded at RUN time.  Every tensor they split reports
+ * max |x| into a per-forward status array; when one leaves [2^-10, 6e4] the head kernel returns NaN for that forward (loud, no host
+ * synchronisation).  syn_backbone_range_status synchronises the device, copies the maxima of the last forward (slot 0 = max-pool
+ * output, 1 + i = convolution i in state_dict order; unguarded slots read 1) and returns the number of tensors outside the window;
+ * with fallback != 0 a violation switches the handle to the exact fp32-MFMA convolutions for all later forwards.  0 for MobileNetV2. */
+int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, int fallback);
+
 /* BASELINE config 5: the ResNet-50 backbone (reference backbone_nets/resnet_backbone.py:139-254, resnet50 :304-312).
  * `flat` = conv1.weight, bn1.{weight,bias,running_mean,running_var}, then per block of layer1..layer4:
  * conv1, bn1, conv2, bn2, conv3, bn3, [downsample.0, downsample.1], then fc_tex, fc_ori, fc_shape, fc_exp

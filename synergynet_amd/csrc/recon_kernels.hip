@@ -213,9 +213,10 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
 // basis is split by the host, alpha by the prologue kernel) and each block product is rebuilt from three partial products
 // a a + a b + b a (b b <= 2^-22 dropped; fp16 x fp16 is exact in fp32, fp32 accumulation).  K = 48 runs as 3 steps of 16 = 27 MFMAs
 // per face tile and wave (the exact 3-way bf16 split used before: 54; the fp32-input MFMA: 78 of 64 cycles), plus ONE more MFMA
-// whose K slots carry the partial products of the last two expression columns and of the mean shape.  fp16's exponent range: the
-// basis (and mean shape) are scaled by one power of two Sb (host: max |.| in [2^13, 2^14)), each face's coefficient vector by its
-// own power of two Sa (prologue: max |alpha| in [2^13, 2^14)), and 1 / (Sa Sb) is folded into the face's pose matrix.
+// whose K slots carry the partial products of the last two expression columns and of the mean shape.  fp16's exponent range: every
+// basis COLUMN k (and the mean shape) is scaled by its own power of two 2^e_k (host: max |column| in [2^13, 2^14)), coefficient k by
+// 2^-e_k (folded into its de-whitening constants: exact), each face's scaled coefficient vector by its own power of two Sa
+// (prologue: max in [2^13, 2^14)), and 1 / Sa is folded into the face's pose matrix.  Nothing but the split itself rounds.
 // =====================================================================================
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8r __attribute__((ext_vector_type(8)));
@@ -261,11 +262,18 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
     const float a49 = ok ? pp[12 + 49] * stdv[12 + 49] + mean[12 + 49] : 0.f;
     amax = fmaxf(amax, fmaxf(fabsf(a48), fabsf(a49)));
     amax = fmaxf(amax, __shfl_xor(amax, 32));                            // the other half of the face's coefficients
+    // `mean` / `stdv` are the COLUMN-SCALED de-whitening constants (synergy_abi.hip pack_basis): al[] = alpha_k 2^-e_k for the basis
+    // column's own power of two 2^e_k, and cu = 2^-e_u is the coefficient of the scaled mean shape -- it takes part in the maximum
+    const float cu = mean[62];
+    amax = fmaxf(amax, cu);
     int ex = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xff) - 126;     // amax = m 2^ex, m in [0.5, 1)
     ex = 14 - ex;
-    ex = amax > 0.f ? (ex < -14 ? -14 : (ex > 14 ? 14 : ex)) : 0;         // Sa itself must be an fp16 number (it multiplies the mean)
+    // cu Sa is an operand of the fourth k-step: it must be a normal fp16 number (>= 2^-14; <= 2^14 holds because cu <= amax)
+    const int ex_cu = (int)((__builtin_bit_cast(unsigned, cu) >> 23) & 0xff) - 127;   // cu = 2^ex_cu
+    ex = ex < -14 - ex_cu ? -14 - ex_cu : ex;
+    ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
     const float Sa = __builtin_bit_cast(float, (unsigned)(127 + ex) << 23);
-    const float Sb = mean[62], inv_ab = mean[63] * __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);
+    const float inv_ab = __builtin_bit_cast(float, (unsigned)(127 - ex) << 23);  // the column scales cancel in every product: only Sa is left
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) {
         u32x4 pc[2];
@@ -282,17 +290,16 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
     // 0; the other half is zero) carry the three split partial products of column 48, of column 49 and the two pieces of the mean
     // times Sa:
     //   basis side   [b48a b48a b48b | b49a b49a b49b | ua ub]
-    //   alpha side   [a48a a48b a48a | a49a a49b a49a | Sa Sa]
+    //   alpha side   [a48a a48b a48a | a49a a49b a49a | cu Sa, cu Sa]
     {
         unsigned a, b2;
         split2r(a48 * Sa, a49 * Sa, a, b2);                              // low half = piece of a48, high half = piece of a49
         const unsigned a8 = a & 0xffffu, b8 = b2 & 0xffffu, a9 = a >> 16, b9 = b2 >> 16;
-        const unsigned sa16 = ok ? (__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(Sa, Sa)) & 0xffffu) : 0u;
+        const unsigned sa16 = ok ? (__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(cu * Sa, cu * Sa)) & 0xffffu) : 0u;   // a power of two: exact
         u32x4 fx = {0u, 0u, 0u, 0u};
         if (hh == 0) fx = (u32x4){a8 | (b8 << 16), a8 | (a9 << 16), b9 | (a9 << 16), sa16 | (sa16 << 16)};
         *(u32x4 *)&rt[(6 * 64 + l) * 4] = fx;
     }
-    (void)Sb;
     if (hh == 0) {
         float r[16];
         float p12[12];
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
             }
             float m0 = p12[4 * c + 0], m1 = p12[4 * c + 1], m2 = p12[4 * c + 2], t = p12[4 * c + 3];
             if (transform && c == 1) { m0 = -m0; m1 = -m1; m2 = -m2; t = (float)(kImg + 1) - t; }
-            r[3 * c + 0] = m0 * sc * inv_ab; r[3 * c + 1] = m1 * sc * inv_ab; r[3 * c + 2] = m2 * sc * inv_ab;     // the MFMA result is Sa Sb x the shape
+            r[3 * c + 0] = m0 * sc * inv_ab; r[3 * c + 1] = m1 * sc * inv_ab; r[3 * c + 2] = m2 * sc * inv_ab;     // the MFMA result is Sa x the shape
             r[9 + c] = t * sc + of;
         }
         r[12] = 0.f; r[13] = 0.f; r[14] = 0.f; r[15] = 0.f;

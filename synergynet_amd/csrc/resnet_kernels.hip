@@ -20,6 +20,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Requires Cin % 16 == 0 and Cout % 4 == 0 (true for every ResNet-50 convolution after the stem).
 // act: 0 none, 1 ReLU (applied AFTER the residual add: out = relu(bn3(conv3) + identity), resnet_backbone.py:130-134).
 // =====================================================================================
+// Run-time range guard of the fp16 x2 convolutions (ReLU networks have no static activation bound: synergy_abi.hip run_resnet50):
+// every kernel whose output a later convolution splits into fp16 pieces folds max |output| into its slot of a per-forward status
+// array -- one v_max per output element, one wave reduction and ONE atomic per wave.  Non-negative floats order like their bit
+// patterns, so the atomic is an unsigned max.  pool_fc_generic_kernel poisons its results with NaN when a slot left the fp16 window.
+__device__ __forceinline__ void range_note(float *stat, float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(stat), __builtin_bit_cast(unsigned, m));
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in, const float *__restrict__ W,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                       int act, int n_tiles, int m_tiles) {
+                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int nt_idx = q % n_tiles;
     const int mt_idx = (q / n_tiles) * 8 + xcd;
@@ -241,6 +251,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
     // then the arithmetic and the stores.  Interleaved, each residual load sat between two stores and its wait (vmcnt is in
     // order, and conservative around the `if`) covered the previous store's acknowledgement: 8 serialised round trips per tile.
     f32x4 scv[NT], shv[NT], rsv[MT][NT];
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         int n = n0 + i * 16 + 4 * g;
@@ -266,7 +277,9 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__
             }
             acc[j][i] = v;
             asm volatile("" : "+v"(acc[j][i]));         // (keeps the arithmetic from being sunk into the store's branch)
+            if (stat && m0 + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
+    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + i * 16 + 4 * g;
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                       int act, int n_tiles, int m_tiles) {
+                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
     constexpr int CH_DW = NT * KS * 2 * 256;                     // one chunk of fragments: [tile NT][step KS][piece 2][64][4]
     constexpr int NPW = NT * KS * 2 / 4;                         // fragments per wave and chunk
     static_assert(NT * KS * 2 % 4 == 0, "a quarter of a chunk per wave");
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
     if (m0 >= M) return;
     // epilogue as conv_bf3_kernel: loads first (branch-free), then arithmetic, then stores
     f32x4 scv[NT], shv[NT], rsv[MT][NT];
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         int n = n0 + i * 16 + 4 * g;
@@ -413,7 +427,9 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
             }
             acc[j][i] = v;
             asm volatile("" : "+v"(acc[j][i]));
+            if (stat && m0 + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
+    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + i * 16 + 4 * g;
@@ -430,39 +446,39 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
 template <int MT, int NT, int KS>
 static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                              hipStream_t s) {
+                              hipStream_t s, float *stat) {
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     conv_h2s_kernel<MT, NT, KS><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                                     act, n_tiles, m_tiles);
+                                                     act, n_tiles, m_tiles, stat);
 }
 
 template <int MT, int NT>
 static void launch_conv_bf3_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                              hipStream_t s) {
+                              hipStream_t s, float *stat) {
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     conv_bf3_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                                 act, n_tiles, m_tiles);
+                                                 act, n_tiles, m_tiles, stat);
 }
 
 void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s) {
+                     hipStream_t s, float *stat) {
     const int M = B * Hout * Hout;
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
     static const int shared = getenv("SYN_CONV_SHARED") ? atoi(getenv("SYN_CONV_SHARED")) : 1;     // 0: every wave fetches its own fragments
     if (shared && N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
-        if (tiles >= 1024) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
-        else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+        if (tiles >= 1024) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         return;
     }
-    if (tiles >= 1024) launch_conv_bf3_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
-    else launch_conv_bf3_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+    if (tiles >= 1024) launch_conv_bf3_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    else launch_conv_bf3_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
 }
 
 // =====================================================================================
@@ -515,9 +531,9 @@ void launch_resnet_stem(const float *img, const uint8_t *img8, const float *w, c
 
 // MaxPool2d(kernel 3, stride 2, padding 1) (resnet_backbone.py:172), NHWC; padding never wins the max (-inf).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ in, float *__restrict__ out, long total,
-                                                           int Hin, int Hout, int C4) {
+                                                           int Hin, int Hout, int C4, float *__restrict__ stat) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+    if (idx >= total) { if (stat) range_note(stat, 0.f); return; }       // (whole waves take part in the reduction)
     const int c4 = (int)(idx % C4);
     long p = idx / C4;
     const int ox = (int)(p % Hout);
@@ -538,19 +554,28 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
         }
     }
     *(f32x4 *)&out[(size_t)idx * 4] = m;
+    if (stat) range_note(stat, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fabsf(m[2]), fabsf(m[3]))));
 }
 
-void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s) {
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat) {
     const long total = (long)B * Hout * Hout * (C / 4);
-    maxpool3x3s2_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, total, Hin, Hout, C / 4);
+    maxpool3x3s2_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, total, Hin, Hout, C / 4, stat);
 }
 
 // adaptive_avg_pool2d -> flatten -> linear heads (resnet_backbone.py:236-246): feat [B,P,C] NHWC, Wfc [n_out][C].
 __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__restrict__ feat, const float *__restrict__ Wfc,
                                                               const float *__restrict__ bias, float *__restrict__ param,
-                                                              float *__restrict__ pool, int P, int C, int n_out, int out_stride) {
+                                                              float *__restrict__ pool, int P, int C, int n_out, int out_stride,
+                                                              const float *__restrict__ stat, int n_stat) {
     __shared__ __attribute__((aligned(16))) float sp[2048];
     const int b = blockIdx.x;
+    // range guard: a tensor that some fp16 x2 convolution split left the fp16 window (kRangeHi / kRangeLo) -> the results of this
+    // forward are NOT fp32-class: make that loud (NaN) instead of returning plausible numbers
+    float poison = 0.f;
+    for (int i = 0; i < n_stat; ++i) {
+        const float m = stat[i];
+        if (!(m <= kRangeHi) || !(m >= kRangeLo)) poison = __builtin_nanf("");
+    }
     const float *f = feat + (size_t)b * P * C;
     const float inv = 1.0f / (float)P;
     for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
         for (int p = 0; p < P; ++p) a += *(const f32x4 *)&f[(size_t)p * C + 4 * c4];
         a *= inv;
         *(f32x4 *)&sp[4 * c4] = a;
-        if (pool) *(f32x4 *)&pool[(size_t)b * C + 4 * c4] = a;
+        if (pool) *(f32x4 *)&pool[(size_t)b * C + 4 * c4] = a + poison;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -572,13 +597,13 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-        if (lane == 0) param[(size_t)b * out_stride + o] = a + bias[o];
+        if (lane == 0) param[(size_t)b * out_stride + o] = a + bias[o] + poison;
     }
 }
 
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
-                            int C, int n_out, int out_stride, hipStream_t s) {
-    pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride);
+                            int C, int n_out, int out_stride, hipStream_t s, const float *stat, int n_stat) {
+    pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride, stat, n_stat);
 }
 
 // =====================================================================================

@@ -129,9 +129,13 @@ void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, cons
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
                  int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s);
 // same conv on the bf16 matrix pipe (exact 3-way operand split): W3 [N/16][taps*Cin/32][3][64][4] dwords, Cin % 32 == 0
+// stat (nullable): one float of the per-forward range-guard array -- max |output| is folded into it (resnet_kernels.hip range_note)
 void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s);
+                     hipStream_t s, float *stat = nullptr);
+// window of a tensor's max |x| inside which the fp16 x2 split of an UNSCALED activation keeps >= 15 bits relative to that maximum:
+// above kRangeHi v_cvt_pkrtz_f16_f32 saturates, below kRangeLo even the largest element's low piece is a 4-bit subnormal
+constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 // 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,
@@ -139,9 +143,9 @@ void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const 
 // zero; weights / 128 x S (power of two) as two fp16 pieces; s_shift [64] = BN shift - 255/256 * sum of the scaled filter, then {S, 1/S}
 constexpr int rn_stem_dwords() { return 2 * 10 * 2 * 256 + 64 + 4; }
 bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s);
-void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s);
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat = nullptr);
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
-                            int C, int n_out, int out_stride, hipStream_t s);
+                            int C, int n_out, int out_stride, hipStream_t s, const float *stat = nullptr, int n_stat = 0);
 
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):
@@ -154,11 +158,12 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
 
 // Same contraction on v_mfma_f32_32x32x16_f16 (two fp16 pieces per operand, three partial products).
 //   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 2][lane 64][4 dwords] for k = 0..47
-//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), scaled by the power of two Sb (mean62[62], 1/Sb in
-//           mean62[63]), then one more [lane 64][4] fragment: a fourth k16 step whose slots carry the split partial products of
-//           columns 48, 49 and the mean (recon_prep_b3_kernel).
+//           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), column k scaled by its own power of two 2^e_k, then one
+//           more [lane 64][4] fragment: a fourth k16 step whose slots carry the split partial products of columns 48, 49 and the
+//           mean (recon_prep_b3_kernel).  mean62 / std62 here are the COLUMN-SCALED de-whitening constants (entries 12..61 x 2^-e_k,
+//           mean62[62] = 2^-e_u, the coefficient of the scaled mean shape): synergy_abi.hip pack_basis.
 //   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces (x the face's power of two Sa) in the same lane order (faces), the
-//           matching fourth-step fragment, then 32 x 16 fp32 records M[9] / (Sa Sb) | T[3] | 0 x 4.
+//           matching fourth-step fragment, then 32 x 16 fp32 records M[9] / Sa | T[3] | 0 x 4.
 constexpr int kBasisB3 = (3 * 2 + 1) * 256;
 constexpr int kRecTileB3 = (3 * 2 + 1) * 256 + 32 * 16;
 constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)

@@ -73,6 +73,7 @@ struct Net {
     size_t src_fc = 0;
     size_t packed_count = 0;    // floats in the packed device blob
     size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_b3 = 0;   // dst_head_b3: features.18 weights as 2 fp16 pieces (dwords) + their power-of-two scale
+    size_t dst_range = 0;                                 // 64 dwords: {unsafe1, unsafe16 (bit masks), in_bound[20], min_wmean[20], w_relerr[20]}
     size_t max_io = 0, max_hidden = 0;   // per-face activation floats (block in/out, expanded)
     double flops = 0, pw_flops = 0;
     Net() {
@@ -172,6 +173,7 @@ struct Net {
         dst_fc_w = dst; dst += 64 * 1280;
         dst_fc_b = dst; dst += 64;
         dst_head_b3 = dst; dst += (size_t)80 * 10 * 2 * 256 + 4;        // fragments, then {S, 1/S}
+        dst_range = dst; dst += 64;                                      // the verdict of analyze_mbv2_ranges (RangeInfo), travels with the blob
         packed_count = dst;
         flops += 2.0 * 1280 * 62;
     }
@@ -193,7 +195,7 @@ struct RBlock { int c1, c2, c3, ds; };
 struct ResNet50 {
     std::vector<RConv> convs;      // convs[0] = stem
     std::vector<RBlock> blocks;
-    size_t flat_count = 0, packed_count = 0, src_fc = 0, dst_fc_w = 0, dst_fc_b = 0;
+    size_t flat_count = 0, packed_count = 0, src_fc = 0, dst_fc_w = 0, dst_fc_b = 0, dst_range = 0;
     size_t buf_big = 0, buf_mid = 0;   // per-face floats: block in/out/identity/stem, bottleneck intermediates
     double flops = 0;
     ResNet50() {
@@ -240,6 +242,7 @@ struct ResNet50 {
         flat_count = src;
         dst_fc_w = dst; dst += (size_t)104 * 2048;
         dst_fc_b = dst; dst += 104;
+        dst_range = dst; dst += 4;                    // 2 dwords: bit i = the packed fp16 x2 weights of convs[i] fail the weight criterion -> fp32-MFMA conv
         packed_count = dst;
         flops += 2.0 * 2048 * 102;
     }
@@ -257,6 +260,17 @@ struct ConstHeader {   // first 256 bytes of an exported constants buffer
 };
 static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
 constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
+constexpr uint32_t kConstVersion = 2;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict)
+
+// verdict of the load-time range analysis of the fp16 x2 schedule (analyze_mbv2_ranges below); 64 dwords at Net::dst_range
+struct RangeInfo {
+    uint32_t unsafe1 = 0, unsafe16 = 0;      // bit f: .features[f] must not run an fp16 x2 kernel with input scale 1 / 16 (bit 0 = stem + features.1)
+    float in_bound[20] = {};                  // max_k U_k of the input of .features[f] (f = 2..18); [0] = 1 (normalised pixels)
+    float min_wmean[20] = {};                 // min over rows of the weighted mean bound (underflow side)
+    float w_relerr[20] = {};                  // worst row of the weight criterion, as a multiple of its threshold (> 1 fails)
+};
+
+static_assert(sizeof(RangeInfo) <= 64 * sizeof(float), "RangeInfo must fit its slot in the backbone blob");
 
 }  // namespace
 
@@ -283,20 +297,27 @@ struct syn_handle {
     int early_rm = 1023;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
+    float *d_range = nullptr;      // resnet50 run-time range guard: [64] per-tensor max |x| of the last forward | [64] its initial values
+    uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
+    int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
+    RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
+    int range_guard = 1;           // SYNERGY_HIP_RANGE_GUARD=0: ignore the verdict (tests use it to show that the adversarial cases do break the unguarded schedule)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
                                    // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
 };
 
 namespace {
 
-size_t basis_float_count(int nvp, int nlp) {        // fp32 tiles | mean, std | bf16 x3 tiles (dense, landmark)
-    return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 128 + (size_t)((nvp + nlp) / 32) * 3 * syn::kBasisB3;
+size_t basis_float_count(int nvp, int nlp) {        // fp32 tiles | mean, std | column-scaled mean, std | fp16 x2 tiles (dense, landmark)
+    return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 256 + (size_t)((nvp + nlp) / 32) * 3 * syn::kBasisB3;
 }
 const float *basis_dense(const syn_handle *h) { return h->d_basis; }
 const float *basis_lmk(const syn_handle *h) { return h->d_basis + (size_t)h->nvp * 3 * syn::kBasisK; }
 const float *basis_mean(const syn_handle *h) { return h->d_basis + (size_t)(h->nvp + h->nlp) * 3 * syn::kBasisK; }
 const float *basis_std(const syn_handle *h) { return basis_mean(h) + 64; }
-const unsigned *basis3_dense(const syn_handle *h) { return reinterpret_cast<const unsigned *>(basis_mean(h) + 128); }
+const float *basis_mean_cs(const syn_handle *h) { return basis_mean(h) + 128; }     // de-whitening constants of the fp16 x2 path: entries 12..61
+const float *basis_std_cs(const syn_handle *h) { return basis_mean(h) + 192; }      // x 2^-e_k (per basis column), [62] of the mean copy = 2^-e_u
+const unsigned *basis3_dense(const syn_handle *h) { return reinterpret_cast<const unsigned *>(basis_mean(h) + 256); }
 const unsigned *basis3_lmk(const syn_handle *h) { return basis3_dense(h) + (size_t)(h->nvp / 32) * 3 * syn::kBasisB3; }
 
 size_t ws_floats_per_face() {
@@ -366,16 +387,25 @@ static float f16_value(unsigned h) {
     return (h & 0x8000u) ? -v : v;
 }
 
+// the packers' power-of-two scale of a layer: max |w| S in [2^13, 2^14), the exponent clamped so that S, 6 S and S x shift stay far
+// inside fp32 whatever the checkpoint holds (a layer that hits the clamp fails the weight criterion of analyze_mbv2_ranges)
+static float pow2_scale(float mx) {
+    int ex = 0;
+    if (mx > 0.f && std::isfinite(mx)) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+    ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+    return ldexpf(1.0f, ex);
+}
 
-// fp16 x2 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3); every entry x Sb
+// fp16 x2 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3); column k (50 = the mean shape)
+// x colscale[k], the column's own power of two
 void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
-                         const int64_t *rows, float Sb) {
+                         const int64_t *rows, const float *colscale /*[51]*/) {
     auto wfull = [&](int v, int c, int k) -> float {
         if (v >= n_rows_valid) return 0.f;
         const size_t row = rows ? (size_t)rows[3 * v + c] : (size_t)3 * v + c;
-        if (k < 40) return w_shp[row * 40 + k] * Sb;
-        if (k < 50) return w_exp[row * 10 + (k - 40)] * Sb;
-        return u[row] * Sb;
+        if (k < 40) return w_shp[row * 40 + k] * colscale[k];
+        if (k < 50) return w_exp[row * 10 + (k - 40)] * colscale[k];
+        return u[row] * colscale[50];
     };
     auto split = [](float x, unsigned (&pc)[2]) {
         pc[0] = f16_rtz(x);
@@ -423,6 +453,9 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     float *H2 = H1 + (size_t)B * n.max_hidden;
     const float *P = h->d_backbone;
     const size_t nl = n.layers.size();
+    // load-time range verdict (analyze_mbv2_ranges): bit f set -> .features[f] must not run an fp16 x2 kernel with input scale 1 / 16
+    const unsigned u1 = h->range_guard ? h->ri.unsafe1 : 0u, u16 = h->range_guard ? (h->ri.unsafe16 | h->ri.unsafe1) : 0u;
+    auto any_unsafe16 = [&](int first, int last) { for (int f = first; f <= last; ++f) if ((u16 >> f) & 1u) return true; return false; };
     auto mark = [&](int feature) {          // profiling hook: one event after every launch
         if (!marks) return;
         hipEvent_t e;
@@ -438,7 +471,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused network head: stem conv + features.1 (dw + linear project) in one launch
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            if (h->fusion >= 2 && img8 && (h->early_rm & 8) &&
+            if (h->fusion >= 2 && img8 && (h->early_rm & 8) && !(u1 & 1u) &&
                 syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 2 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
                                     reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s)) {
                 li += 2;
@@ -463,7 +496,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         const int chain_mode = (h->fusion >= 2 && L.kind == PW && L.relu6 && (L.feature == 7 || L.feature == 8) && (h->early_rm & 128) && (h->early_rm & 512) &&
                                 prof_feature < 0) ? syn::lb_chain_mode(B) : 0;
         const int chain_first = chain_mode == 3 ? 7 : 8, chain_last = chain_mode == 1 ? 13 : 14, chain_n = chain_last - chain_first + 1;
-        if (chain_mode && L.feature == chain_first && (stop_feature < 0 || stop_feature >= chain_last) && li + 3 * chain_n <= nl &&
+        if (chain_mode && L.feature == chain_first && !any_unsafe16(chain_first, chain_last) && (stop_feature < 0 || stop_feature >= chain_last) && li + 3 * chain_n <= nl &&
             n.max_hidden >= 2048 + 2 * (size_t)64 * 96 + 16 * 160 + 64 * 64) {
             // Workgroups run through the stages unsynchronised, so a buffer must never hold two tensor layouts at once -- a fast workgroup's
             // 96-channel store into X would land in the 64-channel rows a slower workgroup still reads.  X keeps the chain input; the
@@ -499,7 +532,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             }
         }
         // features.15-17 as one chain launch (fused_block_lb4.hip); only features.17's output goes to global memory
-        if (h->fusion >= 2 && L.kind == PW && L.relu6 && L.feature == 15 && L.dst_glb && (h->early_rm & 256) && (h->early_rm & 512) && prof_feature < 0 &&
+        if (h->fusion >= 2 && L.kind == PW && L.relu6 && L.feature == 15 && L.dst_glb && !any_unsafe16(15, 17) && (h->early_rm & 256) && (h->early_rm & 512) && prof_feature < 0 &&
             (stop_feature < 0 || stop_feature >= 17) && li + 9 <= nl) {
             syn::FusedBlockArgs ca[3];
             bool ok = true;
@@ -529,21 +562,22 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
                                   P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
             if (prof_feature == L.feature) a.prof = prof;
-            if (h->fusion >= 2 && L.dst_wb3 && Pj.dst_wb3) {
+            const bool ok1 = !((u1 >> L.feature) & 1u), ok16 = !((u16 >> L.feature) & 1u);     // fp16 x2 kernels allowed at input scale 1 / 16
+            if (h->fusion >= 2 && ok1 && L.dst_wb3 && Pj.dst_wb3) {
                 a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
                 a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
             }
             if (h->fusion >= 2 && L.dst_scl && Pj.dst_scl) { a.scl_e = P + L.dst_scl; a.scl_p = P + Pj.dst_scl; }
-            if (h->fusion >= 2 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
+            if (h->fusion >= 2 && ok1 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
                 a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
                 a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
             }
-            if (h->fusion >= 2 && a.We3 && Pj.dst_wlb && L.dst_tlb && (h->early_rm & 128)) {
+            if (h->fusion >= 2 && ok16 && a.We3 && Pj.dst_wlb && L.dst_tlb && (h->early_rm & 128)) {
                 a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
                 a.Alb_e = reinterpret_cast<const unsigned *>(P + L.dst_weh);
                 a.Tlb = P + L.dst_tlb;
             }
-            if (h->fusion >= 2 && L.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + L.dst_glb);
+            if (h->fusion >= 2 && ok16 && L.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + L.dst_glb);
             a.scratch = H2; a.scratch_floats = (size_t)B * n.max_hidden;       // (the per-layer schedule's second hidden buffer: free here)
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
@@ -567,7 +601,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             // input: expanded H1, or the block input X for the t=1 block (no expand conv, :58-60)
             const bool has_expand = li > 0 && n.layers[li - 1].kind == PW && n.layers[li - 1].feature == L.feature;
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
-        } else if (L.feature == 18 && h->fusion >= 2 && stop_feature != 18) {
+        } else if (L.feature == 18 && h->fusion >= 2 && !((u1 >> 18) & 1u) && stop_feature != 18) {
             syn::launch_head_bf16x3(X, reinterpret_cast<const unsigned *>(P + n.dst_head_b3), sh, P + n.dst_fc_w, P + n.dst_fc_b,
                                     param, pool, H1, B, s);
             mark(19);
@@ -600,6 +634,27 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     return SYN_OK;
 }
 
+// slot of the range-guard array a ResNet-50 tensor reports into: 0 = the max-pool output, 1 + i = the output of convs[i]; only
+// tensors that a later fp16 x2 convolution splits take part (not the downsample branches -- added in fp32 -- nor the last block's
+// output, which goes to the pool)
+constexpr int kResnetStat = 54;
+bool resnet_stat_used(int slot) {
+    const ResNet50 &n = resnet50();
+    if (slot == 0) return true;
+    const int ci = slot - 1;
+    if (ci <= 0 || ci >= (int)n.convs.size()) return false;           // (the stem's output is seen through the max-pool)
+    for (const RBlock &b : n.blocks) if (b.ds == ci) return false;
+    return ci != n.blocks.back().c3;
+}
+int ensure_range(syn_handle *h) {
+    if (h->d_range) return SYN_OK;
+    HIP_TRY(hipMalloc((void **)&h->d_range, 128 * sizeof(float)));
+    float init[128];
+    for (int i = 0; i < 64; ++i) init[i] = init[64 + i] = (i < kResnetStat && resnet_stat_used(i)) ? 0.0f : 1.0f;
+    HIP_TRY(hipMemcpy(h->d_range, init, sizeof init, hipMemcpyHostToDevice));
+    return SYN_OK;
+}
+
 int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, float *param, float *pool, hipStream_t s,
                  int n_out = 62) {
     const ResNet50 &n = resnet50();
@@ -608,10 +663,24 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     float *A = h->ws, *X = A + (size_t)B * n.buf_big, *Y = X + (size_t)B * n.buf_big, *D = Y + (size_t)B * n.buf_big;
     float *T1 = D + (size_t)B * n.buf_big, *T2 = T1 + (size_t)B * n.buf_mid;
     const float *P = h->d_backbone;
-    auto conv = [&](const RConv &c, const float *in, const float *res, float *out, int act) {
-        if (h->fusion >= 2 && c.dst_w3) {
+    // ReLU activations have no static bound, so the fp16 x2 convolutions are guarded at run time: every tensor they split reports
+    // its max |x| (resnet_kernels.hip range_note), the head kernel turns the results into NaN when one left [kRangeLo, kRangeHi],
+    // and syn_backbone_range_status() lets the host switch the handle to the exact fp32-MFMA convolutions for good.
+    const bool f16 = h->fusion >= 2 && !h->resnet_fp32;
+    const bool guard = f16 && h->range_guard;
+    float *stat = nullptr;
+    if (guard) {
+        rc = ensure_range(h);
+        if (rc) return rc;
+        stat = h->d_range;
+        HIP_TRY(hipMemcpyAsync(stat, stat + 64, 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    auto conv = [&](int ci, const float *in, const float *res, float *out, int act) {
+        const RConv &c = n.convs[ci];
+        if (f16 && c.dst_w3 && !(h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u))) {
             syn::launch_conv_bf3(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
-                                 c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s);
+                                 c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s,
+                                 stat && resnet_stat_used(1 + ci) ? stat + 1 + ci : nullptr);
             return;
         }
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
@@ -622,17 +691,17 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
           syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
         syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
-    syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s);                                                    // maxpool (:234)
+    syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat);                                              // maxpool (:234)
     for (const RBlock &b : n.blocks) {                     // Bottleneck.forward (:114-136)
-        conv(n.convs[b.c1], X, nullptr, T1, 1);
-        conv(n.convs[b.c2], T1, nullptr, T2, 1);
+        conv(b.c1, X, nullptr, T1, 1);
+        conv(b.c2, T1, nullptr, T2, 1);
         const float *identity = X;
-        if (b.ds >= 0) { conv(n.convs[b.ds], X, nullptr, D, 0); identity = D; }
-        conv(n.convs[b.c3], T2, identity, Y, 1);           // out = relu(bn3(conv3) + identity)
+        if (b.ds >= 0) { conv(b.ds, X, nullptr, D, 0); identity = D; }
+        conv(b.c3, T2, identity, Y, 1);                    // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;
     }
     // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
-    syn::launch_pool_fc_generic(X, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, 16, 2048, n_out, n_out, s);
+    syn::launch_pool_fc_generic(X, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, 16, 2048, n_out, n_out, s, stat, stat ? kResnetStat : 0);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
 }
@@ -653,11 +722,13 @@ int syn_create(int device, syn_handle **out) {
     h->device = device;
     if (const char *e = getenv("SYNERGY_HIP_FUSION")) h->fusion = atoi(e);
     if (const char *e = getenv("SYNERGY_HIP_EARLY_RM")) h->early_rm = atoi(e);
+    if (const char *e = getenv("SYNERGY_HIP_RANGE_GUARD")) h->range_guard = atoi(e);
     *out = h;
     return SYN_OK;
 }
 
 int syn_destroy(syn_handle *h) {
+    if (h && h->d_range) { DeviceGuard g(h->device); (void)hipFree(h->d_range); h->d_range = nullptr; }
     if (!h) return SYN_OK;
     DeviceGuard g(h->device);
     if (h->d_backbone) (void)hipFree(h->d_backbone);
@@ -681,9 +752,168 @@ int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 
 
 // Host-only packing of the MobileNetV2 state (BN folding, MFMA lane order, bf16 x3 split): shared by syn_load_backbone and
 // syn_pack_constants_host, so a blob packed without a device is byte-identical to what a handle exports.
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Load-time range analysis of the fp16 x2 schedule (csrc/*: every GEMM operand is carried as two fp16 pieces).
+// fp16 has a 5-bit exponent: an operand above 65504 saturates silently in v_cvt_pkrtz_f16_f32, one below 2^-14 loses its low
+// piece.  The weights are scaled per layer by the packer; the ACTIVATIONS that are split at run time are the block inputs (the
+// linear, unbounded project outputs and their residual sums) at a fixed scale s: 1 in the row-marching / tiled / head kernels, 16 in
+// the register-resident 8x8 / 4x4 kernels (fused_block_lb.hip, fused_block_lb4.hip).  From the folded constants alone:
+//   * interval arithmetic per channel: hidden activations are in [0, 6] after ReLU6 (tighter where weights and shift say so), a
+//     project output n is in shift_n + [sum_k min(w_nk lo_k, w_nk hi_k), sum_k max(...)], the residual stream adds intervals;
+//   * OVERFLOW (a proof): a block may run an fp16 x2 kernel with input scale s only if s max_k U_k <= 6e4, U_k = max(|lo_k|, |hi_k|);
+//   * UNDERFLOW (an estimate; the bound U may exceed the true activations by the usual slack of interval arithmetic, taken as <= 2^8):
+//     the split of x_k errs by at most max(2^-20 |x_k|, 2^-24 / s); row n of the consuming GEMM keeps >= 14 bits if its weighted
+//     mean bound  (sum_k |w_nk| U_k + |shift_n|) / sum_k |w_nk|  is >= 1 / (4 s);
+//   * WEIGHTS (exact: the packed pieces are re-read): row n of a layer passes if sum_k |w_nk S - (a_nk + b_nk)| <=
+//     2^-17 (sum_k |w_nk| S + |shift_n| S / X), X = the bound of the layer's input -- rows far below the layer's largest lose
+//     their low piece to fp16 subnormals.
+// A block that fails at s = 16 but passes at s = 1 runs the tiled fp16 x2 kernel (fused_block_bf3.hip); one that fails at s = 1
+// runs the exact fp32-MFMA kernel (fused_block.hip / stem_block1.hip / head_kernel.hip: the SYNERGY_HIP_FUSION=1 schedule).
+// The verdict travels with the constants (ConstHeader) and is reported by syn_numerics_report().
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Itv { float lo, hi; };
+
+static void analyze_mbv2_ranges(const float *flat, RangeInfo &ri) {
+    const Net &n = net();
+    auto bn = [&](const Layer &L, std::vector<float> &sc, std::vector<float> &sh) {
+        const size_t wn = L.kind == STEM ? 32 * 27 : L.kind == DW ? (size_t)L.cout * 9 : (size_t)L.cout * L.cin;
+        const float *gamma = flat + L.src_w + wn, *beta = gamma + L.cout, *mean = beta + L.cout, *var = mean + L.cout;
+        sc.resize(L.cout); sh.resize(L.cout);
+        for (int c = 0; c < L.cout; ++c) { sc[c] = gamma[c] * (1.0f / sqrtf(var[c] + 1e-5f)); sh[c] = beta[c] - mean[c] * sc[c]; }
+    };
+    auto clip6 = [](Itv v) { return Itv{fminf(fmaxf(v.lo, 0.f), 6.f), fminf(fmaxf(v.hi, 0.f), 6.f)}; };
+    // y_n = shift_n + sum_k w_nk x_k (w already BN-folded), x_k in in[k]
+    auto gemm_itv = [&](const float *w, const std::vector<float> &sc, const std::vector<float> &sh, int N, int K, const std::vector<Itv> &in,
+                        std::vector<Itv> &out) {
+        out.resize(N);
+        for (int nn = 0; nn < N; ++nn) {
+            double lo = sh[nn], hi = sh[nn];
+            for (int k = 0; k < K; ++k) {
+                const double ww = (double)w[(size_t)nn * K + k] * sc[nn], a = ww * in[k].lo, b = ww * in[k].hi;
+                lo += a < b ? a : b; hi += a < b ? b : a;
+            }
+            out[nn] = Itv{(float)lo, (float)hi};
+        }
+    };
+    // depthwise 3x3 with zero padding: a tap sees its channel's interval or the padding zero
+    auto dw_itv = [&](const float *w, const std::vector<float> &sc, const std::vector<float> &sh, int C, const std::vector<Itv> &in, std::vector<Itv> &out) {
+        out.resize(C);
+        for (int c = 0; c < C; ++c) {
+            const double l = fminf(in[c].lo, 0.f), u = fmaxf(in[c].hi, 0.f);
+            double lo = sh[c], hi = sh[c];
+            for (int t = 0; t < 9; ++t) {
+                const double ww = (double)w[(size_t)c * 9 + t] * sc[c], a = ww * l, b = ww * u;
+                lo += a < b ? a : b; hi += a < b ? b : a;
+            }
+            out[c] = Itv{(float)lo, (float)hi};
+        }
+    };
+    auto umax = [](const std::vector<Itv> &v) { float m = 0.f; for (const Itv &i : v) m = fmaxf(m, fmaxf(fabsf(i.lo), fabsf(i.hi))); return m; };
+    // the packer's scale of a layer (the same arithmetic as pack_backbone_mbv2) and the weight criterion on the pieces it produces
+    auto weight_check = [&](const float *w, const std::vector<float> &sc, const std::vector<float> &sh, int N, int K, float pre, float xbound) {
+        float mx = 0.f;
+        for (int nn = 0; nn < N; ++nn)
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * K + k] * sc[nn] * pre));
+        int ex = 0;
+        if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+        if (!std::isfinite(mx) || ex > 100 || ex < -100) return 1e30f;          // S (or 6 S, S x shift) leaves fp32's comfortable range
+        const float S = ldexpf(1.0f, ex);
+        float worst = 0.f;
+        for (int nn = 0; nn < N; ++nn) {
+            double err = 0, mag = 0;
+            for (int k = 0; k < K; ++k) {
+                const float x = w[(size_t)nn * K + k] * sc[nn] * pre * S;
+                const unsigned a = f16_rtz(x);
+                const unsigned b = f16_rtz(x - f16_value(a));
+                err += fabs((double)x - (double)f16_value(a) - (double)f16_value(b));
+                mag += fabs((double)x);
+            }
+            mag += fabs((double)sh[nn]) * S / (xbound > 0.f ? xbound : 1.f);
+            if (mag > 0) worst = fmaxf(worst, (float)(err / (mag * 7.62939453125e-6)));      // 2^-17
+        }
+        return worst;
+    };
+    auto wmean_check = [&](const float *w, const std::vector<float> &sc, const std::vector<float> &sh, int N, int K, const std::vector<Itv> &in) {
+        float worst = 3.0e38f;
+        for (int nn = 0; nn < N; ++nn) {
+            double sw = 0, swu = 0;
+            for (int k = 0; k < K; ++k) {
+                const double aw = fabs((double)w[(size_t)nn * K + k] * sc[nn]);
+                sw += aw; swu += aw * fmaxf(fabsf(in[k].lo), fabsf(in[k].hi));
+            }
+            if (sw > 0) worst = fminf(worst, (float)((swu + fabs((double)sh[nn])) / sw));
+        }
+        return worst;
+    };
+    std::vector<float> sc, sh;
+    std::vector<Itv> x, e, d, y;
+    const size_t nl = n.layers.size();
+    auto verdict = [&](int f, float ubound, float wmean, float werr) {
+        ri.in_bound[f] = ubound; ri.min_wmean[f] = wmean; ri.w_relerr[f] = fmaxf(ri.w_relerr[f], werr);
+        const bool bad_w = !(werr <= 1.0f);
+        if (bad_w || !(ubound <= 6.0e4f) || !(wmean >= 0.25f)) ri.unsafe1 |= 1u << f;
+        if (bad_w || !(16.0f * ubound <= 6.0e4f) || !(16.0f * wmean >= 0.25f)) ri.unsafe16 |= 1u << f;
+    };
+    for (size_t li = 0; li < nl; ++li) {
+        const Layer &L = n.layers[li];
+        const float *w = flat + L.src_w;
+        if (L.kind == STEM) {            // pixels (p - 127.5) / 128 in [-255/256, 255/256]; stem + features.1 = one kernel
+            bn(L, sc, sh);
+            std::vector<Itv> px(27, Itv{-255.0f / 256.0f, 255.0f / 256.0f});
+            gemm_itv(w, sc, sh, 32, 27, px, e);
+            for (Itv &v : e) v = clip6(v);
+            float werr = weight_check(w, sc, sh, 32, 27, 1.0f / 128.0f, 255.0f);      // stem_rm.hip: filter / 128 against raw bytes
+            const Layer &D = n.layers[li + 1], &P = n.layers[li + 2];
+            std::vector<float> dsc, dsh;
+            bn(D, dsc, dsh);
+            dw_itv(flat + D.src_w, dsc, dsh, D.cout, e, d);
+            for (Itv &v : d) v = clip6(v);
+            bn(P, sc, sh);
+            gemm_itv(flat + P.src_w, sc, sh, P.cout, P.cin, d, x);
+            werr = fmaxf(werr, weight_check(flat + P.src_w, sc, sh, P.cout, P.cin, 1.0f, 6.0f));
+            ri.in_bound[0] = 1.0f; ri.min_wmean[0] = 1.0f; ri.w_relerr[0] = werr;
+            if (!(werr <= 1.0f)) { ri.unsafe1 |= 1u; ri.unsafe16 |= 1u; }
+            li += 2;
+            continue;
+        }
+        if (L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {       // inverted-residual block: expand (li), dw, project
+            const Layer &D = n.layers[li + 1], &P = n.layers[li + 2];
+            const int f = L.feature;
+            bn(L, sc, sh);
+            const float ub = umax(x);
+            const float wm = wmean_check(w, sc, sh, L.cout, L.cin, x);
+            float werr = weight_check(w, sc, sh, L.cout, L.cin, 1.0f, ub);
+            gemm_itv(w, sc, sh, L.cout, L.cin, x, e);
+            for (Itv &v : e) v = clip6(v);
+            std::vector<float> dsc, dsh;
+            bn(D, dsc, dsh);
+            dw_itv(flat + D.src_w, dsc, dsh, D.cout, e, d);
+            for (Itv &v : d) v = clip6(v);
+            bn(P, sc, sh);
+            gemm_itv(flat + P.src_w, sc, sh, P.cout, P.cin, d, y);
+            werr = fmaxf(werr, weight_check(flat + P.src_w, sc, sh, P.cout, P.cin, 1.0f, 6.0f));
+            if (P.residual) for (int c = 0; c < P.cout; ++c) { y[c].lo += x[c].lo; y[c].hi += x[c].hi; }
+            verdict(f, ub, wm, werr);
+            x.swap(y);
+            li += 2;
+            continue;
+        }
+        if (L.kind == PW && L.feature == 18) {                                      // features.18 + pool + heads (head_kernel.hip), s = 1
+            bn(L, sc, sh);
+            verdict(18, umax(x), wmean_check(w, sc, sh, L.cout, L.cin, x), weight_check(w, sc, sh, L.cout, L.cin, 1.0f, umax(x)));
+        }
+    }
+}
+
 static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
     const Net &n = net();
     pk.assign(n.packed_count, 0.f);
+    {
+        RangeInfo ri;
+        analyze_mbv2_ranges(flat, ri);
+        memcpy(pk.data() + n.dst_range, &ri, sizeof ri);
+    }
     for (const Layer &L : n.layers) {
         const float *w = flat + L.src_w;
         size_t wn = L.kind == STEM ? 32 * 27 : L.kind == DW ? (size_t)L.cout * 9 : (size_t)L.cout * L.cin;
@@ -757,9 +987,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 float mx = 0.f;
                 for (int nn = 0; nn < L.cout; ++nn)
                     for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
-                int ex = 0;
-                if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-                const float S = ldexpf(1.0f, ex);
+                                const float S = pow2_scale(mx);
                 pk[L.dst_scl] = S; pk[L.dst_scl + 1] = 1.0f / S; pk[L.dst_scl + 2] = 6.0f * S;
                 const int ntl = round_up(L.cout, 16) / 16, kch = L.cin / 32;
                 for (int nt = 0; nt < ntl; ++nt)
@@ -783,9 +1011,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             float mx = 0.f;
             for (int nn = 0; nn < L.cout; ++nn)
                 for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
-            int ex = 0;
-            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-            const float S = ldexpf(1.0f, ex);                      // (= the scale the row-marching fragments of this layer use: dst_scl)
+                        const float S = pow2_scale(mx);                      // (= the scale the row-marching fragments of this layer use: dst_scl)
             auto put2 = [&](size_t frag, int lane, int d, float x0, float x1) {
                 const unsigned a0 = f16_rtz(x0 * S), a1 = f16_rtz(x1 * S);
                 const unsigned b0 = f16_rtz(x0 * S - f16_value(a0)), b1 = f16_rtz(x1 * S - f16_value(a1));
@@ -825,9 +1051,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             float mx = 0.f;
             for (int co = 0; co < 32; ++co)
                 for (int t = 0; t < 27; ++t) mx = fmaxf(mx, fabsf(w[co * 27 + t] * bn_scale[co] * (1.0f / 128.0f)));
-            int ex = 0;
-            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-            const float S = ldexpf(1.0f, ex);
+                        const float S = pow2_scale(mx);
             for (int st = 0; st < 2; ++st)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int d = 0; d < 4; ++d) {
@@ -867,9 +1091,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 float mx = 0.f;
                 for (int nn = 0; nn < L.cout; ++nn)
                     for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
-                int ex = 0;
-                if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-                S = ldexpf(1.0f, ex);
+                                S = pow2_scale(mx);
                 pk[L.dst_scl] = S; pk[L.dst_scl + 1] = 1.0f / S; pk[L.dst_scl + 2] = 6.0f * S;
             }
             const int hid = expand ? L.cout : L.cin, ng = (hid + 31) / 32, ks = expand ? (L.cin + 15) / 16 : 2;
@@ -926,9 +1148,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 const float sc = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
                 for (int k = 0; k < P.cin; ++k) { v[(size_t)nn * P.cin + k] = w[(size_t)nn * P.cin + k] * sc; mx = fmaxf(mx, fabsf(v[(size_t)nn * P.cin + k])); }
             }
-            int e = 0;
-            if (mx > 0.f) { (void)frexpf(mx, &e); e = 14 - e; }            // mx * 2^e in [2^13, 2^14)
-            const float S = ldexpf(1.0f, e);
+            const float S = pow2_scale(mx);                                // mx * S in [2^13, 2^14)
             for (float &x : v) x *= S;
             return S;
         };
@@ -1006,9 +1226,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             sc[nn] = gamma[nn] * (1.0f / sqrtf(var[nn] + 1e-5f));
             for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * sc[nn]));
         }
-        int ex = 0;
-        if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-        const float S = ldexpf(1.0f, ex);
+                const float S = pow2_scale(mx);
         pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256] = S;
         pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256 + 1] = 1.0f / S;
         for (int nt = 0; nt < 80; ++nt)
@@ -1050,7 +1268,57 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
     if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
     h->arch = 0;
+    memcpy(&h->ri, pk.data() + n.dst_range, sizeof h->ri);
     return SYN_OK;
+}
+
+// Verdict of the load-time range analysis (see analyze_mbv2_ranges) as text + counts; include/synergy_hip.h.
+int syn_numerics_report(syn_handle *h, char *buf, size_t n) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_numerics_report: NULL handle");
+    std::string out;
+    char line[256];
+    int n_fallback = 0;
+    if (!h->d_backbone) out = "no backbone loaded\n";
+    else if (h->arch == 1) {
+        for (int i = 0; i < 64; ++i) n_fallback += (h->resnet_w_unsafe[i >> 5] >> (i & 31)) & 1u;
+        snprintf(line, sizeof line, "resnet50: %d convolution(s) fail the fp16x2 weight criterion -> fp32-MFMA kernel; activations (ReLU) have no static bound: "
+                 "guarded at run time (syn_backbone_range_status)%s\n", n_fallback, h->resnet_fp32 ? "; the guard has switched this handle to fp32-MFMA convolutions" : "");
+        out = line;
+        if (h->resnet_fp32) n_fallback = 53;
+    }
+    else {
+        const RangeInfo &r = h->ri;
+        for (int f = 0; f <= 18; ++f) {
+            if (f == 1) continue;
+            const bool b1 = (r.unsafe1 >> f) & 1u, b16 = ((r.unsafe16 | r.unsafe1) >> f) & 1u, uses16 = f >= 7 && f <= 17;
+            const char *sched = b1 ? "fp32-MFMA (exact) kernel" : (uses16 && b16) ? "fp16x2 tiled kernel, input scale 1" : "fp16x2";
+            if (b1 || (uses16 && b16)) ++n_fallback;
+            snprintf(line, sizeof line, "features.%s%d: input bound %.4g, min weighted-mean bound %.4g, weight criterion %.3g x threshold -> %s\n",
+                     f == 0 ? "0-" : "", f == 0 ? 1 : f, (double)r.in_bound[f], (double)r.min_wmean[f], (double)r.w_relerr[f], sched);
+            out += line;
+        }
+        if (!h->range_guard) out += "SYNERGY_HIP_RANGE_GUARD=0: the verdict is NOT applied\n";
+    }
+    if (buf && n) { snprintf(buf, n, "%s", out.c_str()); }
+    return n_fallback;
+}
+
+// resnet50 run-time range guard (see run_resnet50): synchronises the device, copies max |x| of every guarded tensor of the LAST
+// forward into layer_max[0 .. max_layers) (slot 0 = max-pool output, 1 + i = conv i in state_dict order; unguarded slots read 1)
+// and returns how many left the fp16 window.  fallback != 0 and a violation: the handle runs the exact fp32-MFMA convolutions
+// from now on (sticky until the next syn_load_backbone_resnet50 / syn_import_constants).  mobilenet_v2 handles return 0.
+int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, int fallback) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_backbone_range_status: NULL handle");
+    if (h->arch != 1 || !h->d_range) return 0;
+    DeviceGuard g(h->device);
+    float st[64];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(st, h->d_range, sizeof st, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < kResnetStat; ++i) bad += !(st[i] <= syn::kRangeHi) || !(st[i] >= syn::kRangeLo);
+    for (int i = 0; layer_max && i < max_layers && i < 64; ++i) layer_max[i] = st[i];
+    if (bad && fallback) h->resnet_fp32 = 1;
+    return bad;
 }
 
 size_t syn_resnet50_flat_count(void) { return resnet50().flat_count; }
@@ -1082,9 +1350,7 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                 const float a = gamma[co] * (1.0f / sqrtf(var[co] + 1e-5f));
                 for (int t = 0; t < 147; ++t) mx = fmaxf(mx, fabsf(w[(size_t)co * 147 + t] * a * (1.0f / 128.0f)));
             }
-            int ex = 0;
-            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-            const float S = ldexpf(1.0f, ex);
+                        const float S = pow2_scale(mx);
             for (int G = 0; G < 2; ++G)
                 for (int st = 0; st < 10; ++st)
                     for (int lane = 0; lane < 64; ++lane)
@@ -1117,11 +1383,28 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
             const int kch = c.cin / 32, steps = taps * kch, K = taps * c.cin;
             float mx = 0.f;
             for (size_t i = 0; i < (size_t)c.cout * K; ++i) mx = fmaxf(mx, fabsf(dw[i]));
-            int ex = 0;
-            if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-            const float S = ldexpf(1.0f, ex);
+                        const float S = pow2_scale(mx);
             float *tail = pk.data() + c.dst_w3 + (size_t)(c.cout / 16) * steps * 512;
             tail[0] = S; tail[1] = 1.0f / S;
+            {   // weight criterion of analyze_mbv2_ranges on the BN-less weights (the BN scale is applied in fp32 by the epilogue):
+                // a row whose pieces err by more than 2^-17 of its L1 norm sends the whole convolution to the fp32-MFMA kernel
+                bool bad = !std::isfinite(mx);
+                for (int nn = 0; nn < c.cout && !bad; ++nn) {
+                    double err = 0, mag = 0;
+                    for (int k = 0; k < K; ++k) {
+                        const float x = dw[(size_t)nn * K + k] * S;
+                        const unsigned a = f16_rtz(x), b = f16_rtz(x - f16_value(a));
+                        err += fabs((double)x - (double)f16_value(a) - (double)f16_value(b));
+                        mag += fabs((double)x);
+                    }
+                    bad = err > mag * 7.62939453125e-6;
+                }
+                if (bad) {
+                    const int ci = (int)(&c - n.convs.data());
+                    uint32_t *m = reinterpret_cast<uint32_t *>(pk.data() + n.dst_range);
+                    m[ci >> 5] |= 1u << (ci & 31);
+                }
+            }
             for (int nt = 0; nt < c.cout / 16; ++nt)
                 for (int st = 0; st < steps; ++st)
                     for (int lane = 0; lane < 64; ++lane)
@@ -1167,6 +1450,9 @@ int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats
     HIP_TRY(hipMalloc((void **)&h->d_backbone, n.packed_count * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
     h->arch = 1;
+    h->ri = RangeInfo{};
+    h->resnet_fp32 = 0;
+    memcpy(h->resnet_w_unsafe, pk.data() + n.dst_range, sizeof h->resnet_w_unsafe);
     return SYN_OK;
 }
 
@@ -1181,18 +1467,30 @@ static void pack_basis(const float *w_shp, const float *w_exp, const float *u, c
     float *ms = pk.data() + (size_t)(nvp + nlp) * 3 * syn::kBasisK;
     memcpy(ms, param_mean, sizeof(float) * 62);
     memcpy(ms + 64, param_std, sizeof(float) * 62);
-    // power-of-two scale of the fp16 pieces of the basis: max over w_shp, w_exp and u in [2^13, 2^14)
-    float mx = 0.f;
-    for (size_t i = 0; i < (size_t)3 * n_vert * 40; ++i) mx = fmaxf(mx, fabsf(w_shp[i]));
-    for (size_t i = 0; i < (size_t)3 * n_vert * 10; ++i) mx = fmaxf(mx, fabsf(w_exp[i]));
-    for (size_t i = 0; i < (size_t)3 * n_vert; ++i) mx = fmaxf(mx, fabsf(u[i]));
-    int ex = 0;
-    if (mx > 0.f) { (void)frexpf(mx, &ex); ex = 14 - ex; }
-    const float Sb = ldexpf(1.0f, ex);
-    ms[62] = Sb; ms[63] = 1.0f / Sb;
-    unsigned *b3 = reinterpret_cast<unsigned *>(ms + 128);
-    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr, Sb);
-    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints, Sb);
+    // fp16 x2 path: EVERY basis column k (and the mean shape u, k = 50) gets its own power of two 2^e_k with max_rows |column| 2^e_k in
+    // [2^13, 2^14), so that its entries sit at the top of fp16's exponent range whatever the column's magnitude (BFM-like packs: u ~ 1e5
+    // next to PCA directions ~ 1e-3: under ONE common scale the latter fell into fp16 subnormals and kept ~13 bits).  The inverse
+    // 2^-e_k is folded into the de-whitening constants of coefficient k (alpha_k 2^-e_k = p (std_k 2^-e_k) + mean_k 2^-e_k: exact, a
+    // power of two commutes with the fp32 rounding), the mean shape's coefficient becomes 2^-e_u; the products are unchanged.
+    float colscale[51], colinv[51];
+    for (int k = 0; k < 51; ++k) {
+        float mx = 0.f;
+        if (k < 40) { for (size_t r = 0; r < (size_t)3 * n_vert; ++r) mx = fmaxf(mx, fabsf(w_shp[r * 40 + k])); }
+        else if (k < 50) { for (size_t r = 0; r < (size_t)3 * n_vert; ++r) mx = fmaxf(mx, fabsf(w_exp[r * 10 + (k - 40)])); }
+        else { for (size_t r = 0; r < (size_t)3 * n_vert; ++r) mx = fmaxf(mx, fabsf(u[r])); }
+        int ex = 0;
+        if (mx > 0.f && std::isfinite(mx)) { (void)frexpf(mx, &ex); ex = 14 - ex; }
+        ex = ex < -60 ? -60 : (ex > 60 ? 60 : ex);          // (keeps alpha 2^-e and 2^-e_u comfortably inside fp32)
+        colscale[k] = ldexpf(1.0f, ex); colinv[k] = ldexpf(1.0f, -ex);
+    }
+    float *mcs = ms + 128, *scs = ms + 192;
+    memcpy(mcs, param_mean, sizeof(float) * 62);
+    memcpy(scs, param_std, sizeof(float) * 62);
+    for (int k = 0; k < 50; ++k) { mcs[12 + k] *= colinv[k]; scs[12 + k] *= colinv[k]; }
+    mcs[62] = colinv[50];                                   // coefficient of the (scaled) mean shape
+    unsigned *b3 = reinterpret_cast<unsigned *>(ms + 256);
+    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr, colscale);
+    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints, colscale);
 }
 
 int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u, const float *param_mean,
@@ -1246,7 +1544,7 @@ int syn_pack_constants_host(int arch, const float *backbone_flat, size_t n_float
     if (has_bb) { if (arch == 1) pack_backbone_resnet50(backbone_flat, bb); else pack_backbone_mbv2(backbone_flat, bb); }
     if (has_basis) pack_basis(w_shp, w_exp, u, param_mean, param_std, keypoints, n_lmk, n_vert, bs);
     ConstHeader hd{};
-    hd.magic = kMagic; hd.version = 1;
+    hd.magic = kMagic; hd.version = kConstVersion;
     hd.has_backbone = has_bb; hd.has_basis = has_basis;
     if (has_basis) { hd.n_vert = n_vert; hd.n_lmk = n_lmk; hd.nvp = round_up(n_vert, 32); hd.nlp = round_up(n_lmk, 32); }
     hd.arch = has_bb ? arch : 0;
@@ -1262,7 +1560,8 @@ int syn_pack_constants_host(int arch, const float *backbone_flat, size_t n_float
 namespace {
 // the acceptance checks of a constants blob, on a host copy of its header; shared by the device import and the host twin
 int check_const_header(const ConstHeader &hd, size_t bytes, const char *who) {
-    if (hd.magic != kMagic || hd.version != 1) return fail(SYN_ERR_INVALID, "%s: bad magic/version", who);
+    if (hd.magic != kMagic) return fail(SYN_ERR_INVALID, "%s: bad magic", who);
+    if (hd.version != kConstVersion) return fail(SYN_ERR_INVALID, "%s: constants blob version %u, this library packs version %u", who, hd.version, kConstVersion);
     if (hd.total_bytes > bytes) return fail(SYN_ERR_INVALID, "%s: header says %llu bytes, buffer has %zu", who,
                                             (unsigned long long)hd.total_bytes, bytes);
     if (hd.has_backbone && (hd.arch > 1 || hd.backbone_floats != backbone_floats((int)hd.arch)))
@@ -1295,7 +1594,7 @@ int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *strea
     const size_t need = syn_constants_bytes(h);
     if (bytes < need) return fail(SYN_ERR_INVALID, "syn_export_constants: buffer %zu < %zu bytes", bytes, need);
     ConstHeader hd{};
-    hd.magic = kMagic; hd.version = 1;
+    hd.magic = kMagic; hd.version = kConstVersion;
     hd.has_backbone = h->d_backbone ? 1 : 0; hd.has_basis = h->d_basis ? 1 : 0;
     hd.n_vert = h->n_vert; hd.n_lmk = h->n_lmk; hd.nvp = h->nvp; hd.nlp = h->nlp;
     hd.arch = h->arch;
@@ -1331,6 +1630,16 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
         h->arch = (int)hd.arch;
         if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, hd.backbone_floats * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(h->d_backbone, d, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+        h->ri = RangeInfo{};
+        h->resnet_fp32 = 0;
+        h->resnet_w_unsafe[0] = h->resnet_w_unsafe[1] = 0;
+        if (h->arch == 0) {          // the sender's verdict on its weights rides in the blob
+            HIP_TRY(hipMemcpyAsync(&h->ri, d + net().dst_range * sizeof(float), sizeof h->ri, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(h->resnet_w_unsafe, d + resnet50().dst_range * sizeof(float), sizeof h->resnet_w_unsafe, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         d += hd.backbone_floats * sizeof(float);
     }
     if (hd.has_basis) {
@@ -1493,7 +1802,7 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
     float *rec = h->rec;
     hipStream_t s = (hipStream_t)stream;
     if (h->fusion >= 2)
-        syn::launch_reconstruct_b3(param, basis_mean(h), basis_std(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
+        syn::launch_reconstruct_b3(param, basis_mean_cs(h), basis_std_cs(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
                                    roi, transform, out, row_pitch, pad_writable, B, s, rec);
     else
         syn::launch_reconstruct(param, basis_mean(h), basis_std(h), dense ? basis_dense(h) : basis_lmk(h), n, dense ? h->nvp : h->nlp,

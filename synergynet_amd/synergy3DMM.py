@@ -43,6 +43,7 @@ def parse_param_62(param):
 
 
 _HDR_MAGIC = 0x53594e4833353558          # "SYNH355X" (csrc/synergy_abi.hip ConstHeader)
+_HDR_VERSION = 2                         # kConstVersion: bumped whenever the packed encoding changes
 
 
 def parse_constants_header(raw: bytes) -> dict:
@@ -53,7 +54,7 @@ def parse_constants_header(raw: bytes) -> dict:
     if len(raw) < 256:
         raise ValueError(f'constants blob: {len(raw)} bytes is smaller than the 256-byte header')
     magic, version, has_bb, has_basis, n_vert, n_lmk, nvp, nlp, arch, bb_fl, basis_fl, total = struct.unpack_from('<Q8I3Q', raw, 0)
-    if magic != _HDR_MAGIC or version != 1:
+    if magic != _HDR_MAGIC or version != _HDR_VERSION:
         raise ValueError('constants blob: bad magic/version')
     if has_bb and arch > 1:
         raise ValueError(f'constants blob: unknown backbone arch {arch}')
@@ -151,6 +152,7 @@ class SynergyNet(nn.Module):
         self.data_param = None
         self._n_vert = self._n_lmk = 0
         self._have_backbone = self._have_basis = False
+        self._range_checked = False
         if not load_constants:          # constants arrive later through import_constants() (synergynet_amd/dist.py)
             self.eval()
             from . import inference
@@ -230,6 +232,44 @@ class SynergyNet(nn.Module):
             assert flat.size == self._lib.syn_backbone_flat_count()
             abi.check(self._lib.syn_load_backbone(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._have_backbone = True
+        self._range_checked = False
+        self._warn_numerics()
+
+    def _guarded(self, launch):
+        """Runs a backbone launch.  ResNet-50 has no static activation bound, so its fp16 convolutions are guarded at run time
+        (include/synergy_hip.h syn_backbone_range_status): the FIRST forward after a weight load is checked on the host, and a tensor
+        outside the fp16 window switches the handle to the exact fp32-MFMA convolutions and repeats the launch; any later forward that
+        leaves the window returns NaN (checked on the device, no synchronisation) -- call `range_status(fallback=True)` then."""
+        launch()
+        if self.arch == 'resnet50' and not self._range_checked:
+            self._range_checked = True
+            if self.range_status(fallback=True)[0] > 0:
+                warnings.warn('SynergyNet(resnet50): activations leave the range of the fp16x2 convolutions; '
+                              'this model now runs the exact fp32-MFMA convolutions')
+                launch()
+
+    def range_status(self, fallback=False):
+        """(number of guarded tensors outside the fp16 window in the last forward, per-tensor max |x| [54]); synchronises."""
+        mx = np.ones(64, dtype=np.float32)
+        n = self._lib.syn_backbone_range_status(self._h, mx.ctypes.data_as(C.c_void_p), 64, int(fallback))
+        if n < 0:
+            abi.check(n)
+        return n, mx[:54]
+
+    def numerics_report(self):
+        """(number of blocks that do not run the default fp16x2 kernel, text) -- the load-time range verdict on the loaded weights
+        (include/synergy_hip.h syn_numerics_report): fp16 operands must stay inside 2^-14 .. 65504."""
+        buf = C.create_string_buffer(8192)
+        n = self._lib.syn_numerics_report(self._h, buf, len(buf))
+        if n < 0:
+            abi.check(n)
+        return n, buf.value.decode()
+
+    def _warn_numerics(self):
+        n, text = self.numerics_report()
+        if n > 0:
+            bad = '\n'.join(l for l in text.splitlines() if not l.endswith('-> fp16x2'))
+            warnings.warn(f'SynergyNet: {n} block(s) of the loaded weights leave the range of the fp16x2 kernels and run a slower exact schedule:\n{bad}')
 
     def load_weights(self, path):
         """reference synergy3DMM.py:156-164: torch checkpoint {'state_dict': ...} with DataParallel
@@ -268,6 +308,8 @@ class SynergyNet(nn.Module):
             # the blob decides which backbone the C handle now runs: follow it, or pool buffers would be sized for the wrong one
             self.arch = ('mobilenet_v2', 'resnet50')[hdr['arch']]
             self._have_backbone = True
+            self._range_checked = False
+            self._warn_numerics()
         if hdr['has_basis']:
             self._n_vert, self._n_lmk = hdr['n_vert'], hdr['n_lmk']
             self._have_basis = True
@@ -296,8 +338,8 @@ class SynergyNet(nn.Module):
         with torch.cuda.device(self.device):
             param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
             pool = torch.empty((B, self.pool_dim), dtype=torch.float32, device=self.device) if return_pool else None
-            abi.check(self._lib.syn_backbone_forward(self._h, x.data_ptr(), B, param.data_ptr(),
-                                                     pool.data_ptr() if return_pool else None, self._stream()))
+            self._guarded(lambda: abi.check(self._lib.syn_backbone_forward(self._h, x.data_ptr(), B, param.data_ptr(),
+                                                                          pool.data_ptr() if return_pool else None, self._stream())))
         if was_cpu:
             param = param.cpu()
             pool = pool.cpu() if return_pool else None
@@ -315,8 +357,8 @@ class SynergyNet(nn.Module):
         with torch.cuda.device(self.device):
             param = torch.empty((B, 62), dtype=torch.float32, device=self.device)
             pool = torch.empty((B, self.pool_dim), dtype=torch.float32, device=self.device) if return_pool else None
-            abi.check(self._lib.syn_backbone_forward_u8(self._h, x.data_ptr(), B, param.data_ptr(),
-                                                        pool.data_ptr() if return_pool else None, self._stream()))
+            self._guarded(lambda: abi.check(self._lib.syn_backbone_forward_u8(self._h, x.data_ptr(), B, param.data_ptr(),
+                                                                             pool.data_ptr() if return_pool else None, self._stream())))
         return (param, pool) if return_pool else param
 
     def reconstruct(self, param, roi=None, dense=False, transform=True, out=None):
