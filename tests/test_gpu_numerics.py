@@ -49,8 +49,9 @@ def run_case(pack, sd, B, expect_fallbacks):
         warnings.simplefilter('always')
         model = make_model(pack, sd)
     n_fb, text = model.numerics_report()
-    assert (n_fb > 0) == expect_fallbacks, text
-    assert bool(w) == expect_fallbacks                            # a fallback is announced, the default schedule is silent
+    if expect_fallbacks is not None:
+        assert (n_fb > 0) == expect_fallbacks, text
+    assert bool(w) == (n_fb > 0)                                  # a fallback is announced, the default schedule is silent
     crops = adv.extreme_crops(B)
     got = model.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
     assert np.isfinite(got).all()
@@ -76,7 +77,9 @@ CASES = {
     'rows f5 1e-6..1 (BN shift kept)': (lambda sd: adv.spread_rows(sd, 5, 6.0, False), False),
     'rows f5 1e-6..1 (no shift)': (lambda sd: adv.spread_rows(sd, 5, 6.0, True), True),
     'rows f12 1e-6..1 (no shift)': (lambda sd: adv.spread_rows(sd, 12, 6.0, True), True),
-    'rows f3 1e-6..1 (no shift)': (lambda sd: adv.spread_rows(sd, 3, 6.0, True), True),
+    # (K = 24: the split error of 24 subnormal low pieces stays just inside the criterion -- either verdict is acceptable, the result is not)
+    'rows f3 1e-6..1 (no shift)': (lambda sd: adv.spread_rows(sd, 3, 6.0, True), None),
+    'rows f3 1e-8..1 (no shift)': (lambda sd: adv.spread_rows(sd, 3, 8.0, True), True),
 }
 
 
