@@ -1,6 +1,6 @@
 // Fused inverted-residual block for the EARLY MobileNetV2 blocks (features.2-4: 60x60 / 30x30 maps, 16-32 channels in,
-// 96-144 hidden) with both 1x1 GEMMs on the fp16 matrix instructions at fp32-equivalent accuracy (two fp16 pieces per operand, three partial products: fused_block_bf3.hip;
-// see fused_block_bf3.hip).  Reference: backbone_nets/mobilenetv2_backbone.py:33-70 (InvertedResidual.forward).
+// 96-144 hidden) with both 1x1 GEMMs on the fp16 matrix instructions at fp32-equivalent accuracy (two fp16 pieces per operand, three partial products: fused_block_f16.hip;
+// see fused_block_f16.hip).  Reference: backbone_nets/mobilenetv2_backbone.py:33-70 (InvertedResidual.forward).
 //
 // These blocks are spatially tiled (halo ring recomputed) and their weights are tiny, so the dataflow differs from the
 // late blocks:
@@ -27,7 +27,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 namespace {
 constexpr int cdive(int a, int b) { return (a + b - 1) / b; }
 constexpr int rupe(int a, int b) { return cdive(a, b) * b; }
-// two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 significant bits (fused_block_bf3.hip)
+// two floats -> packed fp16 pieces a (high) and b (low), x = a + b to 22 significant bits (fused_block_f16.hip)
 __device__ __forceinline__ void split2e(float x0, float x1, unsigned &a, unsigned &b) {
     // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
     a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
@@ -125,7 +125,7 @@ void fused_block_early_kernel(
     const int xq = xvalid ? (gw - 1) / C::NT_E : 0, xnt = xvalid ? (gw - 1) % C::NT_E : -1;
     auto slot_pt = [&](int i) { return (C::SPLIT && i == C::PPW - 1) ? (C::PPW - 1) * C::GW + xq : gw + i * C::GW; };
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // power-of-two scales of the fp16 weight pieces (fused_block_bf3.hip): expand accumulators start at Se x shift, ReLU6 clamps at
+    // power-of-two scales of the fp16 weight pieces (fused_block_f16.hip): expand accumulators start at Se x shift, ReLU6 clamps at
     // 6 Se, the depthwise filter carries 1 / Se; project accumulators start at Sp x shift and are rescaled before the residual add
     const float Se = scl_e[0], inv_se = scl_e[1], c6e = scl_e[2], Sp = scl_p[0], inv_sp = scl_p[1];
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, ntiles_done = 0;

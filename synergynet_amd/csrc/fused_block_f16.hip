@@ -102,7 +102,7 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
 // one group per workgroup -- shrinks to the split and the LDS writes), and the expand weights of chunk 0 arrive through the
 // wrap-around of the per-chunk prefetch.
 template <class C, bool PROF = false, int NS = 1, bool PERSIST = false>
-__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_bf3_kernel(
+__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_f16_kernel(
     const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][2][64][4]*/, const float *__restrict__ e_shift,
     const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][2][64][4]*/,
     const float *__restrict__ p_shift, float *__restrict__ Y, int B, const float *__restrict__ scl_e, const float *__restrict__ scl_p,
@@ -385,24 +385,24 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
 }
 
 template <class C, int NS>
-static void launch_bf3_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
+static void launch_f16_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     const dim3 grid((B + C::NF - 1) / C::NF, NS);
-    fused_block_bf3_kernel<C, false, NS><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
+    fused_block_f16_kernel<C, false, NS><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
 }
 
 template <class C>
-static void launch_bf3(const FusedBlockArgs &a, int B, hipStream_t s) {
+static void launch_f16(const FusedBlockArgs &a, int B, hipStream_t s) {
     const int grid = (B + C::NF - 1) / C::NF;
     if (a.prof)
-        fused_block_bf3_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p, a.prof);
+        fused_block_f16_kernel<C, true><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p, a.prof);
     else {
         if constexpr (C::PERSIST) {
             if (grid > C::SLOTS) {
-                fused_block_bf3_kernel<C, false, 1, true><<<C::SLOTS, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
+                fused_block_f16_kernel<C, false, 1, true><<<C::SLOTS, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
                 return;
             }
         }
-        fused_block_bf3_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
+        fused_block_f16_kernel<C><<<grid, C::NW * 64, 0, s>>>(a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p);
     }
 }
 
@@ -419,18 +419,18 @@ using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // feat
 
 constexpr int kSliceMaxGrid = 48;      // workgroups (of 4 faces) below which the late blocks are sliced over output channels
 
-bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
+bool launch_fused_block_f16(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.We3 || !a.Wp3 || !a.scl_e || !a.scl_p) return false;
     switch (feature) {
-        case 5: case 6: launch_bf3<B5>(a, B, s); return true;
-        case 7: launch_bf3<B7>(a, B, s); return true;
-        case 8: case 9: case 10: launch_bf3<B8>(a, B, s); return true;
-        case 11: launch_bf3<B11>(a, B, s); return true;
-        case 12: case 13: launch_bf3<B12>(a, B, s); return true;
-        case 14: launch_bf3<B14>(a, B, s); return true;
+        case 5: case 6: launch_f16<B5>(a, B, s); return true;
+        case 7: launch_f16<B7>(a, B, s); return true;
+        case 8: case 9: case 10: launch_f16<B8>(a, B, s); return true;
+        case 11: launch_f16<B11>(a, B, s); return true;
+        case 12: case 13: launch_f16<B12>(a, B, s); return true;
+        case 14: launch_f16<B14>(a, B, s); return true;
         // few faces: one workgroup would stream 1.8-2.8 MB of weights through a single CU; slice the output channels over 5
-        case 15: case 16: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_bf3_sliced<B15, 5>(a, B, s); else launch_bf3<B15>(a, B, s); return true;
-        case 17: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_bf3_sliced<B17, 5>(a, B, s); else launch_bf3<B17>(a, B, s); return true;
+        case 15: case 16: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_f16_sliced<B15, 5>(a, B, s); else launch_f16<B15>(a, B, s); return true;
+        case 17: if (!a.prof && (B + 3) / 4 <= kSliceMaxGrid) launch_f16_sliced<B17, 5>(a, B, s); else launch_f16<B17>(a, B, s); return true;
         default: return false;
     }
 }

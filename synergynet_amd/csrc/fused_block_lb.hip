@@ -4,7 +4,7 @@
 // small batches the same stage hidden-sliced over several workgroups (PARTIAL + lb_reduce_kernel).
 // Reference: backbone_nets/mobilenetv2_backbone.py:45-74 (InvertedResidual.forward), :33-42 (ConvBNReLU).
 //
-// The tiled kernel (fused_block_bf3.hip) walks the hidden width in chunks behind two workgroup barriers per chunk and moves
+// The tiled kernel (fused_block_f16.hip) walks the hidden width in chunks behind two workgroup barriers per chunk and moves
 // every hidden activation through LDS twice; with two 4-wave workgroups per CU the matrix pipe is busy ~30 % of the time
 // (profiles/r2/stage_profile_b1024.txt).  Here ONE WAVE carries a whole face through a hidden group of 32 channels without
 // leaving registers, and a face is shared by two waves that split the hidden groups between them (even / odd):

@@ -218,7 +218,7 @@ constexpr int kFcRounds = (kParam + 3) / 4;      // 16 rounds of 4 rows
 // that traffic (0.84 -> 0.42 GB per launch at B = 1024), and eight waves keep two per SIMD (four faces on FOUR waves measured
 // slower than two: 74 vs 65 us).  The per-output arithmetic is the same in every configuration.
 template <int NS, int NFK = NF, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void head_bf16x3_kernel(const float *__restrict__ X /*[B,16,320]*/,
+__global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__restrict__ X /*[B,16,320]*/,
                                                           const unsigned *__restrict__ Wb3 /*[80][10][2][64][4] dwords, {S, 1/S}*/,
                                                           const float *__restrict__ shift, const float *__restrict__ Wfc,
                                                           const float *__restrict__ bfc, float *__restrict__ param,
@@ -348,20 +348,20 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float *__restrict__ 
 }
 
 // `scratch` ([B,1280] floats) receives the pooled vectors of the sliced schedule when the caller did not ask for them
-void launch_head_bf16x3(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
+void launch_head_f16x2(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
                         float *param, float *pool, float *scratch, int B, hipStream_t s) {
     const int grid = (B + NF - 1) / NF;
     if (grid <= 96) {                                      // few faces: spread the 1.6 MB of weights over 5 workgroups per face pair
         float *pl = pool ? pool : scratch;
-        head_bf16x3_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
+        head_f16x2_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
         head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);
         return;
     }
     static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;       // (B = 640 / 768 / 896: 60 / 62 / 61 -> 47 / 48 / 48 us; B = 512: the two-face workgroups, 49 us)
     if (B >= wide_min) {
-        head_bf16x3_kernel<1, 4, 8><<<(B + 3) / 4, 512, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
+        head_f16x2_kernel<1, 4, 8><<<(B + 3) / 4, 512, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
         return;
     }
-    head_bf16x3_kernel<1><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
+    head_f16x2_kernel<1><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
 }
 }  // namespace syn

@@ -239,14 +239,14 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 // Prologue: one workgroup (64 lanes) per 32-face tile.  Lane (i = l&31, hh = l>>5) is face f0+i: it de-whitens the 24
 // shape/expression coefficients k = 16*step + 8*hh + e it feeds to the MFMA, splits them and writes them in operand
 // order (plus the fourth-step fragment, see below); lanes hh = 0 also write the face's 16-float record M[9] | T[3] | 0 x 4.
-__global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restrict__ param, const float *__restrict__ mean,
+__global__ __launch_bounds__(64) void recon_prep_f16_kernel(const float *__restrict__ param, const float *__restrict__ mean,
                                                            const float *__restrict__ stdv, const float *__restrict__ roi,
                                                            int transform, unsigned *__restrict__ rec3, int B) {
     const int ft = blockIdx.x, l = threadIdx.x, i = l & 31, hh = l >> 5;
     const int b = ft * 32 + i;
     const bool ok = b < B;
     const float *pp = param + (size_t)(ok ? b : 0) * kParam;
-    unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+    unsigned *rt = rec3 + (size_t)ft * kRecTileF16;
     // this lane's 24 coefficients + (both halves) columns 48, 49; the face's scale Sa = 2^e with max |alpha| Sa in [2^13, 2^14)
     float al[3][8];
     float amax = 0.f;
@@ -344,13 +344,13 @@ __global__ __launch_bounds__(64) void recon_prep_b3_kernel(const float *__restri
 // (see the store phase).  The launcher runs the ragged last face tile / packed outputs through the guarded instantiation.
 template <int WPG, bool FAST, bool PROF = false>
 __global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
+void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
                      int n_vert, int pitch, int n_tiles, int n_split, int ftiles_per_split, int ft_lo, int ft_hi, int n_units,
                      unsigned long long *prof = nullptr) {
     unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
-    constexpr int NTH = WPG * 64, TQ = kRecTileB3 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
-    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileB3];  // alpha pieces (MFMA lane order, 7 fragments) | 32 x 16 fp32 records
+    constexpr int NTH = WPG * 64, TQ = kRecTileF16 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
+    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileF16];  // alpha pieces (MFMA lane order, 7 fragments) | 32 x 16 fp32 records
     __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
@@ -366,7 +366,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     u32x4 bb[3][3][2], bx[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const unsigned *bc = basis3 + ((size_t)T * 3 + c) * kBasisB3;
+        const unsigned *bc = basis3 + ((size_t)T * 3 + c) * kBasisF16;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
@@ -381,7 +381,7 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
 
     u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
     auto fetch = [&](int ft) {                       // branch-free (index clamped): no control flow around in-flight loads
-        const unsigned *rt = rec3 + (size_t)ft * kRecTileB3;
+        const unsigned *rt = rec3 + (size_t)ft * kRecTileF16;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             int q = i * NTH + (int)threadIdx.x;
@@ -504,11 +504,11 @@ void recon_b3_kernel(const unsigned *__restrict__ rec3, const unsigned *__restri
     }
 }
 
-void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
+void launch_reconstruct_f16(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
                            int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3f) {
     unsigned *rec3 = reinterpret_cast<unsigned *>(rec3f);
     const int n_ftiles = (B + 31) / 32;
-    recon_prep_b3_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
+    recon_prep_f16_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
@@ -529,7 +529,7 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
             unsigned long long *d = nullptr, hst[8];
             (void)hipMalloc((void **)&d, sizeof(hst));
             (void)hipMemsetAsync(d, 0, sizeof(hst), s);
-            recon_b3_kernel<WPG, true, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units, d);
+            recon_f16_kernel<WPG, true, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units, d);
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(hst, d, sizeof(hst), hipMemcpyDeviceToHost);
             (void)hipFree(d);
@@ -537,9 +537,9 @@ void launch_reconstruct_b3(const float *param, const float *mean62, const float 
             for (int i = 0; i < 7; ++i) fprintf(stderr, "recon prof %-18s %10.0f ticks/wg\n", nm[i], (double)hst[i] / (double)hst[7]);
             fprintf(stderr, "recon prof workgroups %llu\n", hst[7]);
         } else if (fast)
-            recon_b3_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+            recon_f16_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
         else
-            recon_b3_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+            recon_f16_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
     };
     if (pad_writable && pitch >= n_groups * WPG * 32) {   // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
                                           // store path (columns [n_vert, pitch) receive padding values), the ragged last one guarded

@@ -141,7 +141,7 @@ void launch_conv(const float *in, const float *W, const float *scale, const floa
 
 // =====================================================================================
 // The same implicit GEMM on v_mfma_f32_16x16x32_f16 with fp32-equivalent accuracy: every operand as two fp16 pieces (x = a + b,
-// 22 significant bits), three partial products per K=32 block -- see fused_block_bf3.hip.  Weights are scaled by a power of two
+// 22 significant bits), three partial products per K=32 block -- see fused_block_f16.hip.  Weights are scaled by a power of two
 // S (max |w| S in [2^13, 2^14)), split and lane-ordered offline:
 //   W3[n_tile][tap*Cin/32 + kc][piece 2][lane][4 dwords], {S, 1/S};  lane (channel l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
 // Activations stay fp32 in HBM; a lane fetches its 8 consecutive input channels (two float4) and splits them in registers.
@@ -167,7 +167,7 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (
 }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_bf3_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3,
+__global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
         if (c + 1 < chunks) park_w((c + 1) & 1);
     }
     if (m0 >= M) return;
-    // epilogue as conv_bf3_kernel: loads first (branch-free), then arithmetic, then stores
+    // epilogue as conv_f16x2_kernel: loads first (branch-free), then arithmetic, then stores
     f32x4 scv[NT], shv[NT], rsv[MT][NT];
     float vmax = 0.f;
 #pragma unroll
@@ -455,17 +455,17 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
 }
 
 template <int MT, int NT>
-static void launch_conv_bf3_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+static void launch_conv_f16x2_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
                               hipStream_t s, float *stat) {
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
-    conv_bf3_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
+    conv_f16x2_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
                                                  act, n_tiles, m_tiles, stat);
 }
 
-void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
                      hipStream_t s, float *stat) {
     const int M = B * Hout * Hout;
@@ -477,8 +477,8 @@ void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, co
         else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         return;
     }
-    if (tiles >= 1024) launch_conv_bf3_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-    else launch_conv_bf3_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    if (tiles >= 1024) launch_conv_f16x2_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    else launch_conv_f16x2_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
 }
 
 // =====================================================================================

@@ -45,7 +45,7 @@ struct FusedBlockArgs {
     const float *Wp, *p_scale, *p_shift;              // project: Wpk[COUTP/16][HID/16][64][4], [COUTP], [COUTP]
     float *Y;                                         // block output NHWC
     unsigned long long *prof = nullptr;               // debug: 8 device counters (per-stage s_memtime sums)
-    const unsigned *We3 = nullptr, *Wp3 = nullptr;    // split weights: fp16 x2 for features.5-17 (fused_block_bf3.hip), bf16 x3 for features.2-4 (fused_block_early.hip), or null
+    const unsigned *We3 = nullptr, *Wp3 = nullptr;    // split weights: fp16 x2 for features.5-17 (fused_block_f16.hip), bf16 x3 for features.2-4 (fused_block_early.hip), or null
     const float *scl_e = nullptr, *scl_p = nullptr;   // features.5-17: {S, 1/S, 6 S} of the expand / project weights (device)
     const unsigned *Arm_e = nullptr, *Arm_p = nullptr;  // features.2-4: weight fragments of the row-marching kernel (fused_block_rm.hip), or null
     const unsigned *Alb_p = nullptr;                  // features.8-13: project fragments of the register-resident kernel (fused_block_lb.hip), or null
@@ -93,7 +93,7 @@ bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStre
 // features.15-17 of every face in ONE launch (a[i]: features.(15 + i)); false = not applicable, launch them one by one
 bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s);
 // same block with both GEMMs on the bf16 matrix pipe through the exact 3-way operand split (features.5-17)
-bool launch_fused_block_bf3(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
+bool launch_fused_block_f16(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 
 // features.0 + features.1 fused (stem_block1.hip): image -> NHWC [B,60,60,16].
 void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w0, const unsigned *w0b3, const float *s0,
@@ -117,7 +117,7 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
                  hipStream_t s);
 
 // same tail with the GEMM on the bf16 matrix pipe via an exact 3-way bf16 split of fp32 operands (head_kernel.hip)
-void launch_head_bf16x3(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
+void launch_head_f16x2(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
                         const float *bfc, float *param, float *pool, float *scratch /*[B,1280]*/, int B, hipStream_t s);
 
 // ---- on-device crop + Lanczos-4 resize (preproc_kernels.hip) ----
@@ -130,7 +130,7 @@ void launch_conv(const float *in, const float *W, const float *scale, const floa
                  int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s);
 // same conv on the bf16 matrix pipe (exact 3-way operand split): W3 [N/16][taps*Cin/32][3][64][4] dwords, Cin % 32 == 0
 // stat (nullable): one float of the per-forward range-guard array -- max |output| is folded into it (resnet_kernels.hip range_note)
-void launch_conv_bf3(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
                      hipStream_t s, float *stat = nullptr);
 // window of a tensor's max |x| inside which the fp16 x2 split of an UNSCALED activation keeps >= 15 bits relative to that maximum:
@@ -157,18 +157,18 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
                         int transform, float *out, int pitch /*floats between rows of out, >= n_vert*/, int B, hipStream_t s, float *rec);
 
 // Same contraction on v_mfma_f32_32x32x16_f16 (two fp16 pieces per operand, three partial products).
-//   basis3: per (32-vertex tile, coord) kBasisB3 dwords: [k16 step 3][piece 2][lane 64][4 dwords] for k = 0..47
+//   basis3: per (32-vertex tile, coord) kBasisF16 dwords: [k16 step 3][piece 2][lane 64][4 dwords] for k = 0..47
 //           (lane (j = l&31 vertex, hh = l>>5) holds k = 16*step + 8*hh + e), column k scaled by its own power of two 2^e_k, then one
 //           more [lane 64][4] fragment: a fourth k16 step whose slots carry the split partial products of columns 48, 49 and the
-//           mean (recon_prep_b3_kernel).  mean62 / std62 here are the COLUMN-SCALED de-whitening constants (entries 12..61 x 2^-e_k,
+//           mean (recon_prep_f16_kernel).  mean62 / std62 here are the COLUMN-SCALED de-whitening constants (entries 12..61 x 2^-e_k,
 //           mean62[62] = 2^-e_u, the coefficient of the scaled mean shape): synergy_abi.hip pack_basis.
-//   rec3:   per 32-face tile kRecTileB3 dwords: the alpha pieces (x the face's power of two Sa) in the same lane order (faces), the
+//   rec3:   per 32-face tile kRecTileF16 dwords: the alpha pieces (x the face's power of two Sa) in the same lane order (faces), the
 //           matching fourth-step fragment, then 32 x 16 fp32 records M[9] / Sa | T[3] | 0 x 4.
-constexpr int kBasisB3 = (3 * 2 + 1) * 256;
-constexpr int kRecTileB3 = (3 * 2 + 1) * 256 + 32 * 16;
+constexpr int kBasisF16 = (3 * 2 + 1) * 256;
+constexpr int kRecTileF16 = (3 * 2 + 1) * 256 + 32 * 16;
 constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)
 constexpr int kRecSlack = 4096;
-void launch_reconstruct_b3(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
+void launch_reconstruct_f16(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
                            int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3);
 
 // ---- mesh consumers (render_kernels.hip): Sim3DR.get_normal / RenderPipeline / Sim3DR.rasterize / cv2.addWeighted ----

@@ -72,7 +72,7 @@ struct Net {
     size_t flat_count = 0;      // floats in the host flat input (incl. heads)
     size_t src_fc = 0;
     size_t packed_count = 0;    // floats in the packed device blob
-    size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_b3 = 0;   // dst_head_b3: features.18 weights as 2 fp16 pieces (dwords) + their power-of-two scale
+    size_t dst_fc_w = 0, dst_fc_b = 0, dst_head_f16 = 0;   // dst_head_f16: features.18 weights as 2 fp16 pieces (dwords) + their power-of-two scale
     size_t dst_range = 0;                                 // 64 dwords: {unsafe1, unsafe16 (bit masks), in_bound[20], min_wmean[20], w_relerr[20]}
     size_t max_io = 0, max_hidden = 0;   // per-face activation floats (block in/out, expanded)
     double flops = 0, pw_flops = 0;
@@ -172,7 +172,7 @@ struct Net {
         flat_count = src;
         dst_fc_w = dst; dst += 64 * 1280;
         dst_fc_b = dst; dst += 64;
-        dst_head_b3 = dst; dst += (size_t)80 * 10 * 2 * 256 + 4;        // fragments, then {S, 1/S}
+        dst_head_f16 = dst; dst += (size_t)80 * 10 * 2 * 256 + 4;        // fragments, then {S, 1/S}
         dst_range = dst; dst += 64;                                      // the verdict of analyze_mbv2_ranges (RangeInfo), travels with the blob
         packed_count = dst;
         flops += 2.0 * 1280 * 62;
@@ -302,14 +302,14 @@ struct syn_handle {
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
     int range_guard = 1;           // SYNERGY_HIP_RANGE_GUARD=0: ignore the verdict (tests use it to show that the adversarial cases do break the unguarded schedule)
-    int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks, late-block + head GEMMs on the bf16 pipe via the
-                                   // exact 3-way operand split; 1 fused blocks on the fp32 MFMA only; 0 one kernel per layer
+    int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks / chains, every GEMM on the fp16 matrix instructions with
+                                   // two-piece operands; 1 fused blocks on the fp32-input MFMA only; 0 one kernel per layer
 };
 
 namespace {
 
 size_t basis_float_count(int nvp, int nlp) {        // fp32 tiles | mean, std | column-scaled mean, std | fp16 x2 tiles (dense, landmark)
-    return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 256 + (size_t)((nvp + nlp) / 32) * 3 * syn::kBasisB3;
+    return (size_t)(nvp + nlp) * 3 * syn::kBasisK + 256 + (size_t)((nvp + nlp) / 32) * 3 * syn::kBasisF16;
 }
 const float *basis_dense(const syn_handle *h) { return h->d_basis; }
 const float *basis_lmk(const syn_handle *h) { return h->d_basis + (size_t)h->nvp * 3 * syn::kBasisK; }
@@ -317,8 +317,8 @@ const float *basis_mean(const syn_handle *h) { return h->d_basis + (size_t)(h->n
 const float *basis_std(const syn_handle *h) { return basis_mean(h) + 64; }
 const float *basis_mean_cs(const syn_handle *h) { return basis_mean(h) + 128; }     // de-whitening constants of the fp16 x2 path: entries 12..61
 const float *basis_std_cs(const syn_handle *h) { return basis_mean(h) + 192; }      // x 2^-e_k (per basis column), [62] of the mean copy = 2^-e_u
-const unsigned *basis3_dense(const syn_handle *h) { return reinterpret_cast<const unsigned *>(basis_mean(h) + 256); }
-const unsigned *basis3_lmk(const syn_handle *h) { return basis3_dense(h) + (size_t)(h->nvp / 32) * 3 * syn::kBasisB3; }
+const unsigned *basis_f16_dense(const syn_handle *h) { return reinterpret_cast<const unsigned *>(basis_mean(h) + 256); }
+const unsigned *basis_f16_lmk(const syn_handle *h) { return basis_f16_dense(h) + (size_t)(h->nvp / 32) * 3 * syn::kBasisF16; }
 
 size_t ws_floats_per_face() {
     const size_t mb = 2 * net().max_io + 2 * net().max_hidden, rn = 4 * resnet50().buf_big + 2 * resnet50().buf_mid;
@@ -396,9 +396,9 @@ static float pow2_scale(float mx) {
     return ldexpf(1.0f, ex);
 }
 
-// fp16 x2 layout of the same tiles for recon_b3_kernel (see syn_internal.h, launch_reconstruct_b3); column k (50 = the mean shape)
+// fp16 x2 layout of the same tiles for recon_f16_kernel (see syn_internal.h, launch_reconstruct_f16); column k (50 = the mean shape)
 // x colscale[k], the column's own power of two
-void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
+void pack_basis_tiles_f16(unsigned *dst, int n_rows_valid, int n_tiles, const float *w_shp, const float *w_exp, const float *u,
                          const int64_t *rows, const float *colscale /*[51]*/) {
     auto wfull = [&](int v, int c, int k) -> float {
         if (v >= n_rows_valid) return 0.f;
@@ -413,7 +413,7 @@ void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const flo
     };
     for (int t = 0; t < n_tiles; ++t)
         for (int c = 0; c < 3; ++c) {
-            unsigned *d = dst + ((size_t)t * 3 + c) * syn::kBasisB3;
+            unsigned *d = dst + ((size_t)t * 3 + c) * syn::kBasisF16;
             for (int ks = 0; ks < 3; ++ks)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int dd = 0; dd < 4; ++dd) {
@@ -423,7 +423,7 @@ void pack_basis_tiles_b3(unsigned *dst, int n_rows_valid, int n_tiles, const flo
                         split(wfull(32 * t + (lane & 31), c, k0 + 1), hi);
                         for (int pc = 0; pc < 2; ++pc) d[((ks * 2 + pc) * 64 + lane) * 4 + dd] = lo[pc] | (hi[pc] << 16);
                     }
-            // fourth k16 step (recon_prep_b3_kernel writes the matching alpha side): columns 48, 49 and the mean as split products,
+            // fourth k16 step (recon_prep_f16_kernel writes the matching alpha side): columns 48, 49 and the mean as split products,
             // [b48a b48a b48b | b49a b49a b49b | ua ub] in lane half 0, zeros in lane half 1
             for (int lane = 0; lane < 64; ++lane) {
                 unsigned b8[2], b9[2], uu[2];
@@ -582,7 +582,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.Glb && syn::launch_fused_block_lb4(L.feature, a, B, s)) ||
-                (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_bf3(L.feature, a, B, s))) ||
+                (a.We3 && (syn::launch_fused_block_early(L.feature, a, B, s) || syn::launch_fused_block_f16(L.feature, a, B, s))) ||
                 syn::launch_fused_block(L.feature, a, B, s)) {
                 float *t = X; X = Y; Y = t;
                 li += 2;
@@ -602,7 +602,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             const bool has_expand = li > 0 && n.layers[li - 1].kind == PW && n.layers[li - 1].feature == L.feature;
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
         } else if (L.feature == 18 && h->fusion >= 2 && !((u1 >> 18) & 1u) && stop_feature != 18) {
-            syn::launch_head_bf16x3(X, reinterpret_cast<const unsigned *>(P + n.dst_head_b3), sh, P + n.dst_fc_w, P + n.dst_fc_b,
+            syn::launch_head_f16x2(X, reinterpret_cast<const unsigned *>(P + n.dst_head_f16), sh, P + n.dst_fc_w, P + n.dst_fc_b,
                                     param, pool, H1, B, s);
             mark(19);
             HIP_TRY(hipGetLastError());
@@ -678,7 +678,7 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     auto conv = [&](int ci, const float *in, const float *res, float *out, int act) {
         const RConv &c = n.convs[ci];
         if (f16 && c.dst_w3 && !(h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u))) {
-            syn::launch_conv_bf3(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
+            syn::launch_conv_f16x2(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
                                  c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s,
                                  stat && resnet_stat_used(1 + ci) ? stat + 1 + ci : nullptr);
             return;
@@ -768,7 +768,7 @@ int syn_backbone_launch_count(syn_handle *) { return (int)net().layers.size() + 
 //   * WEIGHTS (exact: the packed pieces are re-read): row n of a layer passes if sum_k |w_nk S - (a_nk + b_nk)| <=
 //     2^-17 (sum_k |w_nk| S + |shift_n| S / X), X = the bound of the layer's input -- rows far below the layer's largest lose
 //     their low piece to fp16 subnormals.
-// A block that fails at s = 16 but passes at s = 1 runs the tiled fp16 x2 kernel (fused_block_bf3.hip); one that fails at s = 1
+// A block that fails at s = 16 but passes at s = 1 runs the tiled fp16 x2 kernel (fused_block_f16.hip); one that fails at s = 1
 // runs the exact fp32-MFMA kernel (fused_block.hip / stem_block1.hip / head_kernel.hip: the SYNERGY_HIP_FUSION=1 schedule).
 // The verdict travels with the constants (ConstHeader) and is reported by syn_numerics_report().
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -983,7 +983,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             // K is walked as `nch` chunks of `hc` real channels, each zero padded to `hcp` (a multiple of 32):
             // late blocks hc = hcp = cin; early expand hc = cin (16 / 24), hcp = 32; early project hc = early_block_hc
             const bool early = L.feature >= 2 && L.feature <= 4;
-            if (!early) {            // late blocks: two fp16 pieces per weight, scaled by S = 2^e to max |w| in [2^13, 2^14) (fused_block_bf3.hip)
+            if (!early) {            // late blocks: two fp16 pieces per weight, scaled by S = 2^e to max |w| in [2^13, 2^14) (fused_block_f16.hip)
                 float mx = 0.f;
                 for (int nn = 0; nn < L.cout; ++nn)
                     for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * bn_scale[nn]));
@@ -1219,7 +1219,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
         const Layer &L = n.layers.back();
         const float *w = flat + L.src_w;
         const float *gamma = w + (size_t)L.cout * L.cin, *var = gamma + 3 * (size_t)L.cout;
-        unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + n.dst_head_b3);
+        unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + n.dst_head_f16);
         std::vector<float> sc(L.cout);
         float mx = 0.f;
         for (int nn = 0; nn < L.cout; ++nn) {
@@ -1227,8 +1227,8 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             for (int k = 0; k < L.cin; ++k) mx = fmaxf(mx, fabsf(w[(size_t)nn * L.cin + k] * sc[nn]));
         }
                 const float S = pow2_scale(mx);
-        pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256] = S;
-        pk[n.dst_head_b3 + (size_t)80 * 10 * 2 * 256 + 1] = 1.0f / S;
+        pk[n.dst_head_f16 + (size_t)80 * 10 * 2 * 256] = S;
+        pk[n.dst_head_f16 + (size_t)80 * 10 * 2 * 256 + 1] = 1.0f / S;
         for (int nt = 0; nt < 80; ++nt)
             for (int kc = 0; kc < 10; ++kc)
                 for (int lane = 0; lane < 64; ++lane)
@@ -1489,8 +1489,8 @@ static void pack_basis(const float *w_shp, const float *w_exp, const float *u, c
     for (int k = 0; k < 50; ++k) { mcs[12 + k] *= colinv[k]; scs[12 + k] *= colinv[k]; }
     mcs[62] = colinv[50];                                   // coefficient of the (scaled) mean shape
     unsigned *b3 = reinterpret_cast<unsigned *>(ms + 256);
-    pack_basis_tiles_b3(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr, colscale);
-    pack_basis_tiles_b3(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisB3, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints, colscale);
+    pack_basis_tiles_f16(b3, n_vert, nvp / 32, w_shp, w_exp, u, nullptr, colscale);
+    pack_basis_tiles_f16(b3 + (size_t)(nvp / 32) * 3 * syn::kBasisF16, n_lmk, nlp / 32, w_shp, w_exp, u, keypoints, colscale);
 }
 
 int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const float *u, const float *param_mean,
@@ -1802,7 +1802,7 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
     float *rec = h->rec;
     hipStream_t s = (hipStream_t)stream;
     if (h->fusion >= 2)
-        syn::launch_reconstruct_b3(param, basis_mean_cs(h), basis_std_cs(h), dense ? basis3_dense(h) : basis3_lmk(h), n, dense ? h->nvp : h->nlp,
+        syn::launch_reconstruct_f16(param, basis_mean_cs(h), basis_std_cs(h), dense ? basis_f16_dense(h) : basis_f16_lmk(h), n, dense ? h->nvp : h->nlp,
                                    roi, transform, out, row_pitch, pad_writable, B, s, rec);
     else
         syn::launch_reconstruct(param, basis_mean(h), basis_std(h), dense ? basis_dense(h) : basis_lmk(h), n, dense ? h->nvp : h->nlp,

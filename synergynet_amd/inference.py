@@ -14,6 +14,8 @@ The vertex / pose helpers keep the reference names (`predict_sparseVert`, `predi
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 _default_model = None
@@ -34,7 +36,8 @@ def _lanczos4_taps(n_dst: int, n_src: int):
     """Per destination index: first source tap (may be out of range, clamp later) and 8 fixed-point weights.
     OpenCV's resize evaluates the source position in double, rounds it to float32 and takes floor / fraction of THAT
     (`fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx`), so the fraction is always < 1; the kernel argument
-    `x + 3 - i` is float32 arithmetic and the eight weights are summed sequentially in float32."""
+    `x + 3 - i` is float32 arithmetic and the eight weights are summed sequentially in float32.  All n_dst indices at once (numpy);
+    the rounding points are exactly those of the scalar formulation: float32 where OpenCV holds a float, float64 in between."""
     f32 = np.float32
     scale = n_src / n_dst
     pos = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(f32)
@@ -42,30 +45,54 @@ def _lanczos4_taps(n_dst: int, n_src: int):
     fx = pos - sx.astype(f32)                      # exact in float32
     s45 = 0.70710678118654752440084436210485
     cs = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]])
-    coeffs = np.zeros((n_dst, 8), dtype=f32)
-    for d in range(n_dst):
-        x = fx[d]
-        if x < np.finfo(f32).eps:
-            coeffs[d, 3] = 1.0
-            continue
-        x3 = f32(x + f32(3))
-        y0 = -float(x3) * np.pi * 0.25
-        s0, c0 = np.sin(y0), np.cos(y0)
-        c = np.empty(8, dtype=f32)
-        tot = f32(0)
-        for i in range(8):
-            y = -float(f32(x3 - f32(i))) * np.pi * 0.25
-            c[i] = f32((cs[i, 0] * s0 + cs[i, 1] * c0) / (y * y))
-            tot = f32(tot + c[i])
-        coeffs[d] = c * f32(f32(1.0) / tot)
+    on_grid = fx < np.finfo(f32).eps               # the source position IS a sample: weight 1 on tap 3
+    x3 = (fx + f32(3)).astype(f32)
+    y0 = -x3.astype(np.float64) * np.pi * 0.25
+    s0, c0 = np.sin(y0), np.cos(y0)
+    arg = (x3[:, None] - np.arange(8, dtype=f32)[None, :]).astype(f32).astype(np.float64)       # f32(x3 - i)
+    arg[on_grid] = 1.0                             # (never used: those rows are overwritten below; avoids 0 / 0)
+    y = -arg * np.pi * 0.25
+    c = ((cs[None, :, 0] * s0[:, None] + cs[None, :, 1] * c0[:, None]) / (y * y)).astype(f32)
+    tot = np.zeros(n_dst, dtype=f32)
+    for i in range(8):                             # sequential float32 sum, tap 0 first
+        tot = (tot + c[:, i]).astype(f32)
+    coeffs = (c * (f32(1.0) / tot)[:, None]).astype(f32)
+    coeffs[on_grid] = 0
+    coeffs[on_grid, 3] = 1
     icoef = np.clip(np.rint(coeffs * f32(2048.0)), -32768, 32767).astype(np.int64)
     return sx - 3, icoef
 
 
-def lanczos4_tables(n_src: int, n_dst: int = 120):
-    """(first tap in source coordinates [n_dst] int32, fixed-point weights [n_dst,8] int16) for syn_crop_resize."""
+@functools.lru_cache(maxsize=4096)
+def _lanczos4_tables_cached(n_src: int, n_dst: int):
     x0, c = _lanczos4_taps(n_dst, n_src)
-    return x0.astype(np.int32), c.astype(np.int16)
+    x0, c = x0.astype(np.int32), c.astype(np.int16)
+    x0.setflags(write=False)
+    c.setflags(write=False)
+    return x0, c
+
+
+def lanczos4_tables(n_src: int, n_dst: int = 120):
+    """(first tap in source coordinates [n_dst] int32, fixed-point weights [n_dst,8] int16) for syn_crop_resize.  Depends on the
+    crop side only, so the tables are computed once per size and cached (read-only arrays): a face costs two dictionary look-ups
+    instead of 4 ms of per-index Python (the reference resizes with cv2 at synergy3DMM.py:188)."""
+    return _lanczos4_tables_cached(int(n_src), int(n_dst))
+
+
+def crop_img(img, roi_box):
+    """reference utils/inference.py:95-125 (imported from there by the reference's demo scripts): the box is rounded to integers,
+    the part of it inside the frame is copied, the rest of the (ey - sy) x (ex - sx) result stays zero.  Host helper kept for
+    scripts ported by module mapping; get_all_outputs crops on the device (syn_crop_resize).  A box entirely outside the frame
+    gives an all-zero crop (the reference's slice assignment raises there)."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    sx, sy, ex, ey = (int(round(v)) for v in roi_box[:4])
+    res = np.zeros((ey - sy, ex - sx) + img.shape[2:], dtype=np.uint8)
+    dsx, dsy = max(0, -sx), max(0, -sy)            # where the part inside the frame lands in the result
+    sx, sy, ex, ey = max(sx, 0), max(sy, 0), min(ex, w), min(ey, h)
+    if ex > sx and ey > sy:
+        res[dsy:dsy + ey - sy, dsx:dsx + ex - sx] = img[sy:ey, sx:ex]
+    return res
 
 
 def predict_sparseVert(param, roi_box, transform=False):

@@ -463,23 +463,140 @@ class SynergyNet(nn.Module):
         ang, t3d = self.predict_pose_batch(p, roi)
         return [float(v) for v in ang[0].cpu().numpy()], t3d[0].cpu().numpy()
 
-    def crop_resize(self, frame, boxes, xofs, xcoef, yofs, ycoef):
+    def crop_resize(self, frame, boxes, xofs, xcoef, yofs, ycoef, out=None):
         """crop_img + cv2.resize(INTER_LANCZOS4) of B detections of one uint8 frame [H,W,3] on the device
-        (syn_crop_resize); returns uint8 crops [B,120,120,3] on the device."""
-        fr = torch.as_tensor(np.ascontiguousarray(frame))
+        (syn_crop_resize); returns uint8 crops [B,120,120,3] on the device (written into `out` when given).
+        frame / tables may be numpy arrays or tensors (device tensors are used in place)."""
+        fr = frame if isinstance(frame, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(frame))
         if fr.dtype != torch.uint8 or fr.dim() != 3 or fr.shape[2] != 3:
             raise RuntimeError('frame must be uint8 [H,W,3]')
-        fr = fr.to(self.device)
-        dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(self.device)
-        bx, xo, xc, yo, yc = dev(boxes, np.int32), dev(xofs, np.int32), dev(xcoef, np.int16), dev(yofs, np.int32), dev(ycoef, np.int16)
+        fr = fr.to(self.device).contiguous()
+
+        def dev(a, dt):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=self.device, dtype=dt).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(a, dtype={torch.int32: np.int32, torch.int16: np.int16}[dt])).to(self.device)
+        bx, xo, xc, yo, yc = dev(boxes, torch.int32), dev(xofs, torch.int32), dev(xcoef, torch.int16), dev(yofs, torch.int32), dev(ycoef, torch.int16)
         B = bx.shape[0]
         if (bx.dim() != 2 or bx.shape[1] != 4 or tuple(xo.shape) != (B, 120) or tuple(yo.shape) != (B, 120) or
                 tuple(xc.shape) != (B, 120, 8) or tuple(yc.shape) != (B, 120, 8)):
             raise RuntimeError('crop_resize: boxes [B,4], xofs/yofs [B,120], xcoef/ycoef [B,120,8] expected')
         with torch.cuda.device(self.device):
-            out = torch.empty((B, 120, 120, 3), dtype=torch.uint8, device=self.device)
+            if out is None:
+                out = torch.empty((B, 120, 120, 3), dtype=torch.uint8, device=self.device)
+            elif tuple(out.shape) != (B, 120, 120, 3) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != self.device:
+                raise RuntimeError('crop_resize: out must be a contiguous uint8 [B,120,120,3] tensor on the model device')
             abi.check(self._lib.syn_crop_resize(self._h, fr.data_ptr(), fr.shape[0], fr.shape[1], bx.data_ptr(), xo.data_ptr(),
                                                 xc.data_ptr(), yo.data_ptr(), yc.data_ptr(), out.data_ptr(), B, self._stream()))
+        return out
+
+    # ---- host staging: page-locked buffers (torch's caching host allocator recycles them), so every transfer is ONE asynchronous DMA
+    def _pinned_like(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0] if arr.ndim else arr).dtype, pin_memory=True)
+        t.numpy()[...] = arr
+        return t
+
+    def _roi_and_box(self, rect):
+        """The box arithmetic of get_all_outputs, verbatim in meaning (reference synergy3DMM.py:178-185): the detection list is
+        aliased and MUTATED into the enlarged square ROI like the reference does; returns (roi5 floats, rounded crop box)."""
+        roi_box = rect
+        HCenter = (rect[1] + rect[3]) / 2
+        WCenter = (rect[0] + rect[2]) / 2
+        side_len = roi_box[3] - roi_box[1]
+        margin = side_len * 1.2 // 2
+        roi_box[0], roi_box[1], roi_box[2], roi_box[3] = WCenter - margin, HCenter - margin, WCenter + margin, HCenter + margin
+        sx, sy, ex, ey = [int(round(v)) for v in roi_box[:4]]             # crop_img's rounding (utils/inference.py:98)
+        if ex - sx <= 0 or ey - sy <= 0:
+            raise ValueError('degenerate detection box')
+        return [float(v) for v in roi_box[:5]], (sx, sy, ex, ey)
+
+    def _detect(self, frame):
+        if self.face_detector is None:
+            # the reference builds FaceBoxes() on every call (:170-171); here once, on first use (HIP kernels,
+            # synergynet_amd/faceboxes.py; needs FaceBoxes/weights/FaceBoxesProd.pth or model.face_detector = FaceBoxes(state_dict=...))
+            from .faceboxes import FaceBoxes
+            self.face_detector = FaceBoxes(device=self.device)
+        return self.face_detector(frame)
+
+    def get_all_outputs_batch(self, frames, rects=None, dense=True):
+        """get_all_outputs for a LIST of frames: every face of every frame goes through ONE backbone forward, ONE
+        reconstruction and ONE download.  frames: uint8 BGR [H,W,3] arrays (sizes may differ); rects: per frame a list of
+        detections [xmin,ymin,xmax,ymax,score] (mutated into the ROI like get_all_outputs does), or None -> face_detector(frame).
+        Returns a list with one (pts_res, vertices_lst, poses) triple per frame, each exactly what get_all_outputs returns
+        (dense=False: vertices_lst is empty -- landmarks + pose only).  The returned arrays of a call are contiguous float32 views
+        into page-locked host blocks allocated for this call and owned by the arrays (freed when the last one is dropped)."""
+        from .inference import lanczos4_tables
+        import time
+        t_start = time.perf_counter()
+        frames = list(frames)
+        if rects is None:
+            rects = [self._detect(f) for f in frames]
+        if len(rects) != len(frames):
+            raise ValueError('rects must hold one detection list per frame')
+        counts = [len(r) for r in rects]
+        n = int(sum(counts))
+        empty = lambda: ([], [], [])
+        if n == 0:
+            return [empty() for _ in frames]
+        # per-face host tables: ROI (float32, as the reference's numpy arithmetic sees it), rounded box, Lanczos tap tables by crop side
+        roi = np.empty((n, 5), dtype=np.float32)
+        box = np.empty((n, 4), dtype=np.int32)
+        ofs = np.empty((2, n, 120), dtype=np.int32)
+        coef = np.empty((2, n, 120, 8), dtype=np.int16)
+        k = 0
+        for fr_rects in rects:
+            for rect in fr_rects:
+                r5, b4 = self._roi_and_box(rect)
+                roi[k] = r5
+                box[k] = b4
+                ofs[0, k], coef[0, k] = lanczos4_tables(b4[2] - b4[0])
+                ofs[1, k], coef[1, k] = lanczos4_tables(b4[3] - b4[1])
+                k += 1
+        with torch.cuda.device(self.device):
+            nb = lambda a: self._pinned_like(a).to(self.device, non_blocking=True)
+            roi_d, box_d, ofs_d, coef_d = nb(roi), nb(box), nb(ofs), nb(coef)
+            crops = torch.empty((n, 120, 120, 3), dtype=torch.uint8, device=self.device)
+            lo = 0
+            for f, c in zip(frames, counts):
+                if c:
+                    fr = np.ascontiguousarray(f)
+                    if fr.dtype != np.uint8 or fr.ndim != 3 or fr.shape[2] != 3:
+                        raise RuntimeError('frame must be uint8 [H,W,3]')
+                    self.crop_resize(nb(fr), box_d[lo:lo + c], ofs_d[0, lo:lo + c], coef_d[0, lo:lo + c], ofs_d[1, lo:lo + c],
+                                     coef_d[1, lo:lo + c], out=crops[lo:lo + c])
+                lo += c
+            param = self.forward_crops_u8(crops)
+            lmk_d = self.reconstruct(param, roi=roi_d, dense=False, transform=True)
+            ang_d, t3d_d = self.predict_pose_batch(param, roi_d)
+            host = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            lmk_h = host((n, 3, self._n_lmk), torch.float32)
+            ang_h, t3d_h = host((n, 3), torch.float64), host((n, 3), torch.float32)
+            lmk_h.copy_(lmk_d, non_blocking=True)
+            ang_h.copy_(ang_d, non_blocking=True)
+            t3d_h.copy_(t3d_d, non_blocking=True)
+            mesh_h = None
+            if dense:
+                # packed rows on the device (the kernel's guarded store path; 0.04 us per face more than pitched rows), so that the
+                # download is one contiguous DMA and every face's (3, 53215) array is a contiguous view of the host block
+                mesh_d = torch.empty((n, 3, self._n_vert), dtype=torch.float32, device=self.device)
+                self.reconstruct(param, roi=roi_d, dense=True, transform=True, out=mesh_d)
+                mesh_h = host((n, 3, self._n_vert), torch.float32)
+                mesh_h.copy_(mesh_d, non_blocking=True)
+            t_enq = time.perf_counter()
+            torch.cuda.current_stream(self.device).synchronize()
+            t_dev = time.perf_counter()
+        lmk, ang, t3d = lmk_h.numpy(), ang_h.numpy().tolist(), t3d_h.numpy()
+        mesh = mesh_h.numpy() if dense else None
+        out, k = [], 0
+        for c in counts:
+            pts_res = [lmk[i] for i in range(k, k + c)]
+            vertices_lst = [mesh[i] for i in range(k, k + c)] if dense else []
+            poses = [[ang[i], t3d[i]] for i in range(k, k + c)]
+            out.append((pts_res, vertices_lst, poses))
+            k += c
+        # where the call's wall time went: host work (tables, staging, enqueueing, result lists) vs waiting for the device + DMA
+        t_end = time.perf_counter()
+        self.last_timing = dict(faces=n, host_s=(t_enq - t_start) + (t_end - t_dev), device_wait_s=t_dev - t_enq)
         return out
 
     def get_all_outputs(self, input, rects=None):
@@ -487,46 +604,9 @@ class SynergyNet(nn.Module):
         list of (3,53215) meshes, list of [angles_deg, translation]) with one entry per face.
 
         All faces of the image go through ONE batched launch chain instead of the reference's
-        per-face loop.  `rects` = detections [[xmin,ymin,xmax,ymax,score], ...]; when omitted the
-        `face_detector(image)` is called -- by default the HIP FaceBoxes of synergynet_amd/faceboxes.py (the
+        per-face loop (get_all_outputs_batch with one frame).  `rects` = detections [[xmin,ymin,xmax,ymax,score], ...];
+        when omitted the `face_detector(image)` is called -- by default the HIP FaceBoxes of synergynet_amd/faceboxes.py (the
         reference constructs FaceBoxes here, :170-171)."""
-        from .inference import lanczos4_tables
         if rects is None:
-            if self.face_detector is None:
-                # the reference builds FaceBoxes() on every call (:170-171); here once, on first use (HIP kernels,
-                # synergynet_amd/faceboxes.py; needs FaceBoxes/weights/FaceBoxesProd.pth or model.face_detector = FaceBoxes(state_dict=...))
-                from .faceboxes import FaceBoxes
-                self.face_detector = FaceBoxes(device=self.device)
-            rects = self.face_detector(input)
-        pts_res, vertices_lst, poses = [], [], []
-        if len(rects) == 0:
-            return pts_res, vertices_lst, poses
-        rois, boxes, xo, xc, yo, yc = [], [], [], [], [], []
-        for rect in rects:
-            roi_box = rect                      # aliases and mutates the caller's list like the reference (:178,185)
-            HCenter = (rect[1] + rect[3]) / 2
-            WCenter = (rect[0] + rect[2]) / 2
-            side_len = roi_box[3] - roi_box[1]
-            margin = side_len * 1.2 // 2
-            roi_box[0], roi_box[1], roi_box[2], roi_box[3] = WCenter - margin, HCenter - margin, WCenter + margin, HCenter + margin
-            rois.append([float(v) for v in roi_box[:5]])
-            sx, sy, ex, ey = [int(round(v)) for v in roi_box[:4]]         # crop_img's rounding (utils/inference.py:98)
-            if ex - sx <= 0 or ey - sy <= 0:
-                raise ValueError('degenerate detection box')
-            boxes.append([sx, sy, ex, ey])
-            a, b = lanczos4_tables(ex - sx)
-            xo.append(a); xc.append(b)
-            a, b = lanczos4_tables(ey - sy)
-            yo.append(a); yc.append(b)
-        rois = np.asarray(rois, dtype=np.float32)
-        crops = self.crop_resize(input, np.asarray(boxes, dtype=np.int32), np.stack(xo), np.stack(xc), np.stack(yo), np.stack(yc))
-        param = self.forward_crops_u8(crops)
-        lmk = self.reconstruct(param, roi=rois, dense=False, transform=True).cpu().numpy()
-        mesh = self.reconstruct(param, roi=rois, dense=True, transform=True).cpu().numpy()
-        ang, t3d = self.predict_pose_batch(param, rois)
-        ang, t3d = ang.cpu().numpy(), t3d.cpu().numpy()
-        for i in range(len(rects)):
-            pts_res.append(lmk[i])
-            vertices_lst.append(mesh[i])
-            poses.append([[float(v) for v in ang[i]], t3d[i]])
-        return pts_res, vertices_lst, poses
+            rects = self._detect(input)
+        return self.get_all_outputs_batch([input], [rects])[0]

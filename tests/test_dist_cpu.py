@@ -180,3 +180,47 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- bench.py's own multi-process launch (`python bench.py --gpus N` outside torchrun), driven WITHOUT GPUs (--dry-run) ----
+def _run_bench(args, env=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    e = dict(os.environ, **(env or {}))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_spawn_ranks_dry_run(world):
+    """spawn_ranks -> N ranks -> gloo rendezvous on 127.0.0.1 -> broadcast of the REAL packed constants (device-free packer on rank
+    0, the library's acceptance checks on every receiver) -> face shards -> barrier-bracketed timing, MAX over ranks -> per-rank
+    report -> ONE JSON line on rank 0's stdout: the launch path of the N > 1 bench, executed before any 8-GPU box sees it."""
+    import json
+    r = _run_bench(['--gpus', str(world), '--dry-run', '--steps', '10', '--warmup', '2'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    d = out['distributed']
+    assert out['dry_run'] is True and out['n_gpus'] == world and d['world'] == world and d['backend'] == 'gloo'
+    assert out['config']['global_batch'] == 1024 * world and out['scaling'] == 'weak'
+    assert len(d['per_rank_faces_s']) == world and d['min_rank_faces_s'] <= d['max_rank_faces_s']
+    assert d['rank_host_threads'] == [1] * world                    # no rank starts a machine-wide thread pool
+    assert d['constants_bytes'] > 9_000_000                          # header + folded backbone + basis went over the wire
+    # whole-job rate = all ranks' faces over the slowest rank's time
+    assert out['value'] <= sum(d['per_rank_faces_s']) * 1.001
+
+
+def test_bench_spawn_ranks_fails_fast_when_a_rank_dies():
+    """A rank that dies before the rendezvous must not leave its peers waiting for the collective timeout: spawn_ranks polls its
+    children, stops the others and returns the failing status."""
+    import time
+    t0 = time.time()
+    r = _run_bench(['--gpus', '4', '--dry-run', '--steps', '10', '--warmup', '2'], env={'SYN_BENCH_FAIL_RANK': '2'}, timeout=120)
+    assert r.returncode == 3
+    assert 'rank 2 exited with status 3' in r.stderr
+    assert time.time() - t0 < 60
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]

@@ -34,7 +34,7 @@ def model(pack, backbone_sd):
     import torch
     assert torch.cuda.is_available(), 'GPU tests need an MI355X'
     from synergynet_amd.synergy3DMM import SynergyNet
-    return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)       # default schedule (fused + bf16x3)
+    return SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)       # default schedule (fused, fp16x2 operands)
 
 
 @pytest.fixture(scope='module')

@@ -15,15 +15,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope='module', params=['fused+bf16x3', 'fused-fp32', 'per-layer'])
+@pytest.fixture(scope='module', params=['fused+fp16x2', 'fused-fp32', 'per-layer'])
 def model(request, pack, backbone_sd):
     """The backbone schedules of the library (SYNERGY_HIP_FUSION, read at syn_create): 1 = fused inverted-residual
-    blocks on the fp32 MFMA, 0 = one kernel per layer, 2 = fused + GEMMs on the bf16 matrix pipe through the exact
-    3-way bf16 operand split."""
+    blocks on the fp32 MFMA, 0 = one kernel per layer, 2 (default) = fused blocks / chains with every GEMM on the fp16 matrix
+    instructions through the two-piece operand split."""
     import torch
     assert torch.cuda.is_available(), 'GPU tests need an MI355X'
     from synergynet_amd.synergy3DMM import SynergyNet
-    os.environ['SYNERGY_HIP_FUSION'] = {'fused-fp32': '1', 'per-layer': '0', 'fused+bf16x3': '2'}[request.param]
+    os.environ['SYNERGY_HIP_FUSION'] = {'fused-fp32': '1', 'per-layer': '0', 'fused+fp16x2': '2'}[request.param]
     try:
         m = SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
         m._test_fusion = os.environ['SYNERGY_HIP_FUSION']
@@ -96,8 +96,8 @@ def test_u8_ingest_equals_fp32_ingest(model, golden):
     assert rel_max(p8.cpu().numpy(), golden['param_net']) < TOL
     assert rel_l2(p8.cpu().numpy(), golden['param_net']) < TOL
     if model._test_fusion == '2':
-        # bf16x3 schedule: the uint8 stem runs on the bf16 matrix pipe (normalised uint8 pixels are exact bf16
-        # numbers, the filter is split exactly 3-way) while fp32 crops take the fp32 MFMA -> equal to fp32 rounding
+        # default schedule: the uint8 stem runs on the 16-bit matrix pipe (raw / normalised uint8 pixels are exact 16-bit
+        # numbers, only the filter is split) while fp32 crops take the fp32 MFMA -> equal to fp32 rounding
         assert rel_max(p8.cpu().numpy(), pf.cpu().numpy()) < 1e-5
     else:
         assert np.array_equal(p8.cpu().numpy(), pf.cpu().numpy())     # same arithmetic, bit-identical
@@ -203,8 +203,8 @@ def model_tiled_early(model, pack, backbone_sd):
 
 @pytest.mark.parametrize('B', [1, 2, 5, 96, 97, 190, 192, 193, 194, 200])
 def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, B):
-    """Below ~200 faces the late blocks and the tail run in the output-channel-sliced schedule (fused_block_bf3.hip
-    kSliceMaxGrid, head_kernel.hip launch_head_bf16x3); a face's parameters must not depend on which schedule ran."""
+    """Below ~200 faces the late blocks and the tail run in the output-channel-sliced schedule (fused_block_f16.hip
+    kSliceMaxGrid, head_kernel.hip launch_head_f16x2); a face's parameters must not depend on which schedule ran."""
     import torch
     from synergynet_amd import synth
     model = model_tiled_early
@@ -463,6 +463,39 @@ def test_get_all_outputs_shapes_and_consistency(model):
     # asks for its weights file (absent in this repo), FaceBoxes/utils/functions.py:30-32
     with pytest.raises(RuntimeError, match='FaceBoxes model'):
         model.get_all_outputs(img)
+
+
+def test_get_all_outputs_batch_equals_per_frame_calls(model):
+    """get_all_outputs_batch (many frames, ONE forward / reconstruction / download) returns, per frame, exactly what
+    get_all_outputs returns for that frame -- frames of different sizes, a frame without faces, boxes over the border -- as
+    contiguous float32 arrays the caller owns; the detection lists are mutated into the ROI like the reference does (:178,185)."""
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((480, 640, 3), (300, 400, 3), (720, 1080, 3), (200, 200, 3))]
+    rects = [[[100.0, 80.0, 260.0, 270.0, 0.99], [400.0, 200.0, 560.0, 420.0, 0.95]],
+             [],
+             [[10.5, 20.25, 300.0, 333.0, 0.9], [700.0, 400.0, 1075.0, 715.0, 0.8], [500.0, 100.0, 640.0, 260.0, 0.7]],
+             [[-20.0, -10.0, 150.0, 170.0, 0.6]]]
+    mine = [[list(r) for r in fr] for fr in rects]
+    out = model.get_all_outputs_batch(frames, mine)
+    assert len(out) == 4 and out[1] == ([], [], [])
+    for f, fr_rects, got, mutated in zip(frames, rects, out, mine):
+        single = [list(r) for r in fr_rects]
+        want = model.get_all_outputs(f, rects=single)
+        assert mutated == single                                   # same ROI written back into the caller's lists
+        for g, w in zip(got[:2], want[:2]):
+            assert len(g) == len(w) == len(fr_rects)
+            for a, b in zip(g, w):
+                assert a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable and np.array_equal(a, b)
+        for (ga, gt), (wa, wt) in zip(got[2], want[2]):
+            assert ga == wa and isinstance(ga[0], float) and np.array_equal(gt, wt)
+    # landmarks + pose only
+    lite = model.get_all_outputs_batch(frames, [[list(r) for r in fr] for fr in rects], dense=False)
+    for a, b in zip(lite, out):
+        assert a[1] == [] and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    # results stay valid after later calls (every call owns its host blocks)
+    keep = out[0][1][0].copy()
+    model.get_all_outputs_batch(frames[2:], [[list(r) for r in fr] for fr in rects[2:]])
+    assert np.array_equal(out[0][1][0], keep)
 
 
 @pytest.fixture(scope='module')

@@ -5,9 +5,9 @@ set -e
 tag=$1; name=$2; var=$3; shift 3
 R=$(cd $(dirname $0)/.. && pwd)
 python -c "from synergynet_amd.build import build_library; build_library()" >/dev/null
-o=$R/synergynet_amd/_obj/${name%.hip}_$tag.o
+mkdir -p $R/synergynet_amd/_obj/variants
+o=$R/synergynet_amd/_obj/variants/${name%.hip}_$tag.o      # variant objects never share a directory with the default build
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I$R/synergynet_amd/csrc -c $var -o $o "$@"
-objs=$(ls $R/synergynet_amd/_obj/*.o | grep -v "_[A-Za-z0-9]*\.o$" | grep -v "/${name%.hip}.o$" || true)
 objs=$(python - <<PY
 import os
 from synergynet_amd.build import SOURCES, OBJ

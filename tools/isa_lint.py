@@ -41,7 +41,7 @@ def main():
                 flag = ''
                 if scratch or spill:
                     # PROF = second template argument of the fused-block kernels, third of the reconstruction kernel
-                    is_prof = bool(re.search(r'(fused_block_\w+<.*>, true(, \d+)?(, (true|false))?>$)|(recon_b3_kernel<\d+, (true|false), true>$)', short))
+                    is_prof = bool(re.search(r'(fused_block_\w+<.*>, true(, \d+)?(, (true|false))?>$)|(recon_f16_kernel<\d+, (true|false), true>$)', short))
                     flag = '  <-- spills (profiling instantiation)' if is_prof else '  <-- SPILLS / SCRATCH'
                     bad += 0 if is_prof else 1
                 print(f'   {vgpr:4d} vgprs {spill:4d} spilled {scratch:5d} B scratch  {short}{flag}')

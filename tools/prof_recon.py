@@ -1,4 +1,4 @@
-"""GPU box: per-stage ticks of recon_b3_kernel (SYN_RECON_PROF=1 makes launch_reconstruct_b3 run the instrumented variant
+"""GPU box: per-stage ticks of recon_f16_kernel (SYN_RECON_PROF=1 makes launch_reconstruct_f16 run the instrumented variant
 and print averages per workgroup to stderr; s_memtime ticks are 10 ns)."""
 import os, sys
 os.environ['SYN_RECON_PROF'] = '1'

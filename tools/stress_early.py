@@ -1,4 +1,4 @@
-"""GPU box: compare features.2-4 of the bf16x3 schedule against the fp32-MFMA schedule on many random batches."""
+"""GPU box: compare features.2-4 of the default (fp16x2) schedule against the fp32-MFMA schedule on many random batches."""
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from synergynet_amd import abi, synth
