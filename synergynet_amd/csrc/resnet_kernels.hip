@@ -21,13 +21,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // act: 0 none, 1 ReLU (applied AFTER the residual add: out = relu(bn3(conv3) + identity), resnet_backbone.py:130-134).
 // =====================================================================================
 // Run-time range guard of the fp16 x2 convolutions (ReLU networks have no static activation bound: synergy_abi.hip run_resnet50):
-// every kernel whose output a later convolution splits into fp16 pieces folds max |output| into its slot of a per-forward status
-// array -- one v_max per output element, one wave reduction and ONE atomic per wave.  Non-negative floats order like their bit
-// patterns, so the atomic is an unsigned max.  pool_fc_generic_kernel poisons its results with NaN when a slot left the fp16 window.
+// every kernel whose output a later convolution splits into fp16 pieces folds max |output| into the status array of the forward --
+// one v_max per output element, one wave reduction and ONE fire-and-forget atomic per wave.  Non-negative floats order like their
+// bit patterns, so the atomic is an unsigned max.  Tens of thousands of waves report per launch, and device-scope atomics on ONE
+// address serialise in that address's memory-side channel (measured: +100 us per convolution, ResNet-50 8.3 -> 13.7 ms; filtering
+// them by a load of the current maximum costs an L2 round trip per wave instead: 9.2 - 11.6 ms), so a tensor has kRangeSub
+// sub-slots kRangeStride floats apart and a wave reports into the one its workgroup index selects; pool_fc_generic_kernel takes the
+// maximum over the sub-slots and poisons its results with NaN when a tensor left the fp16 window.
 __device__ __forceinline__ void range_note(float *stat, float m) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(stat), __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned *>(stat + (size_t)(blockIdx.x % kRangeSub) * kRangeStride), __builtin_bit_cast(unsigned, m));
 }
 
 template <int MT, int NT>
@@ -572,9 +577,15 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
     // range guard: a tensor that some fp16 x2 convolution split left the fp16 window (kRangeHi / kRangeLo) -> the results of this
     // forward are NOT fp32-class: make that loud (NaN) instead of returning plausible numbers
     float poison = 0.f;
-    for (int i = 0; i < n_stat; ++i) {
-        const float m = stat[i];
-        if (!(m <= kRangeHi) || !(m >= kRangeLo)) poison = __builtin_nanf("");
+    if (n_stat > 0) {                                  // (kernel-uniform) four threads per tensor, 16 sub-slots each
+        const int t = threadIdx.x >> 2, q = threadIdx.x & 3;
+        float m = 0.f;
+        if (t < n_stat)
+            for (int i = 0; i < kRangeSub / 4; ++i) m = fmaxf(m, stat[((size_t)t * kRangeSub + q * (kRangeSub / 4) + i) * kRangeStride]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        const int bad = t < n_stat && (!(m <= kRangeHi) || !(m >= kRangeLo));
+        if (__syncthreads_or(bad)) poison = __builtin_nanf("");
     }
     const float *f = feat + (size_t)b * P * C;
     const float inv = 1.0f / (float)P;

@@ -136,6 +136,9 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
 // window of a tensor's max |x| inside which the fp16 x2 split of an UNSCALED activation keeps >= 15 bits relative to that maximum:
 // above kRangeHi v_cvt_pkrtz_f16_f32 saturates, below kRangeLo even the largest element's low piece is a 4-bit subnormal
 constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10
+// layout of the status array: tensor t owns kRangeSub sub-slots, kRangeStride floats (256 B) apart: stat[(t * kRangeSub + sub) * kRangeStride];
+// launchers receive the tensor's base pointer
+constexpr int kRangeSub = 64, kRangeStride = 64;
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 // 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,

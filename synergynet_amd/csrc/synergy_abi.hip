@@ -297,7 +297,7 @@ struct syn_handle {
     int early_rm = 1023;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
-    float *d_range = nullptr;      // resnet50 run-time range guard: [64] per-tensor max |x| of the last forward | [64] its initial values
+    float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
     uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
@@ -646,12 +646,17 @@ bool resnet_stat_used(int slot) {
     for (const RBlock &b : n.blocks) if (b.ds == ci) return false;
     return ci != n.blocks.back().c3;
 }
+constexpr size_t kRangeFloats = (size_t)64 * syn::kRangeSub * syn::kRangeStride;      // 64 tensors x sub-slots x stride (1 MiB)
+float *range_slot(float *base, int t) { return base + (size_t)t * syn::kRangeSub * syn::kRangeStride; }
 int ensure_range(syn_handle *h) {
     if (h->d_range) return SYN_OK;
-    HIP_TRY(hipMalloc((void **)&h->d_range, 128 * sizeof(float)));
-    float init[128];
-    for (int i = 0; i < 64; ++i) init[i] = init[64 + i] = (i < kResnetStat && resnet_stat_used(i)) ? 0.0f : 1.0f;
-    HIP_TRY(hipMemcpy(h->d_range, init, sizeof init, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&h->d_range, 2 * kRangeFloats * sizeof(float)));      // live copy | initial values
+    std::vector<float> init(kRangeFloats, 0.f);
+    for (int t = 0; t < 64; ++t)
+        if (!(t < kResnetStat && resnet_stat_used(t)))
+            for (int i = 0; i < syn::kRangeSub; ++i) init[((size_t)t * syn::kRangeSub + i) * syn::kRangeStride] = 1.0f;
+    HIP_TRY(hipMemcpy(h->d_range + kRangeFloats, init.data(), kRangeFloats * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_range, init.data(), kRangeFloats * sizeof(float), hipMemcpyHostToDevice));
     return SYN_OK;
 }
 
@@ -673,14 +678,14 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         rc = ensure_range(h);
         if (rc) return rc;
         stat = h->d_range;
-        HIP_TRY(hipMemcpyAsync(stat, stat + 64, 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(stat, stat + kRangeFloats, kRangeFloats * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     auto conv = [&](int ci, const float *in, const float *res, float *out, int act) {
         const RConv &c = n.convs[ci];
         if (f16 && c.dst_w3 && !(h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u))) {
             syn::launch_conv_f16x2(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
                                  c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s,
-                                 stat && resnet_stat_used(1 + ci) ? stat + 1 + ci : nullptr);
+                                 stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr);
             return;
         }
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
@@ -1313,7 +1318,14 @@ int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, i
     DeviceGuard g(h->device);
     float st[64];
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(st, h->d_range, sizeof st, hipMemcpyDeviceToHost));
+    {
+        std::vector<float> raw(kRangeFloats);
+        HIP_TRY(hipMemcpy(raw.data(), h->d_range, kRangeFloats * sizeof(float), hipMemcpyDeviceToHost));
+        for (int t = 0; t < 64; ++t) {
+            st[t] = 0.f;
+            for (int i = 0; i < syn::kRangeSub; ++i) st[t] = fmaxf(st[t], raw[((size_t)t * syn::kRangeSub + i) * syn::kRangeStride]);
+        }
+    }
     int bad = 0;
     for (int i = 0; i < kResnetStat; ++i) bad += !(st[i] <= syn::kRangeHi) || !(st[i] >= syn::kRangeLo);
     for (int i = 0; layer_max && i < max_layers && i < 64; ++i) layer_max[i] = st[i];

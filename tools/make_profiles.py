@@ -1,6 +1,6 @@
 """Copy a tools/round_profile.sh result directory into profiles/<name>/ and derive profiles/traffic_<name>.json.
 usage: python tools/make_profiles.py gpurun_out/round_<tag> r2"""
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, shutil, subprocess, sys, time
 src, name = sys.argv[1], sys.argv[2]
 dst = os.path.join('profiles', name)
 os.makedirs(dst, exist_ok=True)
@@ -14,6 +14,7 @@ def cp(a, b):
 cp('stats/k_kernel_stats.csv', 'kernel_stats_b1024.csv')
 cp('stats1/k_kernel_stats.csv', 'kernel_stats_b1024_one_stream.csv')
 cp('stats_r50/k_kernel_stats.csv', 'resnet50_kernel_stats_b512.csv')
+cp('stats_b128/k_kernel_stats.csv', 'kernel_stats_b128_lmk_only.csv')
 cp('stats/k_agent_info.csv', 'agent_info.csv')
 cp('bench.json', 'bench_b1024.json')
 cp('bench_force_dist.json', 'bench_force_dist_b1024.json')
@@ -57,7 +58,25 @@ for k in fetch:
     if k in fam:
         busy_sum += m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) * raw['mfma_launches'][k]
         act_sum += simd_cycles * raw['mfma_launches'][k]
-out = dict(source='rocprofv3 --kernel-trace --pmc <one counter group per run> of bench.py B=1024 --overlap 0 (tools/round_profile.sh): '
+def git(*a):
+    try:
+        return subprocess.run(['git'] + list(a), capture_output=True, text=True).stdout.strip()
+    except OSError:
+        return ''
+
+
+# provenance (bench.py prints it as roofline.counters_source): the commit the bundle was taken at -- recorded by round_profile.sh's
+# caller in <src>/commit.txt, else HEAD now, marked dirty when the kernels differ from it -- and the box
+commit = open(os.path.join(src, 'commit.txt')).read().strip() if os.path.isfile(os.path.join(src, 'commit.txt')) else git('rev-parse', '--short=12', 'HEAD')
+if git('status', '--porcelain', '--', 'synergynet_amd/csrc', 'bench.py'):
+    commit += '+dirty'
+box = None
+if os.path.isfile(os.path.join(dst, 'agent_info.csv')):
+    rows = [r for r in csv.DictReader(open(os.path.join(dst, 'agent_info.csv'))) if r.get('Agent_Type') == 'GPU']
+    if rows:
+        box = '%s (%s CUs, %s MHz max)' % (rows[0].get('Name'), rows[0].get('Cu_Count'), rows[0].get('Max_Engine_Clk_Fcompute'))
+out = dict(commit=commit, box=box, collected=time.strftime('%Y-%m-%d', time.gmtime(os.path.getmtime(os.path.join(src, 'pmc_raw.json')))),
+           source='rocprofv3 --kernel-trace --pmc <one counter group per run> of bench.py B=1024 --overlap 0 (tools/round_profile.sh): '
                   'FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads), KB -> bytes; '
                   'mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 128): the counter sums the per-SIMD busy cycles '
                   'of all 1024 SIMDs and GRBM_GUI_ACTIVE arrives summed over the 8 XCDs',
