@@ -349,8 +349,8 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
                      unsigned long long *prof = nullptr) {
     unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
     constexpr int SS = WPG * 32 + 4;                                          // stage row stride (16-byte aligned rows)
-    constexpr int NTH = WPG * 64, TQ = kRecTileF16 / 4, NPF = (TQ + NTH - 1) / NTH;   // operand tile: 16-byte quads, quads per thread
-    __shared__ __attribute__((aligned(16))) unsigned optile[2][kRecTileF16];  // alpha pieces (MFMA lane order, 7 fragments) | 32 x 16 fp32 records
+    constexpr int NTH = WPG * 64, TQ = kRecTileF16 / 4, NPF = (TQ + NTH - 1) / NTH, TQP = NPF * NTH;
+    __shared__ __attribute__((aligned(16))) unsigned optile[2][TQP * 4];
     __shared__ __attribute__((aligned(16))) float stage[96 * SS];            // [face*3 + coord][WPG tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int per_xcd = (n_units + 7) / 8;                                    // XCD-aware unit order (see recon_kernel)
@@ -380,21 +380,14 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
     if (ft0 >= ft1) return;                          // (workgroup-uniform)
 
     u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
-    auto fetch = [&](int ft) {                       // branch-free (index clamped): no control flow around in-flight loads
+    auto fetch = [&](int ft) {
         const unsigned *rt = rec3 + (size_t)ft * kRecTileF16;
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            int q = i * NTH + (int)threadIdx.x;
-            q = q < TQ ? q : TQ - 1;
-            pf[i] = *(const u32x4 *)(rt + 4 * q);
-        }
+        for (int i = 0; i < NPF; ++i) pf[i] = *(const u32x4 *)(rt + 4 * (i * NTH + (int)threadIdx.x));
     };
     auto park = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int q = i * NTH + (int)threadIdx.x;
-            if ((i + 1) * NTH <= TQ || q < TQ) *(u32x4 *)&optile[buf][4 * q] = pf[i];
-        }
+        for (int i = 0; i < NPF; ++i) *(u32x4 *)&optile[buf][4 * (i * NTH + (int)threadIdx.x)] = pf[i];
     };
     fetch(ft0);
     park(0);                                         // waits for everything issued so far: the loop starts with no load in flight
