@@ -74,6 +74,55 @@ __global__ __launch_bounds__(256) void k_aligned(float *out, int B, int n_vert, 
         __syncthreads();
     }
 }
+// Peeled variant: the same 128-vertex ownership as k<128>, but per row the run is written as its line-aligned interior (three whole
+// 128-byte lines: lanes 0-23, float4 each, 8 lanes per line) plus the head and tail floats around it (32 in total: lanes 24-31, four
+// scalar stores each).  Same bytes, same partial lines at the ends -- only the packaging of the store instructions differs.
+__global__ __launch_bounds__(256) void k_peel(float *out, int B, int n_vert, int n_groups, int n_split, int per, int n_ftiles, int n_units) {
+    const int per_xcd = (n_units + 7) / 8;
+    const int unit = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
+    const int tg = unit / n_split, split = unit - tg * n_split;
+    const int ft0 = split * per, ft1 = min(ft0 + per, n_ftiles);
+    const int seg = threadIdx.x % 32, rsub = threadIdx.x / 32;
+    const f32x4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (int ft = ft0; ft < ft1; ++ft) {
+        for (int kk = 0; kk < 12; ++kk) {
+            const int row = kk * 8 + rsub;
+            const long r = (long)ft * 96 + row;
+            if (r >= 3L * B) continue;
+            const size_t rowoff = (size_t)r * n_vert;
+            const int v0 = tg * 128;
+            const int lead = (int)((32 - ((rowoff + v0) & 31)) & 31);     // floats before the first line boundary inside the run
+            float *o = out + rowoff + v0;
+            if (seg < 24) {
+                const int vv = lead + 4 * seg;
+                if (v0 + vv + 3 < n_vert) *(f32x4 *)(o + vv) = v;
+            } else {
+                // the 32 floats around the body: [0, lead) and [lead + 96, 128)
+                for (int t = 0; t < 4; ++t) {
+                    int i = 4 * (seg - 24) + t;
+                    i = i < lead ? i : i + 96;
+                    if (v0 + i < n_vert) o[i] = 1.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+void run_peel(float *d, int B, int nv, int target_wgs) {
+    const int n_groups = (nv + 127) / 128, n_ftiles = (B + 31) / 32;
+    int n_split = (target_wgs + n_groups - 1) / n_groups; n_split = n_split < 1 ? 1 : (n_split > n_ftiles ? n_ftiles : n_split);
+    const int per = (n_ftiles + n_split - 1) / n_split; n_split = (n_ftiles + per - 1) / per;
+    const int n_units = n_groups * n_split, grid = ((n_units + 7) / 8) * 8;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    k_peel<<<grid, 256>>>(d, B, nv, n_groups, n_split, per, n_ftiles, n_units); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < 10; ++i) k_peel<<<grid, 256>>>(d, B, nv, n_groups, n_split, per, n_ftiles, n_units);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
+    printf("peeled 512 B runs (3 whole lines + head/tail)  wgs=%5d (split %2d, %d ftiles each) : %.1f us  %.2f TB/s\n", n_units, n_split, per, ms * 1e3,
+           (double)B * 3 * nv * 4 / ms / 1e9);
+}
 void run_aligned(float *d, int B, int nv, int target_wgs) {
     const int n_groups = (nv + 95) / 96, n_ftiles = (B + 31) / 32;
     int n_split = (target_wgs + n_groups - 1) / n_groups; n_split = n_split < 1 ? 1 : (n_split > n_ftiles ? n_ftiles : n_split);
@@ -110,6 +159,7 @@ int main(int argc, char **argv) {
         run<128>(d, B, nv, 3072, xcd); run<256>(d, B, nv, 3072, xcd); run<512>(d, B, nv, 3072, xcd); run<1024>(d, B, nv, 3072, xcd);
     }
     run_aligned(d, B, nv, 3072); run_aligned(d, B, nv, 4400); run_aligned(d, B, nv, 1600);
+    run_peel(d, B, nv, 3072); run_peel(d, B, nv, 1664); run<128>(d, B, nv, 1664, 1);
     run<128>(d, B, nv, 512, 2); run<128>(d, B, nv, 1600, 2); run<128>(d, B, nv, 100000, 2); run<256>(d, B, nv, 100000, 2);
     return 0;
 }
