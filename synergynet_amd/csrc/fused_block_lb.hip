@@ -807,7 +807,7 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 // The chain launch: mode 0 = off (one launch per block), 1 = features.8-13, 2 = features.8-14, 3 = features.7-14 (SYN_LB_CHAIN; default 3)
 int lb_chain_mode(int B) {
     static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
-    static const int chain_min = getenv("SYN_LB_CHAIN_MIN") ? atoi(getenv("SYN_LB_CHAIN_MIN")) : 384;      // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
+    constexpr int chain_min = 384;      // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
     if (chain <= 0 || B < chain_min) return 0;
     return chain > 3 ? 3 : chain;
 }
@@ -829,24 +829,17 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int
     return true;
 }
 
-static int lb_min_batch(int feature) {
-    // below: too few workgroups to put two on every CU (the tiled kernel is faster); SYN_LB_MIN<f> overrides
-    char name[32];
-    snprintf(name, sizeof name, "SYN_LB_MIN%d", feature);
-    if (const char *e = getenv(name)) return atoi(e);
-    return 768;
-}
+// below: too few workgroups to put two on every CU (the hidden-sliced schedule, or the tiled kernel, is faster)
+constexpr int kLbMinBatch = 768;
 
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Alb_e || !a.Alb_p || !a.Tlb) return false;
-    if (B < lb_min_batch(feature)) {
-        // small batches: hidden-sliced (SYN_LB_SLICED: bit f - 7 enables features.f).  Measured (us, tiled -> sliced): B = 128: features.12 / 13 / 14
+    if (B < kLbMinBatch) {
+        // small batches: hidden-sliced.  Measured (us, tiled -> sliced): B = 128: features.12 / 13 / 14
         // 42 / 40 / 25 -> 25 / 29 / 21, features.8-11 20-22 -> 17-20; B = 512: 47 / 46 / 30 -> 42 / 42 / 31, but features.8-11 24-28 -> 27-32:
         // the narrow blocks only up to 192 faces.
-        static const int sliced = getenv("SYN_LB_SLICED") ? atoi(getenv("SYN_LB_SLICED")) : 0xFE;
-        static const int sl_min = getenv("SYN_LB_SLICED_MIN") ? atoi(getenv("SYN_LB_SLICED_MIN")) : 32;
-        static const int narrow_max = getenv("SYN_LB_SLICED_NARROW_MAX") ? atoi(getenv("SYN_LB_SLICED_NARROW_MAX")) : 192;
-        if (B < sl_min || !((sliced >> (feature - 7)) & 1) || (feature < 12 && B > narrow_max)) return false;
+        constexpr int sl_min = 32, narrow_max = 192;
+        if (B < sl_min || feature < 8 || (feature < 12 && B > narrow_max)) return false;
         switch (feature) {
             case 8: case 9: case 10: return launch_lb_sliced<L8>(a, B, s);
             case 11: return launch_lb_sliced<L11>(a, B, s);

@@ -369,7 +369,7 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
 }
 
 static int lb4_min_batch() {
-    static const int min_b = getenv("SYN_LB4_MIN") ? atoi(getenv("SYN_LB4_MIN")) : 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
+    constexpr int min_b = 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
     return min_b;
 }
 
@@ -389,7 +389,7 @@ bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Glb || a.prof) return false;
     if (B < lb4_min_batch()) {
-        static const int sl_min = getenv("SYN_LB4_SLICED_MIN") ? atoi(getenv("SYN_LB4_SLICED_MIN")) : 32;      // below: the tiled kernel's own sliced schedule
+        constexpr int sl_min = 32;      // below: the tiled kernel's own sliced schedule
         if (B < sl_min) return false;
         switch (feature) {
             case 15: case 16: return launch_lb4_sliced<Q15>(a, B, s);

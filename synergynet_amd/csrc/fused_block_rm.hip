@@ -529,7 +529,6 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 template <class C>
 static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
     const int n_units = (B + C::NF - 1) / C::NF;
-    if (const char *e = getenv("SYN_RM_WGS")) wgs_per_cu = atoi(e);      // tuning knob: persistent workgroups per CU
     const int cap = 256 * wgs_per_cu, wgs = (n_units + C::U - 1) / C::U;  // persistent: as many workgroups as the CUs hold at once
     const int grid = wgs < cap ? wgs : cap;
     if (a.prof)
@@ -551,34 +550,27 @@ template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, S
 template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
 template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true>;             // features.5/6 15            U x (6 + 1) waves, two faces per unit, 4 per SIMD
 
-namespace {
-int rm_threshold(const char *env, int dflt) {
-    const char *e = getenv(env);
-    return e ? atoi(e) : dflt;
-}
-}  // namespace
-
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p) return false;
-    // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N; SYN_RM_MIN<f>_<U> override them).  The kernels are
+    // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N).  The kernels are
     // persistent over 256 workgroups: 513 faces is where the smaller configuration needs a second round of workgroups (B = 640, us: features.2
     // 123 -> 91, features.4 74 -> 52, features.5/6 51 / 49 -> 43 / 42 with the larger one; at B = 512 the smaller one wins: 66 / 42 / 36 vs 88 / 50 / 41)
     switch (feature) {
         case 2:
-            if (B >= rm_threshold("SYN_RM_MIN2_4", 513)) { launch_rm<R2<4>>(a, B, s, 1); return true; }
-            if (B >= rm_threshold("SYN_RM_MIN2_2", 352)) { launch_rm<R2<2>>(a, B, s, 1); return true; }
+            if (B >= 513) { launch_rm<R2<4>>(a, B, s, 1); return true; }
+            if (B >= 352) { launch_rm<R2<2>>(a, B, s, 1); return true; }
             return false;
         case 3:
-            if (B >= rm_threshold("SYN_RM_MIN3_2", 448)) { launch_rm<R3<2>>(a, B, s, 1); return true; }
-            if (B >= rm_threshold("SYN_RM_MIN3_1", 200)) { launch_rm<R3<1>>(a, B, s, 1); return true; }
+            if (B >= 448) { launch_rm<R3<2>>(a, B, s, 1); return true; }
+            if (B >= 200) { launch_rm<R3<1>>(a, B, s, 1); return true; }
             return false;
         case 4:
-            if (B >= rm_threshold("SYN_RM_MIN4_2", 513)) { launch_rm<R4<2>>(a, B, s, 1); return true; }
-            if (B >= rm_threshold("SYN_RM_MIN4_1", 480)) { launch_rm<R4<1>>(a, B, s, 1); return true; }
+            if (B >= 513) { launch_rm<R4<2>>(a, B, s, 1); return true; }
+            if (B >= 480) { launch_rm<R4<1>>(a, B, s, 1); return true; }
             return false;
         case 5:
         case 6:
-            if (B >= rm_threshold("SYN_RM_MIN5_2", 513)) { launch_rm<R5<2>>(a, B, s, 1); return true; }
+            if (B >= 513) { launch_rm<R5<2>>(a, B, s, 1); return true; }
             return false;
         default: return false;
     }

@@ -475,8 +475,7 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
                      hipStream_t s, float *stat) {
     const int M = B * Hout * Hout;
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
-    static const int shared = getenv("SYN_CONV_SHARED") ? atoi(getenv("SYN_CONV_SHARED")) : 1;     // 0: every wave fetches its own fragments
-    if (shared && N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
+    if (N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
         if (tiles >= 1024) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);

@@ -281,8 +281,8 @@ bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shi
     if (!img8 || !As3 || !Ap3 || !scl_p) return false;
     // like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
     // threshold, the spatially tiled kernel (stem_block1.hip)
-    static const int min4 = getenv("SYN_RM_MIN1_4") ? atoi(getenv("SYN_RM_MIN1_4")) : 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)
-    static const int min2 = getenv("SYN_RM_MIN1_2") ? atoi(getenv("SYN_RM_MIN1_2")) : 480;
+    constexpr int min4 = 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)
+    constexpr int min2 = 480;
     if (B >= min4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     if (B >= min2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     return false;
