@@ -241,6 +241,12 @@ int syn_backbone_launch_count(syn_handle *h);
 int syn_backbone_profile(syn_handle *h, const uint8_t *img_hwc, int B, int max_launches,
                          int *feature_of_launch, float *ms_of_launch, double *flops_of_launch);
 
+/* The dense reconstruction (transform = 1) into a pitched output with HIP events around its kernels, on the default stream;
+ * synchronises.  ms2[0] = per-face prologue, ms2[1] = the contraction + pose epilogue + mesh stores -- the HBM-write-bound kernel
+ * of the path (B * 3 * n_vert * 4 bytes).  Arguments as syn_reconstruct_pitched. */
+int syn_reconstruct_profile(syn_handle *h, const float *param, int B, const float *roi, float *out, int row_pitch, int pad_writable,
+                            float *ms2);
+
 /* Algorithmic FLOPs per face of the whole backbone / of its pointwise (MFMA) convolutions. */
 double syn_backbone_flops_per_face(void);
 double syn_pointwise_flops_per_face(void);

@@ -64,6 +64,7 @@ _SIGS = {
     'syn_pose_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'syn_backbone_launch_count': (C.c_int, [C.c_void_p]),
     'syn_backbone_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'syn_reconstruct_profile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'syn_backbone_flops_per_face': (C.c_double, []),
     'syn_pointwise_flops_per_face': (C.c_double, []),
 }

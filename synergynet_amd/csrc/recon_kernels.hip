@@ -498,10 +498,13 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
 }
 
 void launch_reconstruct_f16(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
-                           int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3f) {
+                           int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3f,
+                           hipEvent_t *marks /* nullable: [3] recorded before the prologue, after it, after the contraction */) {
     unsigned *rec3 = reinterpret_cast<unsigned *>(rec3f);
     const int n_ftiles = (B + 31) / 32;
+    if (marks) (void)hipEventRecord(marks[0], s);
     recon_prep_f16_kernel<<<n_ftiles, 64, 0, s>>>(param, mean62, std62, roi, transform, rec3, B);
+    if (marks) (void)hipEventRecord(marks[1], s);
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
@@ -540,6 +543,7 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
         run(B / 32, n_ftiles, false);
     } else
         run(0, n_ftiles, false);
+    if (marks) (void)hipEventRecord(marks[2], s);
 }
 
 // -------------------------------------------------------------------------------------

@@ -172,7 +172,8 @@ constexpr int kRecTileF16 = (3 * 2 + 1) * 256 + 32 * 16;
 constexpr int kRecFloatsPerFace = 96;       // workspace share per face for the records of either layout (+ kRecSlack in total)
 constexpr int kRecSlack = 4096;
 void launch_reconstruct_f16(const float *param, const float *mean62, const float *std62, const unsigned *basis3, int n_vert,
-                           int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3);
+                           int nvp, const float *roi, int transform, float *out, int pitch, int pad_writable, int B, hipStream_t s, float *rec3,
+                           hipEvent_t *marks = nullptr);
 
 // ---- mesh consumers (render_kernels.hip): Sim3DR.get_normal / RenderPipeline / Sim3DR.rasterize / cv2.addWeighted ----
 // vertices: F meshes, planar = 1 -> [F,3,nver] (the layout syn_reconstruct writes), 0 -> [F,nver,3] (the reference's)

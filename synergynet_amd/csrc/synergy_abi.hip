@@ -1823,6 +1823,27 @@ int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_
     return SYN_OK;
 }
 
+// Introspection (bench): the dense reconstruction into a pitched output with HIP events around its two kernels; synchronises.
+// ms[0] = the per-face prologue (recon_prep_f16_kernel), ms[1] = the contraction + pose epilogue + mesh stores (recon_f16_kernel
+// launches): the kernel whose roofline is HBM writes, B * 3 * n_vert * 4 bytes.
+int syn_reconstruct_profile(syn_handle *h, const float *param, int B, const float *roi, float *out, int row_pitch, int pad_writable, float *ms2) {
+    if (!h || !param || !out || !ms2) return fail(SYN_ERR_INVALID, "syn_reconstruct_profile: NULL argument");
+    if (B <= 0 || !h->d_basis || row_pitch < h->n_vert) return fail(SYN_ERR_INVALID, "syn_reconstruct_profile: bad argument");
+    if (h->fusion < 2) return fail(SYN_ERR_INVALID, "syn_reconstruct_profile: the fp16x2 schedule only");
+    DeviceGuard g(h->device);
+    int rc = ensure_rec(h, B);
+    if (rc) return rc;
+    hipEvent_t ev[3];
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    syn::launch_reconstruct_f16(param, basis_mean_cs(h), basis_std_cs(h), basis_f16_dense(h), h->n_vert, h->nvp, roi, 1, out, row_pitch, pad_writable, B,
+                                nullptr, h->rec, ev);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) { (void)hipEventElapsedTime(&ms2[0], ev[0], ev[1]); (void)hipEventElapsedTime(&ms2[1], ev[1], ev[2]); }
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    if (e != hipSuccess) return fail(SYN_ERR_HIP, "syn_reconstruct_profile: %s", hipGetErrorString(e));
+    return SYN_OK;
+}
+
 int syn_reconstruct(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
                     float *out, void *stream) {
     if (!h) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");
