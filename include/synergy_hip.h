@@ -77,6 +77,12 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats);
  * blocks that do NOT run the default kernel (0 = the whole network is inside the fp16 window), or a negative syn_status. */
 int syn_numerics_report(syn_handle *h, char *buf, size_t n);
 
+/* Which arithmetic the compute calls of this handle use from now on: 2 (default) fused kernels with fp16x2 operands, 1 fused kernels on
+ * the fp32-input MFMA (exact fp32 products: the cross-check and fallback schedule), 0 one fp32 kernel per layer.  Returns the previous
+ * value (>= 0) or a negative syn_status.  Lets a caller compare the default schedule with the exact one ON ITS OWN CHECKPOINT AND
+ * IMAGES without an oracle (SynergyNet.check_numerics).  Not to be changed while calls are in flight. */
+int syn_set_schedule(syn_handle *h, int fusion);
+
 /* ResNet-50 (ReLU, no static activation bound): the fp16 convolutions are guarded at RUN time.  Every tensor they split reports
  * max |x| into a per-forward status array; when one leaves [2^-10, 6e4] the head kernel returns NaN for that forward (loud, no host
  * synchronisation).  syn_backbone_range_status synchronises the device, copies the maxima of the last forward (slot 0 = max-pool

@@ -1277,6 +1277,15 @@ int syn_load_backbone(syn_handle *h, const float *flat, size_t n_floats) {
     return SYN_OK;
 }
 
+// include/synergy_hip.h: switch the handle between the default fp16x2 schedule (2) and the exact fp32-MFMA cross-check schedules (1, 0)
+int syn_set_schedule(syn_handle *h, int fusion) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_set_schedule: NULL handle");
+    if (fusion < 0 || fusion > 2) return fail(SYN_ERR_INVALID, "syn_set_schedule: schedule %d (0 per-layer fp32, 1 fused fp32-MFMA, 2 fused fp16x2)", fusion);
+    const int prev = h->fusion;
+    h->fusion = fusion;
+    return prev;
+}
+
 // Verdict of the load-time range analysis (see analyze_mbv2_ranges) as text + counts; include/synergy_hip.h.
 int syn_numerics_report(syn_handle *h, char *buf, size_t n) {
     if (!h) return fail(SYN_ERR_INVALID, "syn_numerics_report: NULL handle");

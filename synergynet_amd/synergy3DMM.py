@@ -256,6 +256,34 @@ class SynergyNet(nn.Module):
             abi.check(n)
         return n, mx[:54]
 
+    def check_numerics(self, crops_u8, rois=None):
+        """Self-check on the caller's OWN checkpoint and images, no oracle involved: the same crops through the default schedule (fp16x2
+        operands) and through the exact fp32-MFMA schedule of the same library (syn_set_schedule), parameters -> landmarks -> mesh.
+        Returns the largest per-face relative differences {'param', 'lmk', 'mesh'} (max |a - b| / max |b| per face); the default
+        schedule is fp32-class when they are ~1e-6.  Synchronises; not for use while other calls on this model are in flight."""
+        crops = crops_u8 if isinstance(crops_u8, torch.Tensor) else torch.as_tensor(np.asarray(crops_u8))
+        crops = crops.to(self.device)
+        out = {}
+
+        def run():
+            p = self.forward_crops_u8(crops)
+            return p, self.reconstruct(p, roi=rois, dense=False), self.reconstruct(p, roi=rois, dense=True)
+        torch.cuda.synchronize(self.device)
+        got = run()
+        torch.cuda.synchronize(self.device)
+        prev = self._lib.syn_set_schedule(self._h, 1)
+        if prev < 0:
+            abi.check(prev)
+        try:
+            want = run()
+            torch.cuda.synchronize(self.device)
+        finally:
+            self._lib.syn_set_schedule(self._h, prev)
+        for name, a, b in zip(('param', 'lmk', 'mesh'), got, want):
+            a, b = a.reshape(a.shape[0], -1).double(), b.reshape(b.shape[0], -1).double()
+            out[name] = float(((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).max())
+        return out
+
     def numerics_report(self):
         """(number of blocks that do not run the default fp16x2 kernel, text) -- the load-time range verdict on the loaded weights
         (include/synergy_hip.h syn_numerics_report): fp16 operands must stay inside 2^-14 .. 65504."""

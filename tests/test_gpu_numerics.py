@@ -128,6 +128,26 @@ def test_verdict_travels_with_exported_constants(pack, base_sd):
     assert torch.equal(a.forward_crops_u8(crops), b.forward_crops_u8(crops))
 
 
+def test_check_numerics_self_test_without_an_oracle(pack, base_sd):
+    """SynergyNet.check_numerics: default schedule vs the exact fp32-MFMA schedule of the same library on the caller's crops -- ~1e-6
+    on a checkpoint inside the fp16 window, and what the unguarded schedule does to one outside of it shows up without any oracle."""
+    import torch
+    import warnings
+    from synergynet_amd import synth
+    crops = torch.from_numpy(adv.extreme_crops(24)).cuda()
+    rois = torch.from_numpy(synth.make_rois(24, seed=2)).cuda()
+    m = make_model(pack, base_sd)
+    d = m.check_numerics(crops, rois)
+    assert max(d.values()) < 2e-5, d
+    assert torch.equal(m.forward_crops_u8(crops), m.forward_crops_u8(crops))          # the schedule switch was undone
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        bad = make_model(pack, adv.scale_stream(base_sd, '64', 2.0 ** 14), SYNERGY_HIP_RANGE_GUARD=0)
+        good = make_model(pack, adv.scale_stream(base_sd, '64', 2.0 ** 14))
+    assert bad.check_numerics(crops, rois)['param'] > 1e-3
+    assert max(good.check_numerics(crops, rois).values()) < 2e-5
+
+
 # ---- reconstruction: basis columns / coefficients many decades apart (ADVICE r2: one common scale lost the small columns) ----
 
 @pytest.mark.parametrize('B', [8, 100])
