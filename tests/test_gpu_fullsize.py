@@ -159,3 +159,39 @@ def test_pose_matrix_matches_reference_golden_and_oracle(model, basis, golden):
         model.predict_pose_batch(np.zeros((3, 61), np.float32))
     with pytest.raises(RuntimeError, match=r'roi must be \[B,5\]'):
         model.predict_pose_batch(np.zeros((3, 62), np.float32), np.zeros((3, 4), np.float32))
+
+
+def test_batch_beyond_every_baseline_size(model, basis, backbone_sd):
+    """B = 4100 faces in ONE call (4x the per-GPU shard of configs[3], not a multiple of anything): index arithmetic, persistent-loop
+    rounds and workspace growth beyond the sizes the kernels were tuned at.  A sample of faces from every region of the batch vs the
+    oracle (parameters, landmarks, pitched mesh), the mesh's landmark columns vs the landmark launch, and finiteness of everything."""
+    import torch
+    from oracle import recon_numpy
+    from synergynet_amd import synth
+    B = 4100
+    crops = synth.make_crops(B, seed=8100)
+    crops[1::2] = synth.make_crops(B // 2, seed=8101, smooth=True)
+    rois = synth.make_rois(B, seed=8102)
+    cd, rd = torch.from_numpy(crops).cuda(), torch.from_numpy(rois).cuda()
+    param = model.forward_crops_u8(cd)
+    lmk = model.reconstruct(param, roi=rd, dense=False)
+    mesh = model.reconstruct(param, roi=rd, dense=True)
+    ang, t3d = model.predict_pose_batch(param, rd)
+    torch.cuda.synchronize()
+    assert torch.isfinite(param).all() and torch.isfinite(lmk).all() and torch.isfinite(mesh).all() and torch.isfinite(ang).all()
+    pick = np.unique(np.r_[0:4, 1023:1027, 2047:2051, 3071:3075, 4093:4100])
+    want_p, _ = oracle_params(backbone_sd, crops[pick])
+    e = per_face_rel(param[torch.from_numpy(pick).cuda()].cpu().numpy(), want_p)
+    assert e.max() < TOL, f'parameters: face {pick[e.argmax()]} rel err {e.max():.3e}'
+    for i in pick:
+        got_p = param[i].cpu().numpy()
+        wl = recon_numpy.predict_vertices(basis, got_p, rois[i], dense=False, transform=True)
+        wm = recon_numpy.predict_vertices(basis, got_p, rois[i], dense=True, transform=True)
+        assert per_face_rel(lmk[i].cpu().numpy()[None], wl[None]).max() < 1e-5, i
+        assert per_face_rel(mesh[i].cpu().numpy()[None], wm[None]).max() < 1e-5, i
+    # every face: the landmarks are the keypoint columns of its mesh (the same contraction through two launches)
+    kp = torch.as_tensor(np.asarray(basis.keypoints[::3] // 3)).cuda()
+    d = (mesh[:, :, kp] - lmk).abs().amax() / lmk.abs().amax()
+    assert float(d) < 1e-5
+    # and the first 1024 faces equal a 1024-face call bit for bit (same kernels from B = 768 on; position independence)
+    assert torch.equal(model.forward_crops_u8(cd[:1024]), param[:1024])
