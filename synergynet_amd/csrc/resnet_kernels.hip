@@ -486,6 +486,208 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
 }
 
 // =====================================================================================
+// conv3 + BN + identity + ReLU of a bottleneck FUSED with the NEXT bottleneck's conv1 + BN + ReLU (resnet_backbone.py:122-134 of
+// block k, :116-118 of block k+1).  The convolutions of layer 1 are bound by memory throughput, not by the matrix pipe (counters in
+// 56 % of the wave cycles in s_waitcnt, deeper prefetch buys nothing): conv3 writes the 256-channel block output, the next
+// conv1 reads all of it back as its GEMM operand.  Here a workgroup owns 128 pixels and ALL output channels of conv3, in chunks of 64:
+//   * the conv2 output of its pixels (K = 64 channels) is split once into fp16 pieces and stays in registers (B operand of every chunk);
+//   * per chunk: 64 output channels of conv3 (weights through a double-buffered LDS chunk, as in conv_h2s_kernel), BN, + identity, ReLU,
+//     store -- and the chunk, still in registers, is split IN PLACE into the B operand of the next block's conv1: with K slot (g, e) of
+//     k32 step s := channel 64 c + 16 (2 s + (e >> 2)) + 4 g + (e & 3), the D layout of the conv3 MFMAs is the B layout of conv1's
+//     (the host packs conv1's weights in that K order, chunk-major: W1f[chunk][tile][step 2][piece 2][lane][4]); conv1 accumulates over
+//     the chunks in registers;
+//   * at the end BN + ReLU of conv1 and the store of the next block's 64 / 128-channel input.
+// The block output is read back only as the next block's identity: 1.18 GB instead of 1.65 GB per bottleneck of layer 1 at B = 512, and
+// one launch less.
+// =====================================================================================
+#ifndef SYN_C3F_L2_MT
+#define SYN_C3F_L2_MT 2
+#endif
+template <int KS3, int NT1, int MT, int TC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
+                     const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3]*/,
+                     float *__restrict__ out /*[M, N3]*/, const unsigned *__restrict__ W1f /*[N3/64][2][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
+                     const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1]*/, int M, int N3,
+                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1) {
+    // TC = output-channel tiles of conv3 per chunk (4: 64 channels = two k32 steps of conv1; 2: 32 channels = one -- half the LDS per chunk
+    // for the wider layers)
+    constexpr int K = 32 * KS3, N1 = 16 * NT1, CW = 16 * TC, S1 = TC / 2;
+    constexpr int W3C_DW = TC * KS3 * 2 * 256, W1C_DW = S1 * NT1 * 2 * 256;     // one chunk of conv3 / conv1 fragments
+    constexpr int NP3 = TC * KS3 * 2 / 4, NP1 = S1 * NT1 * 2 / 4;                // fragments per wave and chunk
+    static_assert(TC == 2 || TC == 4, "a chunk is one or two k32 steps of conv1");
+    static_assert((TC * KS3 * 2) % 4 == 0 && (S1 * NT1 * 2) % 4 == 0, "a quarter of a chunk per wave");
+    __shared__ __attribute__((aligned(16))) unsigned w3l[2 * W3C_DW];
+    __shared__ __attribute__((aligned(16))) unsigned w1l[2 * W1C_DW];
+    __shared__ __attribute__((aligned(16))) float sc3[512], sh3[512];
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int mt_idx = q * 8 + xcd;
+    if (mt_idx >= m_tiles) return;                               // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m0 = (mt_idx * 4 + wave) * (MT * 16);
+    const int chunks = N3 / CW;
+    const float inv_s3 = __builtin_bit_cast(float, W3[(size_t)(N3 / 16) * KS3 * 512 + 1]), inv_s1 = s1[1];
+    for (int i = threadIdx.x; i < N3; i += 256) { sc3[i] = scale3[i] * inv_s3; sh3[i] = shift3[i]; }
+
+    u32x4 pf3[NP3], pf1[NP1];
+    auto fetch_w3 = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < NP3; ++k) pf3[k] = *(const u32x4 *)(W3 + (size_t)c * W3C_DW + (wave + 4 * k) * 256 + lane * 4);
+    };
+    auto park_w3 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NP3; ++k) *(u32x4 *)&w3l[buf * W3C_DW + (wave + 4 * k) * 256 + lane * 4] = pf3[k];
+    };
+    auto fetch_w1 = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < NP1; ++k) pf1[k] = *(const u32x4 *)(W1f + (size_t)c * W1C_DW + (wave + 4 * k) * 256 + lane * 4);
+    };
+    auto park_w1 = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NP1; ++k) *(u32x4 *)&w1l[buf * W1C_DW + (wave + 4 * k) * 256 + lane * 4] = pf1[k];
+    };
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    fetch_w3(0);
+    fetch_w1(0);
+    // this wave's pixels (clamped: a wave past the end computes on the last pixel and stores nothing) and their conv2 output as pieces
+    int mp[MT];
+    u32x4 bp[MT][KS3][2];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + j * 16 + r16;
+        mp[j] = m < M ? m : M - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) {
+            const float *p = T2 + (size_t)mp[j] * K + ks * 32 + 8 * g;
+            split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), bp[j][ks]);
+        }
+    }
+    park_w3(0);
+    park_w1(0);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc1[MT][NT1];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT1; ++i) acc1[j][i] = z4;
+    float vmax3 = 0.f;
+
+    for (int c = 0; c < chunks; ++c) {
+        __syncthreads();                                         // chunk c of both weight sets is in LDS, chunk c-1 is read
+        // identity of this chunk: requested now, consumed after the conv3 MFMAs
+        f32x4 rsv[MT][TC];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < TC; ++i) rsv[j][i] = *(const f32x4 *)&identity[(size_t)mp[j] * N3 + CW * c + 16 * i + 4 * g];
+        if (c + 1 < chunks) fetch_w3(c + 1);
+        // ---- conv3: the CW output channels of this chunk ----
+        f32x4 acc3[MT][TC];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < TC; ++i) acc3[j][i] = z4;
+        const unsigned *w3c = w3l + (c & 1) * W3C_DW + lane * 4;
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks)
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                u32x4 wa[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wa[p] = *(const u32x4 *)(w3c + ((i * KS3 + ks) * 2 + p) * 256);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    acc3[j][i] = mm(wa[1], bp[j][ks][0], acc3[j][i]);
+                    acc3[j][i] = mm(wa[0], bp[j][ks][1], acc3[j][i]);
+                    acc3[j][i] = mm(wa[0], bp[j][ks][0], acc3[j][i]);
+                }
+            }
+        if (c + 1 < chunks) { park_w3((c + 1) & 1); fetch_w1(c + 1); }
+        // ---- BN, + identity, ReLU, store; the chunk stays in registers as conv1's operand ----
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const f32x4 scv = *(const f32x4 *)&sc3[CW * c + 16 * i + 4 * g], shv = *(const f32x4 *)&sh3[CW * c + 16 * i + 4 * g];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                f32x4 v = acc3[j][i] * scv + shv;
+                v += rsv[j][i];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+                acc3[j][i] = v;
+                asm volatile("" : "+v"(acc3[j][i]));
+                if (m0 + j * 16 + r16 < M) {
+                    *(f32x4 *)&out[(size_t)(m0 + j * 16 + r16) * N3 + CW * c + 16 * i + 4 * g] = v;
+                    vmax3 = fmaxf(vmax3, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                }
+            }
+        }
+        // ---- conv1 of the next block: K = this chunk's channels, in the D-register order (tiles 2 s, 2 s + 1 = one k32 step) ----
+        const unsigned *w1c = w1l + (c & 1) * W1C_DW + lane * 4;
+#pragma unroll
+        for (int sk = 0; sk < S1; ++sk) {
+            u32x4 op[MT][2];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) split8(acc3[j][2 * sk], acc3[j][2 * sk + 1], op[j]);
+#pragma unroll
+            for (int i = 0; i < NT1; ++i) {
+                u32x4 wa[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) wa[p] = *(const u32x4 *)(w1c + ((sk * NT1 + i) * 2 + p) * 256);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    acc1[j][i] = mm(wa[1], op[j][0], acc1[j][i]);
+                    acc1[j][i] = mm(wa[0], op[j][1], acc1[j][i]);
+                    acc1[j][i] = mm(wa[0], op[j][0], acc1[j][i]);
+                }
+            }
+        }
+        if (c + 1 < chunks) park_w1((c + 1) & 1);
+    }
+    if (stat3) range_note(stat3, vmax3);                 // (kernel-uniform conditions)
+    // ---- conv1: BN + ReLU, store the next block's input ----
+    float vmax1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT1; ++i) {
+        const f32x4 scv = *(const f32x4 *)&scale1[16 * i + 4 * g] * inv_s1, shv = *(const f32x4 *)&shift1[16 * i + 4 * g];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v = acc1[j][i] * scv + shv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+            if (m0 + j * 16 + r16 < M) {
+                *(f32x4 *)&T1n[(size_t)(m0 + j * 16 + r16) * N1 + 16 * i + 4 * g] = v;
+                vmax1 = fmaxf(vmax1, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            }
+        }
+    }
+    if (stat1) range_note(stat1, vmax1);
+}
+
+template <int KS3, int NT1, int MT, int TC>
+static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
+                         const unsigned *W1f, const float *s1, const float *scale1, const float *shift1, float *T1n, int M, int N3, hipStream_t s,
+                         float *stat3, float *stat1) {
+    const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
+    conv_c3f_kernel<KS3, NT1, MT, TC><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
+}
+
+bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
+                     const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
+                     hipStream_t s, float *stat3, float *stat1) {
+    if (N3 % 64 || N3 > 512) return false;
+#define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1)
+    if (K == 64 && N1 == 64) SYN_C3F(2, 4, 2, 4);              // layer 1
+    else if (K == 64 && N1 == 128) SYN_C3F(2, 8, 2, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)
+    else if (K == 128 && N1 == 128) SYN_C3F(4, 8, SYN_C3F_L2_MT, 2);       // layer 2
+    else return false;
+#undef SYN_C3F
+    return true;
+}
+
+// =====================================================================================
 // ResNet stem: 7x7 stride-2 pad-3 conv 3->64 + BN + ReLU (resnet_backbone.py:168-171), 120 -> 60, NHWC out.
 // Thread = (output pixel, 4 channels); the 147x64 filter (36.8 KB) sits in LDS.  ~1.4 % of the network's FLOPs.
 // U8 variant fuses the HWC->CHW permute and (x-127.5)/128 like the MobileNetV2 stem.

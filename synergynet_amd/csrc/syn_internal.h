@@ -139,6 +139,13 @@ constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10
 // layout of the status array: tensor t owns kRangeSub sub-slots, kRangeStride floats (256 B) apart: stat[(t * kRangeSub + sub) * kRangeStride];
 // launchers receive the tensor's base pointer
 constexpr int kRangeSub = 64, kRangeStride = 64;
+// conv3 + BN + identity + ReLU of a bottleneck fused with the next bottleneck's conv1 + BN + ReLU (resnet_kernels.hip conv_c3f_kernel).
+// W3: conv3's fp16 x2 fragments as launch_conv_f16x2 takes them; W1f: the next conv1's weights x its power of two S1, two fp16 pieces,
+// chunk-major in the D-register K order [Cin/64][step 2][N1/16][piece 2][lane 64][4 dwords]: lane (row l&15, kg = l>>4) slot e of step s =
+// input channel 64 c + 16 (2 s + (e >> 2)) + 4 kg + (e & 3).  false: this (K, N1) combination is not instantiated -- launch the two separately.
+bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
+                     const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
+                     hipStream_t s, float *stat3, float *stat1);
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 // 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,

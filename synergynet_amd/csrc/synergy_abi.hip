@@ -190,6 +190,7 @@ struct RConv {
     int cin, cout, k, stride, pad, hin, hout;
     size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: fp16 x2 split scaled by a power of two, MFMA lane order (dwords), then {S, 1/S}
     size_t dst_wrm = 0;                                   // stem only: fragments + folded shift of resnet_stem_mfma_kernel
+    size_t dst_w1f = 0;                                   // conv1 of a block that follows another block: its weights in the K order of conv_c3f_kernel (dwords), or 0
 };
 struct RBlock { int c1, c2, c3, ds; };
 struct ResNet50 {
@@ -223,6 +224,8 @@ struct ResNet50 {
                 inpl = outc; h = ho;
             }
         size_t src = 0, dst = 0;
+        std::vector<char> follows(convs.size(), 0);          // conv1 of every block but the first: fed by the previous block's conv3 (same resolution)
+        for (size_t bi = 1; bi < blocks.size(); ++bi) follows[blocks[bi].c1] = 1;
         for (auto &c : convs) {
             const size_t wn = (size_t)c.cout * c.cin * c.k * c.k;
             c.src_w = src; src += wn + 4 * (size_t)c.cout;
@@ -233,6 +236,7 @@ struct ResNet50 {
             c.dst_w3 = 0;
             if (c.cin % 32 == 0) { c.dst_w3 = dst; dst += (size_t)npad * c.cin * c.k * c.k + 4; }      // two fp16 per weight, then {S, 1/S}
             if (c.cin == 3) { c.dst_wrm = dst; dst += syn::rn_stem_dwords(); }
+            if (follows[&c - convs.data()] && c.cin <= 512) { c.dst_w1f = dst; dst += (size_t)c.cout * c.cin; }      // (fused launches exist up to 512 input channels)
             flops += 2.0 * c.cin * c.k * c.k * (double)c.cout * c.hout * c.hout;
             const size_t osz = (size_t)c.cout * c.hout * c.hout;
             buf_big = osz > buf_big ? osz : buf_big;
@@ -299,6 +303,7 @@ struct syn_handle {
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
     uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
+    int resnet_fuse = 1;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel)
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
     int range_guard = 1;           // SYNERGY_HIP_RANGE_GUARD=0: ignore the verdict (tests use it to show that the adversarial cases do break the unguarded schedule)
@@ -697,12 +702,30 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
           syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
         syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
     syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat);                                              // maxpool (:234)
-    for (const RBlock &b : n.blocks) {                     // Bottleneck.forward (:114-136)
-        conv(b.c1, X, nullptr, T1, 1);
+    // Bottleneck.forward (:114-136).  Where conv3 of a block and conv1 of the next can run as ONE launch (conv_c3f_kernel: layer 1, whose
+    // convolutions are bound by memory throughput), the block output is not read back as conv1's operand and T1 already holds the next
+    // block's conv1 output when its turn comes.
+    bool have_t1 = false;
+    auto unsafe_w = [&](int ci) { return h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u); };
+    for (size_t bi = 0; bi < n.blocks.size(); ++bi) {
+        const RBlock &b = n.blocks[bi];
+        if (!have_t1) conv(b.c1, X, nullptr, T1, 1);
         conv(b.c2, T1, nullptr, T2, 1);
         const float *identity = X;
         if (b.ds >= 0) { conv(b.ds, X, nullptr, D, 0); identity = D; }
-        conv(b.c3, T2, identity, Y, 1);                    // out = relu(bn3(conv3) + identity)
+        have_t1 = false;
+        if (f16 && h->resnet_fuse && bi + 1 < n.blocks.size()) {
+            const RConv &c3 = n.convs[b.c3], &c1n = n.convs[n.blocks[bi + 1].c1];
+            if (c3.dst_w3 && c1n.dst_w1f && c1n.hin == c3.hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[bi + 1].c1)) {
+                const float *s1 = P + c1n.dst_w3 + (size_t)(c1n.cout / 16) * (c1n.cin / 32) * 512;      // device {S, 1/S} of the next conv1's weights
+                have_t1 = syn::launch_conv_c3f(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, identity, Y,
+                                               reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
+                                               B * c3.hout * c3.hout, c3.cin, c3.cout, c1n.cout, s,
+                                               stat && resnet_stat_used(1 + b.c3) ? range_slot(stat, 1 + b.c3) : nullptr,
+                                               stat && resnet_stat_used(1 + n.blocks[bi + 1].c1) ? range_slot(stat, 1 + n.blocks[bi + 1].c1) : nullptr);
+            }
+        }
+        if (!have_t1) conv(b.c3, T2, identity, Y, 1);      // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;
     }
     // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
@@ -728,6 +751,7 @@ int syn_create(int device, syn_handle **out) {
     if (const char *e = getenv("SYNERGY_HIP_FUSION")) h->fusion = atoi(e);
     if (const char *e = getenv("SYNERGY_HIP_EARLY_RM")) h->early_rm = atoi(e);
     if (const char *e = getenv("SYNERGY_HIP_RANGE_GUARD")) h->range_guard = atoi(e);
+    if (const char *e = getenv("SYNERGY_HIP_RESNET_FUSE")) h->resnet_fuse = atoi(e);
     *out = h;
     return SYN_OK;
 }
@@ -1438,6 +1462,28 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                             dp[((((size_t)nt * steps + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
                             dp[((((size_t)nt * steps + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                         }
+        }
+        if (c.dst_w1f) {   // the same weights x S for conv_c3f_kernel: chunk-major, K slots in the D-register order of the producing conv3
+            unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_w1f);
+            const float S = (pk.data() + c.dst_w3 + (size_t)(c.cout / 16) * (c.cin / 32) * 512)[0];
+            const int nt1 = c.cout / 16;
+            for (int cc = 0; cc < c.cin / 64; ++cc)
+                for (int i1 = 0; i1 < nt1; ++i1)
+                    for (int sk = 0; sk < 2; ++sk)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int d = 0; d < 4; ++d) {
+                                const int nn = 16 * i1 + (lane & 15), kg = lane >> 4;
+                                float x[2];
+                                for (int e2 = 0; e2 < 2; ++e2) {
+                                    const int e = 2 * d + e2;
+                                    x[e2] = dw[(size_t)nn * c.cin + 64 * cc + 16 * (2 * sk + (e >> 2)) + 4 * kg + (e & 3)] * S;
+                                }
+                                const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
+                                const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
+                                const size_t frag = ((size_t)(cc * 2 + sk) * nt1 + i1) * 2;
+                                dp[((frag + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                                dp[((frag + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+                            }
         }
         for (int ch = 0; ch < c.cout; ++ch) {
             const float a = gamma[ch] * (1.0f / sqrtf(var[ch] + 1e-5f));

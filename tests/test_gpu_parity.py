@@ -531,6 +531,37 @@ def test_resnet50_matches_reference_golden_and_oracle(resnet_model):
     assert tuple(mesh.shape) == (33, 3, 53215) and torch.isfinite(mesh).all()
 
 
+@pytest.mark.parametrize('B', [7, 136, 512])
+def test_resnet50_fused_conv3_conv1_equals_separate_launches(pack, B):
+    """conv_c3f_kernel (conv3 + BN + identity + ReLU of a bottleneck and the next bottleneck's conv1 + BN + ReLU in one launch, layers 1
+    and 2) against the same network with the two convolutions launched separately (SYNERGY_HIP_RESNET_FUSE=0): equal to fp32 rounding
+    (conv1's K axis is walked in another order), both within the tolerance of the oracle; ragged pixel tiles (B = 7: 6300 pixels)."""
+    import torch
+    from oracle import resnet_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = synth.make_resnet50_state(2468)
+    crops = synth.make_crops(B, seed=640 + B)
+    cd = torch.from_numpy(crops).cuda()
+    fused = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    os.environ['SYNERGY_HIP_RESNET_FUSE'] = '0'
+    try:
+        plain = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    finally:
+        os.environ.pop('SYNERGY_HIP_RESNET_FUSE', None)
+    pf, poolf = fused.forward_crops_u8(cd, return_pool=True)
+    pp, poolp = plain.forward_crops_u8(cd, return_pool=True)
+    g, w = pf.cpu().numpy().astype(np.float64), pp.cpu().numpy().astype(np.float64)
+    per_face = np.abs(g - w).max(axis=1) / np.abs(w).max(axis=1)
+    assert per_face.max() < 1e-5, f'face {per_face.argmax()}: {per_face.max():.3e}'
+    assert rel_max(poolf.cpu().numpy(), poolp.cpu().numpy()) < 1e-5
+    pick = np.unique(np.r_[0, B // 2, B - 1])
+    want = resnet_torch.resnet50_forward(sd, synth.normalize_crops(crops[pick]))[0].numpy()[:, :62]
+    assert rel_max(pf[torch.from_numpy(pick).cuda()].cpu().numpy(), want) < TOL
+    assert torch.equal(fused.forward_crops_u8(cd), pf)                 # deterministic
+    assert fused.range_status()[0] == 0
+
+
 def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
     """syn_crop_resize (row f-1) vs oracle.preproc_numpy.crop_img + resize_lanczos4 on boxes that overhang every
     border of the frame, and get_all_outputs' landmarks vs the batched path on those host-made crops."""
