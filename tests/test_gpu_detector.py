@@ -125,6 +125,29 @@ def test_image_to_outputs_with_the_device_detector(det):
         assert np.array_equal(a, b)
 
 
+def test_batch_entry_point_with_the_device_detector(det):
+    """get_all_outputs_batch with no rects: the detector runs per frame, every face of every frame goes through ONE forward /
+    reconstruction / download; per frame the result equals the single-frame call (frames of different sizes) -- to fp32 rounding: the
+    seeded detector returns hundreds of boxes, so the batch call and the per-frame calls run different batch sizes and with them
+    different early-block kernels (<= 1e-5 relative)."""
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_backbone_state(), face_detector=det)
+    frames = [synth.make_frame(300, 420, seed=300), synth.make_frame(360, 500, seed=301), synth.make_frame(240, 320, seed=302)]
+    out = m.get_all_outputs_batch(frames)
+    assert len(out) == 3 and sum(len(o[0]) for o in out) > 0
+    for f, (lmk, mesh, pose) in zip(frames, out):
+        l1, m1, p1 = m.get_all_outputs(f)
+        assert len(lmk) == len(l1) == len(mesh) == len(pose)
+        close = lambda a, b: np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() <= 1e-5 * max(np.abs(np.asarray(b)).max(), 1.0)
+        for a, b in zip(lmk, l1):
+            assert close(a, b)
+        for a, b in zip(mesh, m1):
+            assert a.shape == (3, 640) and close(a, b)
+        for (a, ta), (b, tb) in zip(pose, p1):
+            assert np.abs(np.asarray(a) - np.asarray(b)).max() < 1e-3 and close(ta, tb)
+
+
 def test_more_candidates_than_the_sorter_holds(det):
     """A 720x1080 frame has ~17k priors; with a near-zero confidence threshold all of them are candidates, more than the 8192
     slots of the in-LDS sort network.  The reference sorts everything and keeps the top 5000 (FaceBoxes.py:114-116); the
