@@ -843,10 +843,16 @@ __device__ __forceinline__ f32x16s mfma_rs(u32x4s a, u32x4s b, f32x16s c) {
 }
 }  // namespace
 
-template <int U>
+// POOL: the 3x3 / 2 max-pool (resnet_backbone.py:172) in the epilogue -- out is then [B,30,30,64] and the 60x60x64 stem output (472 MB at
+// B = 512, written and read back by a kernel of its own before) never exists.  The two column blocks of a row become lanes j <-> column
+// 30 c + j - 1 (30 columns + one neighbour each side, overlapping by two columns instead of exchanging them), so the horizontal 3-max is
+// two whole-wave lane shifts; vertically a running max over the rows 2 py - 1, 2 py, 2 py + 1; post-ReLU values are >= 0, so the
+// out-of-image neighbours of the pool (its -inf padding) may be zeros.  stat: range-guard slot of the pooled tensor.
+template <int U, bool POOL = false>
 __global__ __launch_bounds__((2 * U + 1) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][10][2][64][4]*/,
-                             const float *__restrict__ s_shift /*[64] folded*/, float *__restrict__ out /*[B,60,60,64]*/, int B) {
+                             const float *__restrict__ s_shift /*[64] folded*/, float *__restrict__ out /*[B,60,60,64]*/, int B,
+                             float *__restrict__ stat = nullptr) {
     constexpr int UNIT_DW = (kRsSlots + 1) * kRsRowEl / 2, NT = (2 * U + 1) * 64;
     __shared__ __attribute__((aligned(16))) unsigned smem[U * UNIT_DW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -908,8 +914,16 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
     for (int q = 0; q < 4; ++q) sh4[q] = *(const f32x4 *)&s_shift[32 * G + 8 * q + 4 * h] * Ss;
     const char *ring = reinterpret_cast<const char *>(smem + uw * UNIT_DW);
 
+    float vmaxp = 0.f;
     for (int fb = blockIdx.x * U; fb < B; fb += gridDim.x * U) {
         const int f = fb + uw;
+        f32x16s prevhm[2], runmax[2];                          // POOL: horizontal maxima of the previous odd row / running maximum of the open pooled row, per column block
+        if (POOL) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { prevhm[c][r] = 0.f; runmax[c][r] = 0.f; }
+        }
         __syncthreads();                                       // (P)
         for (int oy = 0; oy < 60; ++oy) {
             // byte offsets of the seven image rows 2oy-3 .. 2oy+3 inside the ring (the padding row for rows outside the image)
@@ -922,8 +936,9 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
             rowoff[7] = rowoff[6];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int col = 32 * c + j;
-                const int lanebase = (6 * (col < 60 ? col : 59) + 2) * 2;             // first byte of this lane's 22-element runs
+                const int col = POOL ? 30 * c + j - 1 : 32 * c + j;
+                const bool col_ok = (unsigned)col < 60u;
+                const int lanebase = (6 * (col < 0 ? 0 : (col < 60 ? col : 59)) + 2) * 2;             // first byte of this lane's 22-element runs
                 f32x16s e;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -943,23 +958,58 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
                     e = mfma_rs(as[s][1], xb, e);
                     e = mfma_rs(as[s][0], xb, e);
                 }
-                if (col < 60 && f < B) {
-                    float *dst = out + ((size_t)(f * 60 + oy) * 60 + col) * 64 + 32 * G + 4 * h;
+                if constexpr (!POOL) {
+                    if (col_ok && f < B) {
+                        float *dst = out + ((size_t)(f * 60 + oy) * 60 + col) * 64 + 32 * G + 4 * h;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(f32x4 *)(dst + 8 * q) = (f32x4){fmaxf(e[4 * q], 0.f), fmaxf(e[4 * q + 1], 0.f), fmaxf(e[4 * q + 2], 0.f), fmaxf(e[4 * q + 3], 0.f)} * inv_ss;
+                        for (int q = 0; q < 4; ++q)
+                            *(f32x4 *)(dst + 8 * q) = (f32x4){fmaxf(e[4 * q], 0.f), fmaxf(e[4 * q + 1], 0.f), fmaxf(e[4 * q + 2], 0.f), fmaxf(e[4 * q + 3], 0.f)} * inv_ss;
+                    }
+                } else {
+                    // ReLU (x 1 / Ss), zero outside the image, horizontal 3-max through whole-wave lane shifts (lanes 0 / 31 of a half are the
+                    // overlap columns: what the shifts bring them from the other half is never used)
+                    const float keep = col_ok ? inv_ss : 0.f;
+                    f32x16s hm;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = fmaxf(e[r], 0.f) * keep;
+                        const float l = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+                        const float rt = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+                        hm[r] = fmaxf(fmaxf(l, v), rt);
+                    }
+                    if (!(oy & 1)) {                           // even stem row 2 py: with the odd row above it
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) runmax[c][r] = fmaxf(prevhm[c][r], hm[r]);
+                    } else {                                   // odd stem row 2 py + 1 closes pooled row py
+                        const int py = oy >> 1, px = col >> 1;
+                        const bool st = (j & 1) && j <= 29 && f < B;       // even stem columns 30 c + j - 1, j = 1, 3, .. 29
+                        float *dst = out + ((size_t)(f * 30 + py) * 30 + px) * 64 + 32 * G + 4 * h;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = {fmaxf(runmax[c][4 * q], hm[4 * q]), fmaxf(runmax[c][4 * q + 1], hm[4 * q + 1]),
+                                             fmaxf(runmax[c][4 * q + 2], hm[4 * q + 2]), fmaxf(runmax[c][4 * q + 3], hm[4 * q + 3])};
+                            if (st) {
+                                *(f32x4 *)(dst + 8 * q) = v;
+                                vmaxp = fmaxf(vmaxp, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) prevhm[c][r] = hm[r];
+                    }
                 }
             }
             __syncthreads();
         }
     }
+    if (POOL && stat) range_note(stat, vmaxp);
 }
 
-bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s) {
+bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s, int pool, float *stat) {
     if (!img8 || !As3) return false;
     constexpr int U = 2;
     const int wgs = (B + U - 1) / U;
-    resnet_stem_mfma_kernel<U><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B);
+    if (pool) resnet_stem_mfma_kernel<U, true><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B, stat);
+    else resnet_stem_mfma_kernel<U><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B);
     return true;
 }
 

@@ -152,7 +152,9 @@ void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const 
 // hh) K slot kk = 16s + 8hh + e: kernel row ky = kk / 22, m = kk % 22 (m = 0: don't-care byte, else kx = (m-1)/3, ci = (m-1)%3), kk >= 154
 // zero; weights / 128 x S (power of two) as two fp16 pieces; s_shift [64] = BN shift - 255/256 * sum of the scaled filter, then {S, 1/S}
 constexpr int rn_stem_dwords() { return 2 * 10 * 2 * 256 + 64 + 4; }
-bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s);
+// pool != 0: the 3x3 / 2 max-pool in the epilogue, out = [B,30,30,64] (stat: range-guard slot of the pooled tensor, nullable)
+bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s, int pool = 0,
+                             float *stat = nullptr);
 void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat = nullptr);
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
                             int C, int n_out, int out_stride, hipStream_t s, const float *stat = nullptr, int n_stat = 0);

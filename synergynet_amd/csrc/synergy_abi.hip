@@ -698,10 +698,15 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     };
     const RConv &st = n.convs[0];
     // conv1+bn1+relu (:231-233): uint8 crops on the bf16 matrix pipe (batches that give every CU a workgroup), else the direct kernel
-    if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
-          syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
-        syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
-    syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat);                                              // maxpool (:234)
+    // (the max-pool, :234, rides in the matrix-pipe stem's epilogue: the 60x60x64 tensor never exists)
+    if (h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) && h->resnet_fuse &&
+        syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, X, B, s, 1, stat)) {
+    } else {
+        if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
+              syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
+            syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
+        syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat);                                          // maxpool (:234)
+    }
     // Bottleneck.forward (:114-136).  Where conv3 of a block and conv1 of the next can run as ONE launch (conv_c3f_kernel: layer 1, whose
     // convolutions are bound by memory throughput), the block output is not read back as conv1's operand and T1 already holds the next
     // block's conv1 output when its turn comes.
