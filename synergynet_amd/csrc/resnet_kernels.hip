@@ -503,13 +503,22 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
 #ifndef SYN_C3F_L2_MT
 #define SYN_C3F_L2_MT 2
 #endif
-template <int KS3, int NT1, int MT, int TC>
+// DS (layer1.0: 64 -> 256, stride 1): the block's downsample branch (1x1 conv + BN, resnet_backbone.py:127-128) is evaluated IN the kernel
+// instead of being read as `identity`: the block input of the workgroup's pixels (64 channels) stays in registers as a second B operand, the
+// downsample weights of a chunk come straight from L2 (natural K order, one tile ahead), and the 256-channel branch -- 472 MB written by a
+// launch of its own and read back here at B = 512 -- never exists.
+struct DsArgs {
+    const float *X;             // block input [M, 64]
+    const unsigned *Wd;         // downsample conv's fp16 x2 fragments [N3/16][2][2][64][4], {S, 1/S}
+    const float *scale_d, *shift_d;
+};
+template <int KS3, int NT1, int MT, int TC, bool DS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
                      const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3]*/,
                      float *__restrict__ out /*[M, N3]*/, const unsigned *__restrict__ W1f /*[N3/64][2][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
                      const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1]*/, int M, int N3,
-                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1) {
+                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, DsArgs ds = DsArgs{}) {
     // TC = output-channel tiles of conv3 per chunk (4: 64 channels = two k32 steps of conv1; 2: 32 channels = one -- half the LDS per chunk
     // for the wider layers)
     constexpr int K = 32 * KS3, N1 = 16 * NT1, CW = 16 * TC, S1 = TC / 2;
@@ -565,6 +574,19 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
             split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), bp[j][ks]);
         }
     }
+    // DS: the block input of the same pixels as pieces (K = 64: two k32 steps) and the branch's scale
+    u32x4 xd[DS ? MT : 1][2][2];
+    float inv_sd = 0.f;
+    if constexpr (DS) {
+        inv_sd = __builtin_bit_cast(float, ds.Wd[(size_t)(N3 / 16) * 2 * 512 + 1]);
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float *p = ds.X + (size_t)mp[j] * 64 + ks * 32 + 8 * g;
+                split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), xd[j][ks]);
+            }
+    }
     park_w3(0);
     park_w1(0);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -579,11 +601,40 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
         __syncthreads();                                         // chunk c of both weight sets is in LDS, chunk c-1 is read
         // identity of this chunk: requested now, consumed after the conv3 MFMAs
         f32x4 rsv[MT][TC];
+        if constexpr (!DS) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
+            for (int j = 0; j < MT; ++j)
 #pragma unroll
-            for (int i = 0; i < TC; ++i) rsv[j][i] = *(const f32x4 *)&identity[(size_t)mp[j] * N3 + CW * c + 16 * i + 4 * g];
+                for (int i = 0; i < TC; ++i) rsv[j][i] = *(const f32x4 *)&identity[(size_t)mp[j] * N3 + CW * c + 16 * i + 4 * g];
+        }
         if (c + 1 < chunks) fetch_w3(c + 1);
+        if constexpr (DS) {
+            // the downsample branch of this chunk: rsv = BN_d(Wd . x); fragments of tile i + 1 are requested while tile i is on the matrix pipe
+            u32x4 wd[2][2][2];
+            auto fetch_d = [&](int i, u32x4 (&w)[2][2]) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) w[ks][p] = *(const u32x4 *)(ds.Wd + ((size_t)((TC * c + i) * 2 + ks) * 2 + p) * 256 + lane * 4);
+            };
+            fetch_d(0, wd[0]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                if (i + 1 < TC) fetch_d(i + 1, wd[(i + 1) & 1]);
+                const f32x4 scd = *(const f32x4 *)&ds.scale_d[CW * c + 16 * i + 4 * g] * inv_sd, shd = *(const f32x4 *)&ds.shift_d[CW * c + 16 * i + 4 * g];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    f32x4 a = z4;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a = mm(wd[i & 1][ks][1], xd[j][ks][0], a);
+                        a = mm(wd[i & 1][ks][0], xd[j][ks][1], a);
+                        a = mm(wd[i & 1][ks][0], xd[j][ks][0], a);
+                    }
+                    rsv[j][i] = a * scd + shd;
+                }
+            }
+        }
         // ---- conv3: the CW output channels of this chunk ----
         f32x4 acc3[MT][TC];
 #pragma unroll
@@ -672,6 +723,17 @@ static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale
                          float *stat3, float *stat1) {
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
     conv_c3f_kernel<KS3, NT1, MT, TC><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
+}
+
+// ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0
+bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
+                        const float *scale_d, const float *shift_d, float *out, const unsigned *W1f, const float *s1, const float *scale1,
+                        const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1) {
+    if (K != 64 || Kd != 64 || N3 != 256 || N1 != 64) return false;
+    const DsArgs ds{X, Wd, scale_d, shift_d};
+    const int m_tiles = (M + 127) / 128, grid = ((m_tiles + 7) / 8) * 8;
+    conv_c3f_kernel<2, 4, 2, 2, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);      // (32-channel chunks: with 64 the second B operand spills)
+    return true;
 }
 
 bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,

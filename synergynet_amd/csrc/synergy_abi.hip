@@ -716,20 +716,33 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         const RBlock &b = n.blocks[bi];
         if (!have_t1) conv(b.c1, X, nullptr, T1, 1);
         conv(b.c2, T1, nullptr, T2, 1);
-        const float *identity = X;
-        if (b.ds >= 0) { conv(b.ds, X, nullptr, D, 0); identity = D; }
         have_t1 = false;
+        const float *identity = X;
+        bool ds_done = b.ds < 0;
         if (f16 && h->resnet_fuse && bi + 1 < n.blocks.size()) {
             const RConv &c3 = n.convs[b.c3], &c1n = n.convs[n.blocks[bi + 1].c1];
             if (c3.dst_w3 && c1n.dst_w1f && c1n.hin == c3.hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[bi + 1].c1)) {
                 const float *s1 = P + c1n.dst_w3 + (size_t)(c1n.cout / 16) * (c1n.cin / 32) * 512;      // device {S, 1/S} of the next conv1's weights
-                have_t1 = syn::launch_conv_c3f(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, identity, Y,
-                                               reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
-                                               B * c3.hout * c3.hout, c3.cin, c3.cout, c1n.cout, s,
-                                               stat && resnet_stat_used(1 + b.c3) ? range_slot(stat, 1 + b.c3) : nullptr,
-                                               stat && resnet_stat_used(1 + n.blocks[bi + 1].c1) ? range_slot(stat, 1 + n.blocks[bi + 1].c1) : nullptr);
+                float *st3 = stat && resnet_stat_used(1 + b.c3) ? range_slot(stat, 1 + b.c3) : nullptr;
+                float *st1 = stat && resnet_stat_used(1 + n.blocks[bi + 1].c1) ? range_slot(stat, 1 + n.blocks[bi + 1].c1) : nullptr;
+                const int M = B * c3.hout * c3.hout;
+                // a stride-1 downsample branch on 64 channels (layer1.0) is evaluated inside the fused kernel: no launch, no 256-channel tensor
+                if (b.ds >= 0 && n.convs[b.ds].stride == 1 && n.convs[b.ds].dst_w3 && !unsafe_w(b.ds)) {
+                    const RConv &cd = n.convs[b.ds];
+                    have_t1 = ds_done = syn::launch_conv_c3f_ds(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, X,
+                                                                reinterpret_cast<const unsigned *>(P + cd.dst_w3), P + cd.dst_scale, P + cd.dst_shift, Y,
+                                                                reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
+                                                                M, c3.cin, cd.cin, c3.cout, c1n.cout, s, st3, st1);
+                }
+                if (!have_t1) {
+                    if (!ds_done) { conv(b.ds, X, nullptr, D, 0); identity = D; ds_done = true; }
+                    have_t1 = syn::launch_conv_c3f(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, identity, Y,
+                                                   reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
+                                                   M, c3.cin, c3.cout, c1n.cout, s, st3, st1);
+                }
             }
         }
+        if (!ds_done) { conv(b.ds, X, nullptr, D, 0); identity = D; }
         if (!have_t1) conv(b.c3, T2, identity, Y, 1);      // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;
     }
