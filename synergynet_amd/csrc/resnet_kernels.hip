@@ -477,7 +477,9 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
     if (N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
-        if (tiles >= 1024) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        // 32-pixel wave tiles from 2048 workgroup tiles on: at 1024 (layer 3's conv1 / conv2: 256 x 4) they are 1.33 rounds of the 768 workgroups
+        // the chip holds, the 16-pixel configuration's 2048 are 2.67 (B = 512: 6.96 -> 6.85 ms; from 4097 on instead: 7.06)
+        if (tiles >= 2048) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         return;
     }
