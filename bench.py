@@ -555,62 +555,66 @@ def main():
             ms_ = time_steps(fn, steps, warmup, sync) * 1e3
             return dict(faces_s=round(Bx / ms_ * 1e3, 1), ms_per_step=round(ms_, 4), faces_per_step=Bx, steps=steps)
 
-        # configs[1]: B = 128, 68 landmarks (+ pose) only
-        c128, r128 = crops[:128].contiguous(), rois[:128].contiguous()
-        l128 = torch.empty((128, 3, 68), dtype=torch.float32, device=dev)
-        p128 = OverlappedPipeline(model, overlap=True, rec_priority=args.rec_priority)
-        extra['b128_lmk_only'] = dict(rate(128, lambda: p128.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10),
-                                      what='BASELINE configs[1]: uint8 crops -> MobileNetV2 -> 68 landmarks + pose, no mesh')
-        p1 = OverlappedPipeline(model, overlap=False)
-        extra['b128_lmk_only_one_stream'] = rate(128, lambda: p1.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10)
-        extra['b1_lmk_only_latency_ms'] = round(time_steps(lambda: p1.submit(crops[:1], rois[:1], dense=False), 200, 20, sync) * 1e3, 4)
-        # the headline step through the reference's own entry points: fp32 NCHW crops into forward_test, packed [B,3,53215] output
-        xf = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=1000))).to(dev)
-        packed = torch.empty((B, 3, model._n_vert), dtype=torch.float32, device=dev)
+        try:                                                    # an extra must never cost the headline line
+            # configs[1]: B = 128, 68 landmarks (+ pose) only
+            c128, r128 = crops[:128].contiguous(), rois[:128].contiguous()
+            l128 = torch.empty((128, 3, 68), dtype=torch.float32, device=dev)
+            p128 = OverlappedPipeline(model, overlap=True, rec_priority=args.rec_priority)
+            extra['b128_lmk_only'] = dict(rate(128, lambda: p128.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10),
+                                          what='BASELINE configs[1]: uint8 crops -> MobileNetV2 -> 68 landmarks + pose, no mesh')
+            p1 = OverlappedPipeline(model, overlap=False)
+            extra['b128_lmk_only_one_stream'] = rate(128, lambda: p1.submit(c128, r128, lmk_out=l128, dense=False), steps=100, warmup=10)
+            extra['b1_lmk_only_latency_ms'] = round(time_steps(lambda: p1.submit(crops[:1], rois[:1], dense=False), 200, 20, sync) * 1e3, 4)
+            # the headline step through the reference's own entry points: fp32 NCHW crops into forward_test, packed [B,3,53215] output
+            xf = torch.from_numpy(synth.normalize_crops(synth.make_crops(B, seed=1000))).to(dev)
+            packed = torch.empty((B, 3, model._n_vert), dtype=torch.float32, device=dev)
 
-        def ref_api_step():
-            p = model.forward_test(xf)
-            model.reconstruct(p, roi=rois, dense=False, out=lmk)
-            model.reconstruct(p, roi=rois, dense=True, out=packed)
-            model.predict_pose_batch(p, rois)
-        extra['fp32_ingest_packed_output_one_stream'] = dict(rate(B, ref_api_step, steps=10, warmup=2),
-                                                             what='forward_test(fp32 [B,3,120,120]) + reconstruct into the packed [B,3,53215] layout '
-                                                                  '(synergy3DMM.py:131-147), one stream: the step exactly as the reference API shapes it')
-        pk = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
-        extra['packed_output'] = rate(B, lambda: pk.submit(crops, rois, lmk_out=lmk, mesh_out=packed), steps=10, warmup=2)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            def ref_api_step():
+                p = model.forward_test(xf)
+                model.reconstruct(p, roi=rois, dense=False, out=lmk)
+                model.reconstruct(p, roi=rois, dense=True, out=packed)
+                model.predict_pose_batch(p, rois)
+            extra['fp32_ingest_packed_output_one_stream'] = dict(rate(B, ref_api_step, steps=10, warmup=2),
+                                                                 what='forward_test(fp32 [B,3,120,120]) + reconstruct into the packed [B,3,53215] layout '
+                                                                      '(synergy3DMM.py:131-147), one stream: the step exactly as the reference API shapes it')
+            pk = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
+            extra['packed_output'] = rate(B, lambda: pk.submit(crops, rois, lmk_out=lmk, mesh_out=packed), steps=10, warmup=2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def ev_ms(fn, reps=10):
-            fn(); sync(); e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record(); sync()
-            return e0.elapsed_time(e1) / reps
-        pp = model.forward_crops_u8(crops)
-        mesh_bytes = B * 3 * model._n_vert * 4
-        t_pitch = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=mesh))
-        t_pack = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=packed))
-        # the kernel itself (HIP events inside the library, no prologue, no launch bubbles): the HBM-write-bound kernel of the path
-        ms2 = (ctypes.c_float * 2)()
-        kms = []
-        for _ in range(5):
-            abi.check(lib.syn_reconstruct_profile(model._h, pp.data_ptr(), B, rois.data_ptr(), mesh.data_ptr(), mesh.stride(1), 1, ms2))
-            kms.append((ms2[0], ms2[1]))
-        k_prep, k_main = float(np.median([k[0] for k in kms])), float(np.median([k[1] for k in kms]))
-        extra['reconstruction_alone'] = dict(pitched_ms=round(t_pitch, 4), pitched_tb_s=round(mesh_bytes / t_pitch / 1e9, 3),
-                                             packed_ms=round(t_pack, 4), packed_tb_s=round(mesh_bytes / t_pack / 1e9, 3),
-                                             mesh_bytes=mesh_bytes, peak_tb_s=PEAK_HBM_GBS / 1e3,
-                                             what='pitched_ms / packed_ms: one reconstruct() call = prologue kernel + contraction kernel + the launch '
-                                                  'bubbles between dependent kernels, back to back; kernel: the contraction kernel alone (HIP events in the library)',
-                                             kernel=dict(bound='hbm', name='syn::recon_f16_kernel', ms=round(k_main, 4), prologue_ms=round(k_prep, 4),
-                                                         achieved=round(mesh_bytes / k_main / 1e6, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                                         frac=round(mesh_bytes / k_main / 1e6 / PEAK_HBM_GBS, 4)))
-        extra['fp32_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_test(xf), 5), 4)
-        extra['u8_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_crops_u8(crops), 5), 4)
-        del xf, packed
-        if args.overlap:
-            one = OverlappedPipeline(model, overlap=False)
-            extra['one_stream'] = rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=10, warmup=2)
+            def ev_ms(fn, reps=10):
+                fn(); sync(); e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record(); sync()
+                return e0.elapsed_time(e1) / reps
+            pp = model.forward_crops_u8(crops)
+            mesh_bytes = B * 3 * model._n_vert * 4
+            t_pitch = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=mesh))
+            t_pack = ev_ms(lambda: model.reconstruct(pp, roi=rois, dense=True, out=packed))
+            # the kernel itself (HIP events inside the library, no prologue, no launch bubbles): the HBM-write-bound kernel of the path
+            ms2 = (ctypes.c_float * 2)()
+            kms = []
+            for _ in range(5):
+                abi.check(lib.syn_reconstruct_profile(model._h, pp.data_ptr(), B, rois.data_ptr(), mesh.data_ptr(), mesh.stride(1), 1, ms2))
+                kms.append((ms2[0], ms2[1]))
+            k_prep, k_main = float(np.median([k[0] for k in kms])), float(np.median([k[1] for k in kms]))
+            extra['reconstruction_alone'] = dict(pitched_ms=round(t_pitch, 4), pitched_tb_s=round(mesh_bytes / t_pitch / 1e9, 3),
+                                                 packed_ms=round(t_pack, 4), packed_tb_s=round(mesh_bytes / t_pack / 1e9, 3),
+                                                 mesh_bytes=mesh_bytes, peak_tb_s=PEAK_HBM_GBS / 1e3,
+                                                 what='pitched_ms / packed_ms: one reconstruct() call = prologue kernel + contraction kernel + the launch '
+                                                      'bubbles between dependent kernels, back to back; kernel: the contraction kernel alone (HIP events in the library)',
+                                                 kernel=dict(bound='hbm', name='syn::recon_f16_kernel', ms=round(k_main, 4), prologue_ms=round(k_prep, 4),
+                                                             achieved=round(mesh_bytes / k_main / 1e6, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                                             frac=round(mesh_bytes / k_main / 1e6 / PEAK_HBM_GBS, 4)))
+            extra['fp32_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_test(xf), 5), 4)
+            extra['u8_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_crops_u8(crops), 5), 4)
+            del xf, packed
+            if args.overlap:
+                one = OverlappedPipeline(model, overlap=False)
+                extra['one_stream'] = rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=10, warmup=2)
+        except Exception as e:
+            extra['error'] = 'extras stopped at: ' + str(e)[:300]
+            torch.cuda.synchronize()
         # the documented entry point (reference synergy3DMM.py:167-207): frames + detections in, numpy landmarks / meshes / poses out,
         # through get_all_outputs (1 frame) and get_all_outputs_batch (16 frames); detections are given (the detector is timed in
         # tools/bench_detector.py), the frame upload, crop + resize, forward, reconstruction and the DOWNLOAD of every mesh are inside
@@ -672,7 +676,10 @@ def main():
         except Exception as e:                                  # an extra must never cost the headline line
             extra['resnet50_b512'] = dict(error=str(e)[:200])
         # sustained clocks: the same headline step for ~2 s
-        extra['sustained_2s'] = rate(B, step, steps=max(args.steps, int(2.0 / max(el / args.steps, 1e-4))), warmup=0)
+        try:
+            extra['sustained_2s'] = rate(B, step, steps=max(args.steps, int(2.0 / max(el / args.steps, 1e-4))), warmup=0)
+        except Exception as e:
+            extra['sustained_2s'] = dict(error=str(e)[:200])
 
     if rank == 0:
         faces = B * world * args.steps
