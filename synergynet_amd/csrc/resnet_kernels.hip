@@ -3,6 +3,7 @@
 // and one implicit-GEMM convolution kernel (any kh x kw / stride / pad, NHWC fp32) on v_mfma_f32_16x16x4_f32
 // with a fused BN (+ residual) + ReLU epilogue that serves every 1x1 and 3x3 convolution of the bottlenecks.
 #include <cstdlib>
+#include <type_traits>
 
 #include "syn_internal.h"
 
@@ -168,6 +169,21 @@ __device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
         pc[0][d] = a;
         pc[1][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    }
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// four values -> their high and low fp16 pieces (two packed dwords each), the same arithmetic as split8
+__device__ __forceinline__ void split4(const f32x4 &x, u32x2 &hi, u32x2 &lo) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float x0 = x[2 * d], x1 = x[2 * d + 1];
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+        hi[d] = a;
+        lo[d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     }
 }
 
@@ -459,6 +475,230 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
                                                      act, n_tiles, m_tiles, stat);
 }
 
+// =====================================================================================
+// The deep layers (3 / 4: 55 % of the forward) on a workgroup tile of 64 MTW pixels x 128 output channels, BOTH operands through LDS.
+// conv_h2s_kernel's tile is 64 (MT = 1) or 128 pixels x 64 channels: per k32 step a CU moves 128 B x (pixels + channels) through its
+// vector cache (64 B/cycle) for 12 (pixels / 16)(channels / 16) matrix-pipe cycles -- 256 against 192 cycles for 64 x 64, more bytes than the
+// cache delivers in the time the MFMAs take, and every fp32 activation is split by the one wave that owns its pixel while three of
+// four SIMDs wait for theirs.  Here eight waves (4 along pixels x 2 along channels, 16 MTW pixels x 64 channels of accumulators each)
+// share a step's operands: each wave fetches 1/8 of the step's activations (fp32, implicit-GEMM addressing as above) and 1/8 of its
+// weight fragments into registers one step AHEAD, splits the activations once and parks both as ready-made MFMA fragments in the
+// other half of a double buffer ([pixel tile][piece][lane][4] / [channel tile][piece][lane][4]: every ds_write / ds_read is a lane's
+// own 16 bytes, conflict-free); one barrier per step.  Per step and CU (MTW = 4): 48 KB through the vector cache = 768 cycles against
+// 1536 matrix-pipe cycles per SIMD; an activation is split once per 128 output channels instead of once per 64.
+// Same K order, same three products per step, same epilogue expression as conv_h2s_kernel: BIT-IDENTICAL results
+// (tests/test_gpu_parity.py), so the two are interchangeable per convolution.  Requires Cin % 32 == 0, N % 128 == 0.
+// =====================================================================================
+#ifndef LT_ABL
+#define LT_ABL 0
+#endif
+#ifndef LT_D
+#define LT_D 4
+#endif
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+template <int MTW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3, const float *__restrict__ scale,
+                    const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ out, int M, int Hin,
+                    int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, int n_tiles, int m_tiles,
+                    float *__restrict__ stat, unsigned in_bytes) {
+    constexpr int PT = 4 * MTW;                                  // 16-pixel tiles of the workgroup
+    constexpr int U = MTW / 2;                                   // ... staged per wave
+    static_assert(MTW == 2 || MTW == 4, "128 | 256 pixels per workgroup");
+    constexpr int BF_DW = PT * 512, AF_DW = 8 * 512, ST_DW = BF_DW + AF_DW;      // one step: activation | weight fragments
+    __shared__ __attribute__((aligned(16))) unsigned sm[2 * ST_DW];
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt_idx = q % n_tiles;
+    const int mt_idx = (q / n_tiles) * 8 + xcd;                  // the channel tiles of one pixel tile share an XCD's L2
+    if (mt_idx >= m_tiles) return;                               // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt_idx * (PT * 16);
+    const int n0 = nt_idx * 128;
+    const int KCH = Cin >> 5, steps = KH * KW * KCH;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // staging: a wave instruction fetches 8 pixels x 128 B (lane = pixel l >> 3, 16-byte chunk l & 7: two whole lines per 16 lanes; the
+    // fragment order -- lane = (pixel, 8 channels) -- would touch 16 lines per 16 lanes and cost the vector cache four times the
+    // tag lookups: measured 92 -> ... us for layer 3's conv1).  A lane stages pixels (l >> 3) and 8 + (l >> 3) of the tiles wave U + u.
+    const int sp = lane >> 3, sc = lane & 7;
+    // Buffer loads: a 32-bit byte offset per lane = pixel base + a scalar per (tap, k32 step); a tap outside the image takes an offset
+    // past the end of the tensor, which the buffer hardware answers with zeros = the zero padding -- no select behind the load, so
+    // nothing consumes a loaded register before the step that parks it (a v_cndmask there made the compiler wait for every load
+    // right after issuing it).  in_bytes < 2^31 (launcher).
+    int py[U][2], px[U][2];
+    unsigned pbase[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + (wave * U + u) * 16 + 8 * h + sp;
+            m = m < M ? m : M - 1;                               // (rows past the end: clamped loads, no stores)
+            const int hw = Hout * Hout;
+            const int pbi = m / hw;
+            const int r = m - pbi * hw;
+            py[u][h] = (r / Hout) * stride - pad;
+            px[u][h] = (r % Hout) * stride - pad;
+            pbase[u][h] = (unsigned)(((pbi * Hin + py[u][h]) * Hin + px[u][h]) * Cin + 4 * sc) * 4u;     // (wraps for padding rows: only used when the tap is inside)
+        }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(W3), 0, 0x7fffffff, 0x00027000);
+    // LDS slot (16 bytes) of fragment lane (pixel r, k-group gg): gg 16 + ((r + 4 gg) & 15) -- the rotation keeps both the 8-byte
+    // writes of a staging instruction (4 pixels x 8 chunks per 32 lanes) and the 16-byte reads of a fragment (16 pixels of one k-group
+    // per 16 lanes) on distinct banks
+    auto slot = [](int r, int gg) { return gg * 16 + ((r + 4 * gg) & 15); };
+    int woff[2];                                                  // dword offset of this lane's 8 bytes inside a fragment, pixel halves 0 / 1
+#pragma unroll
+    for (int h = 0; h < 2; ++h) woff[h] = slot(8 * h + sp, sc >> 1) * 4 + (sc & 1) * 2;
+    const int roff = slot(r16, g) * 4;                            // ... of this lane's 16 bytes as a reader
+    const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
+    f32x4 acc[MTW][4];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = z4;
+
+    // Operands travel D steps ahead of their use in a register ring (slot = step % D): a step's loads are issued D barriers before the
+    // step that parks them -- first-touch activations come from HBM (~2 us under load), one step of MFMAs is ~0.7 us.
+    constexpr int D = LT_D;
+    f32x4 sa[D][U][2];
+    u32x4 sw[D][2];
+    const unsigned wbase = (unsigned)((n0 / 16 + wave) * steps) * 2048u;        // this wave's channel tile: both pieces of a step (bytes)
+    const unsigned l16 = lane * 16;
+    auto fetch = [&](int s, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        const int tap = s / KCH, kc = s - tap * KCH;
+        const int ky = tap / KW, kx = tap - ky * KW;
+        const unsigned dlt = (unsigned)((ky * Hin + kx) * Cin + kc * 32) * 4u;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int iy = py[u][h] + ky, ix = px[u][h] + kx;
+                const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+                if (LT_ABL & 1) { sa[SL][u][h] = (f32x4){1.f, 2.f, 3.f, (float)s}; continue; }
+                sa[SL][u][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? pbase[u][h] + dlt : 0x80000000u, 0, 0));
+            }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { if (LT_ABL & 2) { sw[SL][p] = (u32x4){1u, 2u, 3u, (unsigned)s}; continue; } sw[SL][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, l16, wbase + s * 2048 + p * 1024, 0); }
+    };
+    auto park = [&](int buf, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        unsigned *b = sm + buf * ST_DW;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x2 hi, lo;
+                split4(sa[SL][u][h], hi, lo);
+                unsigned *t = b + (wave * U + u) * 512 + woff[h];
+                *(u32x2 *)t = hi;
+                *(u32x2 *)(t + 256) = lo;
+            }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *(u32x4 *)&b[BF_DW + (wave * 2 + p) * 256 + lane * 4] = sw[SL][p];
+    };
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    auto body = [&](int s, auto slot_c) {                        // slot_c = slot of step s + 1
+        // step s is in LDS; the other half (step s - 1) has been read.  Raw barrier: __syncthreads() would drain the loads in flight.
+        // No branches in here (the last steps park / fetch clamped leftovers nobody reads): the compiler's vmcnt bookkeeping
+        // falls back to vmcnt(0) at every join
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        park((s + 1) & 1, slot_c);
+        const int sf = s + 1 + D;
+        fetch(sf < steps ? sf : steps - 1, slot_c);
+        const unsigned *b = sm + (s & 1) * ST_DW;
+        u32x4 wa[4][2], bp[MTW][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wa[i][p] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + p) * 256 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bp[j][p] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + p) * 256 + roff);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
+#pragma unroll
+            for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { if (LT_ABL & 4) { acc[j][i] += __builtin_bit_cast(f32x4, wa[i][pa[t]] ^ bp[j][pbk[t]]); continue; } acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]); }
+        }
+    };
+    // prologue: steps 0 .. D - 1 into their slots, step 0 parked, step D into the freed slot 0   (steps % D == 0, steps >= D: launcher)
+    static_for<D>([&](auto d) { fetch(decltype(d)::value, d); });
+    park(0, std::integral_constant<int, 0>{});
+    fetch(D < steps ? D : steps - 1, std::integral_constant<int, 0>{});
+    for (int s0 = 0; s0 < steps; s0 += D)
+        static_for<D>([&](auto d) {
+            constexpr int dd = decltype(d)::value;
+            body(s0 + dd, std::integral_constant<int, (dd + 1) % D>{});
+        });
+    const int mw = m0 + wm * (MTW * 16), nw = n0 + wn * 64;
+    if (mw >= M) return;
+    // epilogue as conv_h2s_kernel: loads first (branch-free), then arithmetic, then stores
+    f32x4 scv[4], shv[4], rsv[MTW][4];
+    float vmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = nw + i * 16 + 4 * g;
+        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
+        shv[i] = *(const f32x4 *)&shift[n];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            int m = mw + j * 16 + r16;
+            m = m < M ? m : 0;
+            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            f32x4 v = acc[j][i] * scv[i] + shv[i];
+            if (residual) v += rsv[j][i];
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+            }
+            acc[j][i] = v;
+            asm volatile("" : "+v"(acc[j][i]));
+            if (stat && mw + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = nw + i * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int m = mw + j * 16 + r16;
+            if (m >= M) continue;
+            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
+        }
+    }
+}
+
+template <int MTW>
+static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
+                             float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
+                             hipStream_t s, float *stat) {
+    const int n_tiles = N / 128;
+    const int m_tiles = (M + 64 * MTW - 1) / (64 * MTW);
+    const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
+    conv_lt_kernel<MTW><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act,
+                                             n_tiles, m_tiles, stat, in_bytes);
+}
+
 template <int MT, int NT>
 static void launch_conv_f16x2_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
@@ -472,9 +712,17 @@ static void launch_conv_f16x2_t(const float *in, const unsigned *W3, const float
 
 void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s, float *stat) {
+                     hipStream_t s, float *stat, int lt) {
+    const int lt_min_m = lt == 2 ? 1 : 4096;                      // (2 = cross-check mode: 128-pixel tiles on every shape that fits, ragged ones too)
     const int M = B * Hout * Hout;
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
+    if (lt && N % 128 == 0 && M >= lt_min_m && (KH * KW * (Cin / 32)) % 4 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31) &&
+        (size_t)N * KH * KW * Cin * 4 < (1ull << 31)) {
+        // 256-pixel tiles when they still give every CU a workgroup
+        if (lt != 2 && (long)((M + 255) / 256) * (N / 128) >= 256) launch_conv_lt_t<4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        else launch_conv_lt_t<2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        return;
+    }
     if (N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
         // 32-pixel wave tiles from 2048 workgroup tiles on: at 1024 (layer 3's conv1 / conv2: 256 x 4) they are 1.33 rounds of the 768 workgroups

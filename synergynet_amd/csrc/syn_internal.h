@@ -132,7 +132,7 @@ void launch_conv(const float *in, const float *W, const float *scale, const floa
 // stat (nullable): one float of the per-forward range-guard array -- max |output| is folded into it (resnet_kernels.hip range_note)
 void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s, float *stat = nullptr);
+                     hipStream_t s, float *stat = nullptr, int lt = 0 /* 1: the LDS-tiled kernel where its shape fits (N % 128 == 0, M >= 4096); 2: ... 128-pixel tiles only */);
 // window of a tensor's max |x| inside which the fp16 x2 split of an UNSCALED activation keeps >= 15 bits relative to that maximum:
 // above kRangeHi v_cvt_pkrtz_f16_f32 saturates, below kRangeLo even the largest element's low piece is a 4-bit subnormal
 constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10

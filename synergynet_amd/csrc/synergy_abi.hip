@@ -303,6 +303,7 @@ struct syn_handle {
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
     uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
+    int resnet_gemm = 1;           // SYNERGY_HIP_RESNET_GEMM=0: every convolution on conv_h2s_kernel (cross-check of conv_lt_kernel; 2: its 128-pixel tiles only)
     int resnet_fuse = 1;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel)
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
@@ -690,7 +691,7 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         if (f16 && c.dst_w3 && !(h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u))) {
             syn::launch_conv_f16x2(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
                                  c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s,
-                                 stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr);
+                                 stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr, h->resnet_gemm);
             return;
         }
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
@@ -770,6 +771,7 @@ int syn_create(int device, syn_handle **out) {
     if (const char *e = getenv("SYNERGY_HIP_EARLY_RM")) h->early_rm = atoi(e);
     if (const char *e = getenv("SYNERGY_HIP_RANGE_GUARD")) h->range_guard = atoi(e);
     if (const char *e = getenv("SYNERGY_HIP_RESNET_FUSE")) h->resnet_fuse = atoi(e);
+    if (const char *e = getenv("SYNERGY_HIP_RESNET_GEMM")) h->resnet_gemm = atoi(e);
     *out = h;
     return SYN_OK;
 }

@@ -562,6 +562,30 @@ def test_resnet50_fused_conv3_conv1_equals_separate_launches(pack, B):
     assert fused.range_status()[0] == 0
 
 
+@pytest.mark.parametrize('B', [9, 136, 512])
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_resnet50_lds_tiled_gemm_is_bit_identical_to_the_wave_tiled_one(pack, B, mode):
+    """conv_lt_kernel (256 / 128 pixels x 128 channels per workgroup, both operands as fragments through LDS; mode 2: its 128-pixel
+    tiles everywhere) against conv_h2s_kernel (SYNERGY_HIP_RESNET_GEMM=0): same K order, same products, same epilogue -> the
+    same bits, on ragged pixel tiles too (B = 9: 576 / 144 pixels in layers 3 / 4 with the threshold lowered)."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = synth.make_resnet50_state(1357)
+    cd = torch.from_numpy(synth.make_crops(B, seed=77 + B)).cuda()
+    os.environ['SYNERGY_HIP_RESNET_GEMM'] = mode
+    try:
+        tiled = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+        os.environ['SYNERGY_HIP_RESNET_GEMM'] = '0'
+        plain = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    finally:
+        os.environ.pop('SYNERGY_HIP_RESNET_GEMM', None)
+    pt, poolt = tiled.forward_crops_u8(cd, return_pool=True)
+    pp, poolp = plain.forward_crops_u8(cd, return_pool=True)
+    assert torch.equal(pt, pp) and torch.equal(poolt, poolp)
+    assert tiled.range_status()[0] == 0
+
+
 def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
     """syn_crop_resize (row f-1) vs oracle.preproc_numpy.crop_img + resize_lanczos4 on boxes that overhang every
     border of the frame, and get_all_outputs' landmarks vs the batched path on those host-made crops."""
