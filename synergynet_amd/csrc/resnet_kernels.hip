@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
+                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat, unsigned in_bytes) {
     constexpr int CH_DW = NT * KS * 2 * 256;                     // one chunk of fragments: [tile NT][step KS][piece 2][64][4]
     constexpr int NPW = NT * KS * 2 / 4;                         // fragments per wave and chunk
     static_assert(NT * KS * 2 % 4 == 0, "a quarter of a chunk per wave");
@@ -339,17 +339,23 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
     const int n0 = nt_idx * (NT * 16);
     const int KCH = Cin >> 5, steps = KH * KW * KCH, chunks = steps / KS;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    int pb[MT], py[MT], px[MT];
+    // activations through buffer loads (byte offset = pixel base + a scalar per step; a tap outside the image gets an offset past the
+    // end of the tensor and reads zeros = the padding): no select behind a load -- with one, the compiler waits for every load right
+    // after issuing it and the whole memory latency stands in every step (conv_lt_kernel below)
+    int py[MT], px[MT];
+    unsigned pbase[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         int m = m0 + j * 16 + r16;
         m = m < M ? m : M - 1;                                   // (a wave past the end computes on clamped rows and stores nothing)
         const int hw = Hout * Hout;
-        pb[j] = m / hw;
-        const int r = m - pb[j] * hw;
+        const int pbi = m / hw;
+        const int r = m - pbi * hw;
         py[j] = (r / Hout) * stride - pad;
         px[j] = (r % Hout) * stride - pad;
+        pbase[j] = (unsigned)(((pbi * Hin + py[j]) * Hin + px[j]) * Cin + 8 * g) * 4u;      // (wraps for padding rows: only used when the tap is inside)
     }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
     const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -370,34 +376,44 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
 #pragma unroll
         for (int k = 0; k < NPW; ++k) *(u32x4 *)&wl[buf * CH_DW + (wave + 4 * k) * 256 + lane * 4] = wf[k];
     };
-    auto fetch_a = [&](int s, f32x4(&a0)[MT], f32x4(&a1)[MT]) {
-        const int tap = s / KCH, kc = s - tap * KCH;
-        const int ky = tap / KW, kx = tap - ky * KW;
+    int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0;                   // the fetch pointer walks the steps in order (no division per step); it stops at the last one
+    auto fetch_a = [&](f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+        const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * Cin + f_kc * 32) * 4u;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const int iy = py[j] + ky, ix = px[j] + kx;
+            const int iy = py[j] + f_ky, ix = px[j] + f_kx;
             const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
-            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 32 + 8 * g;
-            const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
-            a0[j] = ok ? v0 : z4;
-            a1[j] = ok ? v1 : z4;
+            const unsigned off = ok ? pbase[j] + dlt : 0x80000000u;
+            a0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            a1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 16, 0));
         }
+        const int adv = f_s + 1 < steps ? 1 : 0;
+        f_s += adv;
+        f_kc += adv;
+        const int c1 = f_kc == KCH ? 1 : 0;
+        f_kc = c1 ? 0 : f_kc;
+        f_kx += c1;
+        const int c2 = f_kx == KW ? 1 : 0;
+        f_kx = c2 ? 0 : f_kx;
+        f_ky += c2;
     };
     auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
     f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
     fetch_w(0);
-    fetch_a(0, c0, c1);
+    fetch_a(c0, c1);
     park_w(0);
     for (int c = 0; c < chunks; ++c) {
-        __syncthreads();                                         // chunk c is in LDS, chunk c-1 is read
-        if (c + 1 < chunks) fetch_w(c + 1);
+        // chunk c is in LDS, chunk c - 1 is read.  A raw barrier (__syncthreads() drains the activation loads in flight across it), and
+        // no branches in the loop (past the end the last chunk is fetched / parked again, unread): the compiler's vmcnt bookkeeping
+        // gives up at joins
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fetch_w(c + 1 < chunks ? c + 1 : c);
         const unsigned *wc = wl + (c & 1) * CH_DW + lane * 4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int s = c * KS + ks;
-            if (s + 1 < steps) fetch_a(s + 1, n0v, n1v);
+            fetch_a(n0v, n1v);                                   // step s + 1 (past the end: the last step again, unused)
             u32x4 bp[MT][2];
 #pragma unroll
             for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
 #pragma unroll
             for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
         }
-        if (c + 1 < chunks) park_w((c + 1) & 1);
+        park_w((c + 1) & 1);
     }
     if (m0 >= M) return;
     // epilogue as conv_f16x2_kernel: loads first (branch-free), then arithmetic, then stores
@@ -471,8 +487,9 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
     conv_h2s_kernel<MT, NT, KS><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                                     act, n_tiles, m_tiles, stat);
+                                                     act, n_tiles, m_tiles, stat, in_bytes);
 }
 
 // =====================================================================================
@@ -489,12 +506,10 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
 // Same K order, same three products per step, same epilogue expression as conv_h2s_kernel: BIT-IDENTICAL results
 // (tests/test_gpu_parity.py), so the two are interchangeable per convolution.  Requires Cin % 32 == 0, N % 128 == 0.
 // =====================================================================================
-#ifndef LT_ABL
-#define LT_ABL 0
+#ifndef LT_PROF
+#define LT_PROF 0                      // 1: s_memtime sums per phase of waves 0 / 5 of one workgroup, printed per launch (tools/lt_prof.sh)
 #endif
-#ifndef LT_D
-#define LT_D 4
-#endif
+#define LT_LAP(i) do { if (LT_PROF) { __builtin_amdgcn_sched_barrier(0); tn = __builtin_amdgcn_s_memtime(); pt_[i] += tn - tk; tk = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
@@ -503,7 +518,7 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 template <int MTW>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MTW == 2 ? 4 : 2, MTW == 2 ? 4 : 2)))
 void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ out, int M, int Hin,
                     int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, int n_tiles, int m_tiles,
@@ -566,27 +581,41 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
 
     // Operands travel D steps ahead of their use in a register ring (slot = step % D): a step's loads are issued D barriers before the
     // step that parks them -- first-touch activations come from HBM (~2 us under load), one step of MFMAs is ~0.7 us.
-    constexpr int D = LT_D;
+    constexpr int D = 2;                                         // (4: the same time -- what mattered was that nothing waits for a load right behind it; PMC / variants in DESIGN 7)
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = LT_PROF ? __builtin_amdgcn_s_memtime() : 0, tn;
     f32x4 sa[D][U][2];
     u32x4 sw[D][2];
     const unsigned wbase = (unsigned)((n0 / 16 + wave) * steps) * 2048u;        // this wave's channel tile: both pieces of a step (bytes)
     const unsigned l16 = lane * 16;
-    auto fetch = [&](int s, auto slot_c) {
+    // the fetch pointer walks the steps in order: (tap row, tap column, k32 chunk) as running scalars (a division per fetch cost ~400
+    // cycles of a 3600-cycle step); past the last step it stays there (the last D fetches re-read it into slots nobody parks)
+    int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0, w_s = 0;
+    auto fetch = [&](auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
-        const int tap = s / KCH, kc = s - tap * KCH;
-        const int ky = tap / KW, kx = tap - ky * KW;
-        const unsigned dlt = (unsigned)((ky * Hin + kx) * Cin + kc * 32) * 4u;
+        const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * Cin + f_kc * 32) * 4u;
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int iy = py[u][h] + ky, ix = px[u][h] + kx;
+                const int iy = py[u][h] + f_ky, ix = px[u][h] + f_kx;
                 const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
-                if (LT_ABL & 1) { sa[SL][u][h] = (f32x4){1.f, 2.f, 3.f, (float)s}; continue; }
                 sa[SL][u][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? pbase[u][h] + dlt : 0x80000000u, 0, 0));
             }
+        const int adv = f_s + 1 < steps ? 1 : 0;
+        f_s += adv;
+        f_kc += adv;
+        const int c1 = f_kc == KCH ? 1 : 0;
+        f_kc = c1 ? 0 : f_kc;
+        f_kx += c1;
+        const int c2 = f_kx == KW ? 1 : 0;
+        f_kx = c2 ? 0 : f_kx;
+        f_ky += c2;
+    };
+    auto fetch_w = [&](auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { if (LT_ABL & 2) { sw[SL][p] = (u32x4){1u, 2u, 3u, (unsigned)s}; continue; } sw[SL][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, l16, wbase + s * 2048 + p * 1024, 0); }
+        for (int p = 0; p < 2; ++p) sw[SL][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, l16, wbase + w_s * 2048 + p * 1024, 0);
+        w_s += w_s + 1 < steps ? 1 : 0;
     };
     auto park = [&](int buf, auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
@@ -607,42 +636,63 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
-    auto body = [&](int s, auto slot_c) {                        // slot_c = slot of step s + 1
-        // step s is in LDS; the other half (step s - 1) has been read.  Raw barrier: __syncthreads() would drain the loads in flight.
-        // No branches in here (the last steps park / fetch clamped leftovers nobody reads): the compiler's vmcnt bookkeeping
-        // falls back to vmcnt(0) at every join
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        park((s + 1) & 1, slot_c);
-        const int sf = s + 1 + D;
-        fetch(sf < steps ? sf : steps - 1, slot_c);
+    u32x4 wa[4][2], bp[MTW][2];
+    auto read_frags = [&](int s) {
         const unsigned *b = sm + (s & 1) * ST_DW;
-        u32x4 wa[4][2], bp[MTW][2];
+        // fragments in the order the products need them: (weights low, activations high) first
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) wa[i][1] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + 1) * 256 + lane * 4);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wa[i][p] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + p) * 256 + lane * 4);
+        for (int j = 0; j < MTW; ++j) bp[j][0] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 0) * 256 + roff);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j)
+        for (int i = 0; i < 4; ++i) wa[i][0] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + 0) * 256 + lane * 4);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) bp[j][p] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + p) * 256 + roff);
+        for (int j = 0; j < MTW; ++j) bp[j][1] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 1) * 256 + roff);
+    };
+    auto products = [&]() {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
 #pragma unroll
             for (int j = 0; j < MTW; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { if (LT_ABL & 4) { acc[j][i] += __builtin_bit_cast(f32x4, wa[i][pa[t]] ^ bp[j][pbk[t]]); continue; } acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]); }
+                for (int i = 0; i < 4; ++i) acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]);
         }
     };
-    // prologue: steps 0 .. D - 1 into their slots, step 0 parked, step D into the freed slot 0   (steps % D == 0, steps >= D: launcher)
-    static_for<D>([&](auto d) { fetch(decltype(d)::value, d); });
+    // Raw barriers: __syncthreads() would drain the loads in flight.  No branches inside a step (the last steps park / fetch clamped
+    // leftovers nobody reads): the compiler's vmcnt bookkeeping falls back to vmcnt(0) at every join.
+#define LT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // load segment of step s: this wave's fragments of step s into registers, its share of step s + 1 into the other LDS half, the loads
+    // of step s + 1 + D;  slot_c = ring slot of step s + 1
+    auto load_seg = [&](int s, auto slot_c) {
+        read_frags(s);
+        if (LT_PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LT_LAP(4);
+        park((s + 1) & 1, slot_c);
+        LT_LAP(2);
+        fetch(slot_c);
+        fetch_w(slot_c);
+        LT_LAP(3);
+    };
+    // prologue: steps 0 .. D - 1 into their slots, step 0 parked, step D into the freed slot 0   (steps % D == 0: launcher)
+    static_for<D>([&](auto d) { fetch(d); });
+    static_for<D>([&](auto d) { fetch_w(d); });
     park(0, std::integral_constant<int, 0>{});
-    fetch(D < steps ? D : steps - 1, std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 0>{});
+    fetch_w(std::integral_constant<int, 0>{});
     for (int s0 = 0; s0 < steps; s0 += D)
         static_for<D>([&](auto d) {
             constexpr int dd = decltype(d)::value;
-            body(s0 + dd, std::integral_constant<int, (dd + 1) % D>{});
+            LT_LAP(0);
+            LT_BARRIER();                                        // step s is in LDS; the other half (step s - 1) has been read
+            LT_LAP(1);
+            load_seg(s0 + dd, std::integral_constant<int, (dd + 1) % D>{});
+            products();
         });
+    LT_LAP(0);
+    if (LT_PROF && blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 5) && steps >= 16)
+        printf("lt<%d> M %d N %d steps %d wave %d: mfma %llu barrier %llu park %llu fetch %llu dsread %llu  (cycles/step x100MHz ticks)\n", MTW, M, N, steps, wave,
+               pt_[0] / steps, pt_[1] / steps, pt_[2] / steps, pt_[3] / steps, pt_[4] / steps);
     const int mw = m0 + wm * (MTW * 16), nw = n0 + wn * 64;
     if (mw >= M) return;
     // epilogue as conv_h2s_kernel: loads first (branch-free), then arithmetic, then stores
@@ -716,14 +766,17 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
     const int lt_min_m = lt == 2 ? 1 : 4096;                      // (2 = cross-check mode: 128-pixel tiles on every shape that fits, ragged ones too)
     const int M = B * Hout * Hout;
     const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
-    if (lt && N % 128 == 0 && M >= lt_min_m && (KH * KW * (Cin / 32)) % 4 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31) &&
+    const int steps = KH * KW * (Cin / 32);
+    if (lt && N % 128 == 0 && M >= lt_min_m && steps % 2 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31) &&
         (size_t)N * KH * KW * Cin * 4 < (1ull << 31)) {
-        // 256-pixel tiles when they still give every CU a workgroup
-        if (lt != 2 && (long)((M + 255) / 256) * (N / 128) >= 256) launch_conv_lt_t<4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        // 256-pixel tiles (one 8-wave workgroup per CU) for long K when they still give every CU a workgroup; 128-pixel tiles (two workgroups
+        // per CU: one's prologue / epilogue beside the other's steps) for K <= 512 -- conv3 and the downsample branches, whose time is their
+        // epilogue (layer 3 conv3: 111 -> 96 us; conv1 / conv2 the other way: 56 -> 60, 106 -> 110)
+        if (lt != 2 && steps > 16 && (long)((M + 255) / 256) * (N / 128) >= 256) launch_conv_lt_t<4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         else launch_conv_lt_t<2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
         return;
     }
-    if (N % 64 == 0 && (KH * KW * (Cin / 32)) % 2 == 0) {
+    if (N % 64 == 0 && steps % 2 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31)) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
         // 32-pixel wave tiles from 2048 workgroup tiles on: at 1024 (layer 3's conv1 / conv2: 256 x 4) they are 1.33 rounds of the 768 workgroups
         // the chip holds, the 16-pixel configuration's 2048 are 2.67 (B = 512: 6.96 -> 6.85 ms; from 4097 on instead: 7.06)

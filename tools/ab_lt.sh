@@ -2,7 +2,12 @@
 # per-launch durations of one ResNet-50 forward (B = 512) for the default library and each variant library given (tags): A/B of conv_lt_kernel
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/ab_lt.txt; : > $out
 for tag in "" "$@"; do
-  if [ -n "$tag" ]; then export SYNERGY_HIP_LIB=$R/synergynet_amd/libsynergy_hip_$tag.so; else unset SYNERGY_HIP_LIB; fi
+  unset SYNERGY_HIP_LIB SYNERGY_HIP_RESNET_GEMM
+  case "$tag" in
+    "") ;;
+    env:*) export "${tag#env:}" ;;
+    *) export SYNERGY_HIP_LIB=$R/synergynet_amd/libsynergy_hip_$tag.so ;;
+  esac
   bash $R/tools/resnet_layers.sh > /dev/null 2>&1
   echo "== ${tag:-default}" >> $out
   python - >> $out <<PY
@@ -11,6 +16,7 @@ rows=[l.split() for l in open('$R/gpurun_out/resnet_layers.txt')]
 us=[float(r[-2]) for r in rows]
 names=[r[0] for r in rows]
 print('total %.0f us; conv_lt sum %.0f' % (sum(us), sum(u for n,u in zip(names,us) if 'conv_lt' in n)))
+print(' '.join('%.0f' % u for u in us))
 print('L3 block (conv1 conv2 conv3):', us[21:24], ' L4 block:', us[40:43], ' L2 conv2:', us[11], ' L3.0 c1,c2,ds,c3:', us[16:20])
 PY
 done
