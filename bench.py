@@ -483,7 +483,7 @@ def main():
         torch.cuda.synchronize()
         bb_ms = e0.elapsed_time(e1) / 5
         ach = fl / (bb_ms * 1e-3) / 1e12
-        roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (syn::conv_h2s_kernel implicit-GEMM launches, syn::conv_c3f_kernel = conv3 + next conv1 in layers 1 / 2, stem, max-pool, heads); '
+        roof = dict(bound='mfma', kernel='ResNet-50 backbone forward (syn::conv_lt_kernel LDS-tiled implicit GEMM in layers 2-4, syn::conv_h2s_kernel for the 64-channel convolutions, syn::conv_c3f_kernel = conv3 + next conv1 in layers 1 / 2, stem with the max-pool in its epilogue, heads); '
                                          'fp32-accurate results on v_mfma_f32_16x16x32_f16 with every operand as two fp16 pieces (3 MFMAs per '
                                          'block product); peak = dense fp16 MFMA peak 2500 TFLOP/s / 3',
                     achieved=round(ach, 3), peak=round(PEAK_F16X2_TFLOPS, 1), unit='TFLOP/s', frac=round(ach / PEAK_F16X2_TFLOPS, 4), traffic=None,

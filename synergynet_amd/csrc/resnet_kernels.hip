@@ -499,12 +499,18 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
 // cache delivers in the time the MFMAs take, and every fp32 activation is split by the one wave that owns its pixel while three of
 // four SIMDs wait for theirs.  Here eight waves (4 along pixels x 2 along channels, 16 MTW pixels x 64 channels of accumulators each)
 // share a step's operands: each wave fetches 1/8 of the step's activations (fp32, implicit-GEMM addressing as above) and 1/8 of its
-// weight fragments into registers one step AHEAD, splits the activations once and parks both as ready-made MFMA fragments in the
-// other half of a double buffer ([pixel tile][piece][lane][4] / [channel tile][piece][lane][4]: every ds_write / ds_read is a lane's
-// own 16 bytes, conflict-free); one barrier per step.  Per step and CU (MTW = 4): 48 KB through the vector cache = 768 cycles against
+// weight fragments into registers steps AHEAD, splits the activations once and parks both as ready-made MFMA fragments in the
+// other half of a double buffer ([pixel tile][piece][slot 64][4] / [channel tile][piece][lane][4]: a fragment read is a lane's own
+// 16 bytes); one barrier per step.  Per step and CU (MTW = 4): 48 KB through the vector cache = 768 cycles against
 // 1536 matrix-pipe cycles per SIMD; an activation is split once per 128 output channels instead of once per 64.
+// What made it fast (91 -> 55 us for layer 3's conv1; the tile alone: 91 vs conv_h2s_kernel's 92) is that NOTHING consumes a loaded
+// register before the step that parks it: buffer loads whose out-of-range offsets return the padding zeros (a select behind the load
+// made the compiler wait for it at once), a branch-free loop body (its vmcnt bookkeeping gives up at joins), a raw barrier, loads two
+// steps ahead in a register ring.  DESIGN 7 has the ablations, the phase profile (tools/lt_prof.sh, -DLT_PROF=1) and what did not
+// help (ping-pong wave halves, pinned MFMA / VALU interleave, a deeper ring).
 // Same K order, same three products per step, same epilogue expression as conv_h2s_kernel: BIT-IDENTICAL results
-// (tests/test_gpu_parity.py), so the two are interchangeable per convolution.  Requires Cin % 32 == 0, N % 128 == 0.
+// (tests/test_gpu_parity.py), so the two are interchangeable per convolution.  Requires Cin % 64 == 0 (an even number of k32 steps),
+// N % 128 == 0, tensors below 2 GiB (32-bit buffer offsets).
 // =====================================================================================
 #ifndef LT_PROF
 #define LT_PROF 0                      // 1: s_memtime sums per phase of waves 0 / 5 of one workgroup, printed per launch (tools/lt_prof.sh)
@@ -541,7 +547,7 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     // staging: a wave instruction fetches 8 pixels x 128 B (lane = pixel l >> 3, 16-byte chunk l & 7: two whole lines per 16 lanes; the
     // fragment order -- lane = (pixel, 8 channels) -- would touch 16 lines per 16 lanes and cost the vector cache four times the
-    // tag lookups: measured 92 -> ... us for layer 3's conv1).  A lane stages pixels (l >> 3) and 8 + (l >> 3) of the tiles wave U + u.
+    // tag lookups -- measured: no difference, kept for the contiguous lines).  A lane stages pixels (l >> 3) and 8 + (l >> 3) of the tiles wave U + u.
     const int sp = lane >> 3, sc = lane & 7;
     // Buffer loads: a 32-bit byte offset per lane = pixel base + a scalar per (tap, k32 step); a tap outside the image takes an offset
     // past the end of the tensor, which the buffer hardware answers with zeros = the zero padding -- no select behind the load, so
