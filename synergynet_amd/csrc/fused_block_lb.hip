@@ -270,6 +270,14 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 SYNL_FENCE();
             }
         }
+        // EPF == KE: the next group's expand fragments are requested HERE, into the registers the expand just stopped reading -- the depthwise
+        // phase (~1600 cycles) and the project stand between the request and its use instead of the project alone (~800 cycles against an L2
+        // round trip of about that: with the loads replaced by constants the chain runs 270 -> 252 us, this placement gets 6 of those 18)
+        if (C::EPF == KE && G + C::NS < gend) {
+#pragma unroll
+            for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
+        }
+        SYNL_FENCE();
         SYNL_LAP(1);
         // ---- depthwise 3x3 + BN shift + ReLU6, split in place into the B operand of the project step ----
         constexpr int RING = C::S2 ? 4 : C::PPF + 1;   // project fragment slots (stride 2: output tiles go in pairs)
@@ -350,8 +358,10 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
             if (i < MT) fetch_p(i);
         if (more) {
             if (!C::TLATE) fetch_t(G + C::NS);
+            if (C::EPF != KE) {                                  // (one k32 step of them: the other slot is still being read -- see above for EPF == KE)
 #pragma unroll
-            for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
+                for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
+            }
         }
         if constexpr (C::S2) {
             static_assert(!C::S2 || (C::PPF == 2 && MT % 2 == 0), "output tiles in pairs, two tiles fetched ahead");
