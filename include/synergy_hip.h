@@ -152,6 +152,14 @@ int syn_backbone_forward_u8(syn_handle *h, const uint8_t *img_hwc, int B, float 
 int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int *box, const int *xofs,
                     const int16_t *xcoef, const int *yofs, const int16_t *ycoef, uint8_t *out, int B, void *stream);
 
+/* The same for the faces of SEVERAL frames in ONE launch (the reference loops over faces inside get_all_outputs, synergy3DMM.py:176-191,
+ * and over images outside it; a caller with a list of frames -- synergynet_amd get_all_outputs_batch -- stages all of them in one device
+ * block): frames = base of that block, frame_off [n_frames] byte offset of each frame in it, frame_dim [n_frames][2] = H, W of each,
+ * face_frame [B] = frame index of face b; box / tables / out per face as above.  Same arithmetic per face: same bytes. */
+int syn_crop_resize_frames(syn_handle *h, const uint8_t *frames, const long long *frame_off, const int *frame_dim,
+                           const int *face_frame, const int *box, const int *xofs, const int16_t *xcoef, const int *yofs,
+                           const int16_t *ycoef, uint8_t *out, int B, void *stream);
+
 /* reconstruct_vertex_62 (synergy3DMM.py:116-149) fused with the ROI affine of
  * _predict_vertices (utils/inference.py:127-138).
  * param [B,param_len] whitened; param_len must be 62 (else SYN_ERR_PARAM_LEN).

@@ -49,6 +49,7 @@ _SIGS = {
     'syn_backbone_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_backbone_forward_u8': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'syn_crop_resize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]),
+    'syn_crop_resize_frames': (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_void_p]),
     'syn_detector_flat_count': (C.c_size_t, []),
     'syn_load_detector': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'syn_detector_prior_count': (C.c_int, [C.c_int, C.c_int]),

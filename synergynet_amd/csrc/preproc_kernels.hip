@@ -14,10 +14,18 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t *__restr
                                                           const int *__restrict__ xofs /*[B,120] first tap, crop coords*/,
                                                           const short *__restrict__ xcoef /*[B,120,8]*/,
                                                           const int *__restrict__ yofs, const short *__restrict__ ycoef,
-                                                          uint8_t *__restrict__ out, int B) {
+                                                          uint8_t *__restrict__ out, int B,
+                                                          const long long *__restrict__ foff /* nullable: faces of SEVERAL frames (syn_crop_resize_frames) */,
+                                                          const int *__restrict__ fdim, const int *__restrict__ fidx) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * kImg * kImg) return;
     const int b = idx / (kImg * kImg), r = idx % (kImg * kImg);
+    if (foff) {                                            // (kernel-uniform) frame of face b: byte offset from `frame`, its height and width
+        const int f = fidx[b];
+        frame += foff[f];
+        H = fdim[2 * f];
+        W = fdim[2 * f + 1];
+    }
     const int oy = r / kImg, ox = r % kImg;
     const int sx = box[4 * b + 0], sy = box[4 * b + 1], ex = box[4 * b + 2], ey = box[4 * b + 3];
     const int cw = ex - sx, ch = ey - sy;                 // crop size
@@ -56,9 +64,10 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const uint8_t *__restr
 }
 
 void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, const int *xofs, const short *xcoef,
-                        const int *yofs, const short *ycoef, uint8_t *out, int B, hipStream_t s) {
+                        const int *yofs, const short *ycoef, uint8_t *out, int B, hipStream_t s, const long long *foff, const int *fdim,
+                        const int *fidx) {
     const int total = B * kImg * kImg;
-    crop_resize_kernel<<<(total + 255) / 256, 256, 0, s>>>(frame, H, W, box, xofs, xcoef, yofs, ycoef, out, B);
+    crop_resize_kernel<<<(total + 255) / 256, 256, 0, s>>>(frame, H, W, box, xofs, xcoef, yofs, ycoef, out, B, foff, fdim, fidx);
 }
 
 }  // namespace syn

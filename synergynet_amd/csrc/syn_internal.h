@@ -122,7 +122,8 @@ void launch_head_f16x2(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*
 
 // ---- on-device crop + Lanczos-4 resize (preproc_kernels.hip) ----
 void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, const int *xofs, const short *xcoef,
-                        const int *yofs, const short *ycoef, uint8_t *out, int B, hipStream_t s);
+                        const int *yofs, const short *ycoef, uint8_t *out, int B, hipStream_t s,
+                        const long long *foff = nullptr, const int *fdim = nullptr, const int *fidx = nullptr);   // foff: faces of several frames (frame + foff[fidx[b]], fdim[2 f] x fdim[2 f + 1])
 
 // ---- ResNet-50 variant (resnet_kernels.hip) ----
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add

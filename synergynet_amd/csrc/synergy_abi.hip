@@ -1875,6 +1875,18 @@ int syn_crop_resize(syn_handle *h, const uint8_t *frame, int H, int W, const int
     return SYN_OK;
 }
 
+int syn_crop_resize_frames(syn_handle *h, const uint8_t *frames, const long long *frame_off, const int *frame_dim, const int *face_frame,
+                           const int *box, const int *xofs, const int16_t *xcoef, const int *yofs, const int16_t *ycoef, uint8_t *out, int B,
+                           void *stream) {
+    if (!h || !frames || !frame_off || !frame_dim || !face_frame || !box || !xofs || !xcoef || !yofs || !ycoef || !out)
+        return fail(SYN_ERR_INVALID, "syn_crop_resize_frames: NULL argument");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_crop_resize_frames: B=%d", B);
+    DeviceGuard g(h->device);
+    syn::launch_crop_resize(frames, 0, 0, box, xofs, xcoef, yofs, ycoef, out, B, (hipStream_t)stream, frame_off, frame_dim, face_frame);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
 int syn_reconstruct_pitched(syn_handle *h, const float *param, int B, int param_len, int dense, int transform, const float *roi,
                             float *out, int row_pitch, int pad_writable, void *stream) {
     if (!h || !param || !out) return fail(SYN_ERR_INVALID, "syn_reconstruct: NULL argument");

@@ -538,6 +538,38 @@ class SynergyNet(nn.Module):
             raise ValueError('degenerate detection box')
         return [float(v) for v in roi_box[:5]], (sx, sy, ex, ey)
 
+    @staticmethod
+    def _face_tables(rects, n):
+        """_roi_and_box + the Lanczos tap tables for ALL faces of a call in array arithmetic (the per-face Python loop was 9 of the
+        ~21 us of host work per face): the same IEEE double operations in the same order as the scalar code -- `//` is floor division
+        on doubles, round() and numpy's rint both round halves to even -- so the results are the same bits
+        (tests/test_host_cpu.py::test_face_tables_equal_the_per_face_arithmetic).  The detection lists are mutated into the ROI as before."""
+        from .inference import lanczos4_tables
+        flat = [r for fr in rects for r in fr]
+        d = np.array([r[:5] for r in flat], dtype=np.float64).reshape(n, 5)
+        hc = (d[:, 1] + d[:, 3]) / 2
+        wc = (d[:, 0] + d[:, 2]) / 2
+        margin = np.floor_divide((d[:, 3] - d[:, 1]) * 1.2, 2)
+        r4 = np.stack([wc - margin, hc - margin, wc + margin, hc + margin], axis=1)
+        b4 = np.rint(r4)
+        if not np.all(np.isfinite(b4)) or np.any(np.abs(b4) > 2 ** 30):
+            raise ValueError('degenerate detection box')
+        box = b4.astype(np.int32)
+        w, h = box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]
+        if np.any(w <= 0) or np.any(h <= 0):
+            raise ValueError('degenerate detection box')
+        vals = r4.tolist()
+        for r, v in zip(flat, vals):
+            r[0], r[1], r[2], r[3] = v
+        roi = np.concatenate([r4, d[:, 4:5]], axis=1).astype(np.float32)
+        sides, inv = np.unique(np.concatenate([w, h]), return_inverse=True)
+        tabs = [lanczos4_tables(int(sd)) for sd in sides]
+        o_u = np.stack([t[0] for t in tabs])
+        c_u = np.stack([t[1] for t in tabs])
+        ofs = o_u[inv].reshape(2, n, 120).astype(np.int32, copy=False)
+        coef = c_u[inv].reshape(2, n, 120, 8).astype(np.int16, copy=False)
+        return roi, box, ofs, coef
+
     def _detect(self, frame):
         if self.face_detector is None:
             # the reference builds FaceBoxes() on every call (:170-171); here once, on first use (HIP kernels,
@@ -567,32 +599,40 @@ class SynergyNet(nn.Module):
         if n == 0:
             return [empty() for _ in frames]
         # per-face host tables: ROI (float32, as the reference's numpy arithmetic sees it), rounded box, Lanczos tap tables by crop side
-        roi = np.empty((n, 5), dtype=np.float32)
-        box = np.empty((n, 4), dtype=np.int32)
-        ofs = np.empty((2, n, 120), dtype=np.int32)
-        coef = np.empty((2, n, 120, 8), dtype=np.int16)
-        k = 0
-        for fr_rects in rects:
-            for rect in fr_rects:
-                r5, b4 = self._roi_and_box(rect)
-                roi[k] = r5
-                box[k] = b4
-                ofs[0, k], coef[0, k] = lanczos4_tables(b4[2] - b4[0])
-                ofs[1, k], coef[1, k] = lanczos4_tables(b4[3] - b4[1])
-                k += 1
+        roi, box, ofs, coef = self._face_tables(rects, n)
+        # ONE page-locked staging block for everything that goes up -- the frames that hold a face and the per-face tables -- and one DMA
+        # (a block, a copy call and a crop launch per frame were half of the call's host time at 16 frames)
+        used = [(i, np.ascontiguousarray(f)) for i, (f, c) in enumerate(zip(frames, counts)) if c]
+        for _, fr in used:
+            if fr.dtype != np.uint8 or fr.ndim != 3 or fr.shape[2] != 3:
+                raise RuntimeError('frame must be uint8 [H,W,3]')
+        slot = {i: k for k, (i, _) in enumerate(used)}
+        fidx = np.repeat(np.array([slot.get(i, 0) for i in range(len(frames))], dtype=np.int32), counts)
+        fdim = np.array([fr.shape[:2] for _, fr in used], dtype=np.int32)
+        parts, total = [], 0
+
+        def place(nbytes):
+            nonlocal total
+            at = total
+            total = (at + nbytes + 255) & ~255
+            return at
+        foff = np.array([place(fr.nbytes) for _, fr in used], dtype=np.int64)
+        tables = [roi, box, ofs, coef, foff, fdim, fidx]
+        t_at = [place(a.nbytes) for a in tables]
         with torch.cuda.device(self.device):
-            nb = lambda a: self._pinned_like(a).to(self.device, non_blocking=True)
-            roi_d, box_d, ofs_d, coef_d = nb(roi), nb(box), nb(ofs), nb(coef)
+            stage = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+            sv = stage.numpy()
+            for at, (_, fr) in zip(foff, used):
+                sv[at:at + fr.nbytes] = fr.reshape(-1)
+            for at, a in zip(t_at, tables):
+                sv[at:at + a.nbytes] = a.reshape(-1).view(np.uint8)
+            dev_blk = stage.to(self.device, non_blocking=True)
+            tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16, np.dtype(np.int64): torch.int64}
+            roi_d, box_d, ofs_d, coef_d, foff_d, fdim_d, fidx_d = [dev_blk[at:at + a.nbytes].view(tdt[a.dtype]).view(a.shape) for at, a in zip(t_at, tables)]
             crops = torch.empty((n, 120, 120, 3), dtype=torch.uint8, device=self.device)
-            lo = 0
-            for f, c in zip(frames, counts):
-                if c:
-                    fr = np.ascontiguousarray(f)
-                    if fr.dtype != np.uint8 or fr.ndim != 3 or fr.shape[2] != 3:
-                        raise RuntimeError('frame must be uint8 [H,W,3]')
-                    self.crop_resize(nb(fr), box_d[lo:lo + c], ofs_d[0, lo:lo + c], coef_d[0, lo:lo + c], ofs_d[1, lo:lo + c],
-                                     coef_d[1, lo:lo + c], out=crops[lo:lo + c])
-                lo += c
+            abi.check(self._lib.syn_crop_resize_frames(self._h, dev_blk.data_ptr(), foff_d.data_ptr(), fdim_d.data_ptr(), fidx_d.data_ptr(),
+                                                       box_d.data_ptr(), ofs_d[0].data_ptr(), coef_d[0].data_ptr(), ofs_d[1].data_ptr(),
+                                                       coef_d[1].data_ptr(), crops.data_ptr(), n, self._stream()))
             param = self.forward_crops_u8(crops)
             lmk_d = self.reconstruct(param, roi=roi_d, dense=False, transform=True)
             ang_d, t3d_d = self.predict_pose_batch(param, roi_d)

@@ -224,3 +224,39 @@ def test_roofline_fraction_can_be_recomputed_from_the_committed_kernel_stats():
     # and the profile bundle is the one the line says its counters are from
     t = json.load(open(os.path.join(root, r['counters_source']['file'])))
     assert t['commit'] == r['counters_source']['commit']
+
+
+def test_face_tables_equal_the_per_face_arithmetic():
+    """get_all_outputs_batch's array form of the ROI / crop-box / tap-table preparation (synergy3DMM.py _face_tables) against the
+    scalar statement of reference synergy3DMM.py:178-185 + utils/inference.py:98 (_roi_and_box): same bits, same in-place mutation of
+    the detection lists; halves (x.5 box edges, margins on the floor-division boundary) included."""
+    import copy
+    from synergynet_amd.inference import lanczos4_tables
+    from synergynet_amd.synergy3DMM import SynergyNet
+    rng = np.random.default_rng(5)
+    rects = []
+    for f in range(6):
+        fr = []
+        for i in range(f):                                   # frame 0 has no face
+            x, y = rng.uniform(-40, 400), rng.uniform(-40, 300)
+            s = [rng.uniform(30, 220), 100.0, 83.5, 125.0 / 1.2, 64.0][i % 5]
+            fr.append([x if i % 2 else float(round(x)) + 0.5, y, x + s, y + s * rng.uniform(0.9, 1.2), float(rng.uniform(0.5, 1))])
+        rects.append(fr)
+    n = sum(len(fr) for fr in rects)
+    want_rects = copy.deepcopy(rects)
+    roi = np.empty((n, 5), np.float32); box = np.empty((n, 4), np.int32)
+    ofs = np.empty((2, n, 120), np.int32); coef = np.empty((2, n, 120, 8), np.int16)
+    k = 0
+    for fr in want_rects:
+        for rect in fr:
+            r5, b4 = SynergyNet._roi_and_box(None, rect)
+            roi[k], box[k] = r5, b4
+            ofs[0, k], coef[0, k] = lanczos4_tables(b4[2] - b4[0])
+            ofs[1, k], coef[1, k] = lanczos4_tables(b4[3] - b4[1])
+            k += 1
+    got = SynergyNet._face_tables(rects, n)
+    for g, w in zip(got, (roi, box, ofs, coef)):
+        assert g.dtype == w.dtype and np.array_equal(g, w)
+    assert rects == want_rects
+    with pytest.raises(ValueError):
+        SynergyNet._face_tables([[[10.0, 10.0, 20.0, 10.2, 0.9]]], 1)
