@@ -271,8 +271,12 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
     }
     __syncthreads();
 
-    for (int nt = nt0 + wave; nt < nt_end; nt += NWV) {
-        const f32x4 sh = *(const f32x4 *)&shift[nt * 16 + 4 * g] * S;
+    // the BN shift of a tile is requested one tile ahead: loaded at the top of its own tile it was consumed at once, and vector memory
+    // retires in order -- the wait for it drained the five weight chunks in flight behind it at every tile
+    f32x4 sh_n = *(const f32x4 *)&shift[(nt0 + wave) * 16 + 4 * g];
+    auto tile = [&](int nt) __attribute__((always_inline)) {
+        const f32x4 sh = sh_n * S;
+        sh_n = *(const f32x4 *)&shift[(nt + NWV < nt_end ? nt + NWV : nt) * 16 + 4 * g];
         f32x4 acc[NFK];
 #pragma unroll
         for (int j = 0; j < NFK; ++j) acc[j] = sh;
@@ -297,8 +301,10 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
 #pragma unroll
             for (int j = 0; j < NFK; ++j) acc[j] = mfma_h(aa, bc[j][0], acc[j]);
             // refill this ring slot with the chunk 5 steps ahead (possibly of this wave's next channel tile)
+            // (no branch: after the last tile its own chunks are fetched again, unused -- a conditional fetch makes the compiler's
+            // wait-count bookkeeping fall back to vmcnt(0) at the join, i.e. every tile started by draining the ring)
             if (kc + 5 < KC32) lda(nt, kc + 5, ring[kc % 5]);
-            else if (nt + NWV < nt_end) lda(nt + NWV, kc + 5 - KC32, ring[kc % 5]);
+            else lda(nt + NWV < nt_end ? nt + NWV : nt, kc + 5 - KC32, ring[kc % 5]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -308,7 +314,11 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
             for (int t = 0; t < 4; ++t) v[t] = row16_sum(r6h(acc[j][t] * inv_s));
             if (r16 == 0) *(f32x4 *)&Ps[j * N + nt * 16 + 4 * g] = v * 0.0625f;
         }
-    }
+    };
+    // first tile peeled: the loop is then entered with the loads in flight that every later tile finds (the compiler's wait counts at a
+    // loop header are exact only when the entry and the back edge agree; otherwise: vmcnt(0) at the top of every tile)
+    tile(nt0 + wave);
+    for (int nt = nt0 + wave + NWV; nt < nt_end; nt += NWV) tile(nt);
     __syncthreads();
     if (NS > 1) {                                          // this slice of the pooled vectors -> HBM
         for (int it = tid; it < NFK * (NTS * 4); it += NT) {
