@@ -137,6 +137,28 @@ def test_resnet50_b512_distinct_faces_match_oracle(pack, basis):
         assert e.max() < TOL, f'mesh: worst face {i + e.argmax()} rel err {e.max():.3e}'
 
 
+def test_resnet50_beyond_the_32bit_offset_window(pack):
+    """ResNet-50 at B = 2400: layer 1's tensors are 2.2 GB, past what the buffer-load kernels address with 32-bit byte offsets
+    (conv_lt_kernel / conv_h2s_kernel: tensors < 2 GiB, csrc/resnet_kernels.hip launch_conv_f16x2) -- those convolutions must fall back to
+    the flat-addressed kernel while the smaller deep-layer tensors stay on the LDS-tiled one.  The batch is 300 copies of 8 distinct
+    faces; every copy must reproduce a B = 136 run of the same faces (fused pairs on both sides; the generic kernel walks K in the same
+    order: equal to fp32 rounding) and the copies must agree with each other bit for bit."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = synth.make_resnet50_state(2468)
+    m = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    eight = distinct_crops(8, seed=4242)
+    small = m.forward_crops_u8(torch.from_numpy(np.tile(eight, (17, 1, 1, 1))).cuda())[:8].cpu().numpy()
+    big = m.forward_crops_u8(torch.from_numpy(np.tile(eight, (300, 1, 1, 1))).cuda())
+    assert tuple(big.shape)[0] == 2400 and torch.isfinite(big).all()
+    bigv = big.view(300, 8, -1)
+    assert torch.equal(bigv[0], bigv[137]) and torch.equal(bigv[0], bigv[299])
+    e = per_face_rel(bigv[0].cpu().numpy(), small)
+    assert e.max() < 1e-5, f'face {e.argmax()}: {e.max():.3e}'
+    assert m.range_status()[0] == 0
+
+
 def test_pose_matrix_matches_reference_golden_and_oracle(model, basis, golden):
     """predict_pose(..., ret_mat=True) (utils/inference.py:146-157): vs the REAL reference's output (pose_mat_golden.npz) and,
     on a big batch of distinct parameter vectors, vs the oracle."""
