@@ -675,6 +675,15 @@ def main():
             del rmodel, rm
         except Exception as e:                                  # an extra must never cost the headline line
             extra['resnet50_b512'] = dict(error=str(e)[:200])
+        # configs[1] with several batches in flight (ReplicaRing): in a process of its own -- extra HIP streams slow every later
+        # measurement of the process that owns them (streams.py reconstruction_stream)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'b128_streams.py'), '--json', '1', '2', '4'],
+                               capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get('HIP_VISIBLE_DEVICES', str(local))))
+            extra['b128_lmk_only_batches_in_flight'] = dict(json.loads(r.stdout.strip().splitlines()[-1]),
+                                                            what='BASELINE configs[1] batches submitted round-robin to N replicas (handle + stream each): throughput of a queue of small batches; latency per batch is b128_lmk_only')
+        except Exception as e:
+            extra['b128_lmk_only_batches_in_flight'] = dict(error=str(e)[:200])
         # sustained clocks: the same headline step for ~2 s
         try:
             extra['sustained_2s'] = rate(B, step, steps=max(args.steps, int(2.0 / max(el / args.steps, 1e-4))), warmup=0)

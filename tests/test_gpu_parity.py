@@ -586,6 +586,32 @@ def test_resnet50_lds_tiled_gemm_is_bit_identical_to_the_wave_tiled_one(pack, B,
     assert tiled.range_status()[0] == 0
 
 
+def test_replica_ring_returns_the_bits_of_a_lone_replica(pack, backbone_sd):
+    """streams.ReplicaRing: small batches submitted round-robin to three replicas (handle + stream each) while the others are still
+    running -- different batches, different sizes, landmarks-only and dense -- give exactly what one model gives batch by batch."""
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.streams import ReplicaRing
+    from synergynet_amd.synergy3DMM import SynergyNet
+    mk = lambda: SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    lone, ring = mk(), ReplicaRing(mk, 3)
+    jobs = []
+    for k, B in enumerate((128, 5, 64, 128, 33, 1, 128)):
+        crops = torch.from_numpy(synth.make_crops(B, seed=50 + k)).cuda()
+        rois = torch.from_numpy(synth.make_rois(B, seed=70 + k)).cuda()
+        jobs.append((crops, rois, k % 3 == 2, ring.submit(crops, rois, dense=k % 3 == 2)))
+    ring.wait()
+    for crops, rois, dense, (param, lmk, mesh, pose, done) in jobs:
+        assert done.query()
+        p = lone.forward_crops_u8(crops)
+        assert torch.equal(param, p)
+        assert torch.equal(lmk, lone.reconstruct(p, roi=rois, dense=False))
+        if dense:
+            assert torch.equal(mesh, lone.reconstruct(p, roi=rois, dense=True))
+        a, t = lone.predict_pose_batch(p, rois)
+        assert torch.equal(pose[0], a) and torch.equal(pose[1], t)
+
+
 def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
     """syn_crop_resize (row f-1) vs oracle.preproc_numpy.crop_img + resize_lanczos4 on boxes that overhang every
     border of the frame, and get_all_outputs' landmarks vs the batched path on those host-made crops."""
