@@ -362,7 +362,7 @@ def main():
     ap.add_argument('--lmk-only', action='store_true', help='BASELINE configs[1]: 68 landmarks + pose only, no 53215-vertex mesh')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the `extra` measurements (other configs / API variants)')
-    ap.add_argument('--overlap', type=int, default=1, help='1 (default): reconstruction of batch i on a second stream beside the backbone of batch i+1; 0: one stream')
+    ap.add_argument('--overlap', type=int, default=None, help='2 (default): two replicas (handle + stream each) take the batches alternately; 1: one handle, reconstruction of batch i on a second stream beside the backbone of batch i+1; 0: one stream')
     ap.add_argument('--rec-priority', type=int, default=-1, help='HIP priority of the reconstruction stream (-1 high = default, 0 normal)')
     ap.add_argument('--arch', default='mobilenet_v2', choices=['mobilenet_v2', 'resnet50'],
                     help='resnet50 = BASELINE configs[4]; the default bench line is mobilenet_v2')
@@ -370,6 +370,8 @@ def main():
                     '~0.2 s, and a 20-step / 24 ms window taken right after W = 5 steps reads ~5 %% low (reported as `prewarm_s`)')
     ap.add_argument('--dry-run', action='store_true', help='multi-process plumbing only (gloo on host memory, no GPU): what the CPU tests drive')
     args = ap.parse_args()
+    if args.overlap is None:
+        args.overlap = 2
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -433,11 +435,25 @@ def main():
 
     # Two HIP streams (synergynet_amd/streams.py): the reconstruction of batch i (HBM-write bound) runs beside the backbone of
     # batch i+1 (issue bound); every step still does the whole pass, the final barrier waits for both streams.
-    from synergynet_amd.streams import OverlappedPipeline
-    pipe = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
+    from synergynet_amd.streams import OverlappedPipeline, ReplicaRing
+    if args.overlap == 2:
+        # two replicas (a handle + a HIP stream each; the second one imports the first one's packed constants on the device) take the
+        # batches alternately: the whole tail of batch i runs beside batch i + 1.  Every batch still does the whole pass into buffers
+        # of its own; the final barrier waits for both streams.
+        twin = SynergyNet(device=dev, load_constants=False, arch=args.arch)
+        twin.import_constants(model.export_constants())
+        ring = ReplicaRing(models=[model, twin])
+        outs = [(lmk, mesh), (torch.empty_like(lmk), None if args.lmk_only else twin.empty_vertices(B, dense=True))]
+        pipe = None
 
-    def step():
-        pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh, dense=not args.lmk_only)
+        def step():
+            lo, mo = outs[ring._k % 2]
+            ring.submit(crops, rois, dense=not args.lmk_only, lmk_out=lo, mesh_out=mo)
+    else:
+        pipe = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
+
+        def step():
+            pipe.submit(crops, rois, lmk_out=lmk, mesh_out=mesh, dense=not args.lmk_only)
 
     t_pre, n_pre = time.perf_counter(), 0
     while time.perf_counter() - t_pre < args.prewarm:       # clock ramp of an idle GPU: untimed, before the contract's W warm-up steps
@@ -460,6 +476,19 @@ def main():
         step()
     barrier()
     el = time.perf_counter() - t0
+    sustained = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # sustained clocks: the same step for ~2 s, right here -- before any extra creates further HIP streams (they cost every stream)
+        try:
+            n2 = max(args.steps, int(2.0 / max(el / args.steps, 1e-4)))
+            t1 = time.perf_counter()
+            for _ in range(n2):
+                step()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            sustained = dict(faces_s=round(B * n2 / e2, 1), ms_per_step=round(e2 / n2 * 1e3, 4), faces_per_step=B, steps=n2)
+        except Exception as e:
+            sustained = dict(error=str(e)[:200])
     if dist is not None:
         el_own = el
         t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -609,6 +638,10 @@ def main():
             extra['fp32_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_test(xf), 5), 4)
             extra['u8_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_crops_u8(crops), 5), 4)
             del xf, packed
+            if args.overlap == 2:
+                two = OverlappedPipeline(model, overlap=True, rec_priority=args.rec_priority)
+                extra['one_handle_two_streams'] = dict(rate(B, lambda: two.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=40, warmup=5),
+                                                       what='rounds 1-3a headline mode: one handle, the reconstruction of batch i on a second stream beside the backbone of batch i+1')
             if args.overlap:
                 one = OverlappedPipeline(model, overlap=False)
                 extra['one_stream'] = rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=10, warmup=2)
@@ -684,11 +717,7 @@ def main():
                                                             what='BASELINE configs[1] batches submitted round-robin to N replicas (handle + stream each): throughput of a queue of small batches; latency per batch is b128_lmk_only')
         except Exception as e:
             extra['b128_lmk_only_batches_in_flight'] = dict(error=str(e)[:200])
-        # sustained clocks: the same headline step for ~2 s
-        try:
-            extra['sustained_2s'] = rate(B, step, steps=max(args.steps, int(2.0 / max(el / args.steps, 1e-4))), warmup=0)
-        except Exception as e:
-            extra['sustained_2s'] = dict(error=str(e)[:200])
+        extra['sustained_2s'] = sustained
 
     if rank == 0:
         faces = B * world * args.steps
@@ -710,7 +739,7 @@ def main():
                    config=dict(workload=what,
                                faces_per_gpu_per_step=B, global_batch=B * world, parallelism=f'face-shard x{world}',
                                collectives='one RCCL broadcast of packed constants at init, none in the timed region',
-                               streams=('2: reconstruction of batch i beside the backbone of batch i+1' if args.overlap else '1'),
+                               streams={2: '2 replicas (handle + HIP stream each) take the batches alternately: batch i+1 runs beside the tail of batch i; every batch does the whole pass into its own buffers', 1: '2: reconstruction of batch i beside the backbone of batch i+1', 0: '1'}[args.overlap],
                                ingest='uint8 NHWC crops resident in HBM (what cv2.resize hands over, synergy3DMM.py:188); the fp32 NCHW '
                                       'forward_test ingest is timed in extra.fp32_ingest_*',
                                mesh_layout=None if args.lmk_only else 'row-pitched [B,3,53248][:, :, :53215] view written in place (same shape / values '

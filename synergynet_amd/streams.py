@@ -73,24 +73,30 @@ class ReplicaRing:
     that each use part of the chip: 0.39 ms whether it holds 1 face or 128.  A process that always has several such batches in flight
     (a server draining a request queue) gets their launches interleaved by the hardware: measured 331 k faces/s with one replica,
     506 k with two, 558 k with three, 575 k with four (tools/b128_streams.py, 0.223 ms per batch of 128).  Latency per batch is unchanged;
-    results are the same bits as a lone replica's (same kernels, same inputs)."""
+    results are the same bits as a lone replica's (same kernels, same inputs).
+    Large batches gain too: at B = 1024 with the mesh, TWO replicas alternating beat one handle with a reconstruction stream
+    (OverlappedPipeline) by 3.6-4 % on the same box (1.070 -> 1.032 ms per batch) -- the whole tail of batch i (the store-bound
+    reconstruction, the short last rounds of its kernels) runs beside batch i + 1 -- as long as the process owns no other streams: every
+    further HIP stream that has ever been used costs all of them (1.052 -> 1.121 ms with six more in the process).  bench.py's headline
+    uses exactly this (--overlap 2)."""
 
-    def __init__(self, make_model, n=4):
-        self.models = [make_model() for _ in range(n)]
+    def __init__(self, make_model=None, n=4, models=None):
+        self.models = list(models) if models is not None else [make_model() for _ in range(n)]
         dev = self.models[0].device
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.models]
         self._k = 0
 
-    def submit(self, crops_u8, rois, dense=False):
-        """Enqueue one batch on the next replica; returns (param, lmk, mesh | None, (angles, t3d), done_event)."""
+    def submit(self, crops_u8, rois, dense=False, lmk_out=None, mesh_out=None):
+        """Enqueue one batch on the next replica; returns (param, lmk, mesh | None, (angles, t3d), done_event).  lmk_out / mesh_out: result
+        buffers of THIS batch (a buffer must not be handed to a later batch before this batch's event has fired)."""
         i = self._k % len(self.models)
         self._k += 1
         m, st = self.models[i], self.streams[i]
         st.wait_stream(torch.cuda.current_stream(m.device))          # the inputs were produced on the caller's stream
         with torch.cuda.stream(st):
             param = m.forward_crops_u8(crops_u8)
-            lmk = m.reconstruct(param, roi=rois, dense=False)
-            mesh = m.reconstruct(param, roi=rois, dense=True) if dense else None
+            lmk = m.reconstruct(param, roi=rois, dense=False, out=lmk_out)
+            mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out) if dense else None
             pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
             done.record(st)
