@@ -704,8 +704,18 @@ def main():
             r.update(backbone_ms=round(bb, 4), backbone_tflops=round(fl / (bb * 1e-3) / 1e12, 2),
                      frac_of_fp32_mfma_peak=round(fl / (bb * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      what='BASELINE configs[4]: ResNet-50 120x120 B=512 -> 62 params -> 68 landmarks + 53215-vertex mesh + pose')
-            extra['resnet50_b512'] = r
+            r['mode'] = 'in this process (one handle + reconstruction stream, beside the streams the other extras left behind)'
             del rmodel, rm
+            try:
+                # the same workload as a bench line of its own, in a fresh process: the default schedule (two replicas) and no other streams
+                q = subprocess.run([sys.executable, os.path.abspath(__file__), '--arch', 'resnet50', '--steps', '40', '--warmup', '5', '--no-extras', '--no-cpu-baseline'],
+                                   capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get('HIP_VISIBLE_DEVICES', str(local))))
+                ql = json.loads(q.stdout.strip().splitlines()[-1])
+                r['in_process'] = dict(faces_s=r['faces_s'], ms_per_step=r['ms_per_step'], mode=r.pop('mode'))
+                r.update(faces_s=ql['value'], ms_per_step=ql['ms_per_step'], steps=ql['steps'], mode='own process, default schedule: ' + ql['config']['streams'][:60])
+            except Exception as e:
+                r['own_process_error'] = str(e)[:200]
+            extra['resnet50_b512'] = r
         except Exception as e:                                  # an extra must never cost the headline line
             extra['resnet50_b512'] = dict(error=str(e)[:200])
         # configs[1] with several batches in flight (ReplicaRing): in a process of its own -- extra HIP streams slow every later
