@@ -524,13 +524,12 @@ def main():
         feat = (ctypes.c_int * nmax)()
         ms = (ctypes.c_float * nmax)()
         fl = (ctypes.c_double * nmax)()
-        reps, acc_ms, n = 5, None, 0
+        reps, all_ms, n = 9, [], 0
         for _ in range(reps):
             n = lib.syn_backbone_profile(model._h, crops.data_ptr(), B, nmax, feat, ms, fl)
             assert n > 0, lib.syn_last_error()
-            cur = np.array(ms[:n], dtype=np.float64)
-            acc_ms = cur if acc_ms is None else acc_ms + cur
-        avg_ms = acc_ms / reps
+            all_ms.append(np.array(ms[:n], dtype=np.float64))
+        avg_ms = np.median(np.stack(all_ms), axis=0)            # per launch: one pre-empted launch in one repetition must not move the figure
         feats = list(feat[:n])
         flops = np.array(fl[:n])
         fam = [i for i, f in enumerate(feats) if 2 <= f <= 17 or f >= 100]  # fused inverted-residual block launches (>= 100: a chain, 100 * first + last)
@@ -569,6 +568,7 @@ def main():
                     mfma_issue_tflops=round(3 * achieved, 1), mfma_peak_fp16=PEAK_F16_MFMA_TFLOPS, mfma_pipe_busy=pipe_busy,
                     frac_of_fp32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     flops_per_launch=round(fam_fl / len(fam)), ms_per_launch=round(fam_ms / len(fam), 5),
+                    timing='per-launch median of 9 isolated forwards, HIP events after every launch on the launch stream (syn_backbone_profile)',
                     backbone=dict(ms=round(float(avg_ms.sum()), 4), launches=n,
                                   tflops=round(float(flops.sum()) / (float(avg_ms.sum()) * 1e-3) / 1e12, 3)),
                     per_launch=[dict(feature=int(f), ms=round(float(m), 4), tflops=round(float(x) / (float(m) * 1e-3) / 1e12, 2))
