@@ -492,6 +492,13 @@ def test_get_all_outputs_batch_equals_per_frame_calls(model):
     lite = model.get_all_outputs_batch(frames, [[list(r) for r in fr] for fr in rects], dense=False)
     for a, b in zip(lite, out):
         assert a[1] == [] and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    # chunked schedule (from 2 x chunk_faces faces on: staging of chunk k + 1 beside the device work and downloads of chunk k): same bits
+    for cf in (1, 2, 3):
+        chunked = model.get_all_outputs_batch(frames, [[list(r) for r in fr] for fr in rects], chunk_faces=cf)
+        for a, b in zip(chunked, out):
+            assert len(a[0]) == len(b[0]) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+            assert all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+            assert all(pa[0] == pb[0] and np.array_equal(pa[1], pb[1]) for pa, pb in zip(a[2], b[2]))
     # results stay valid after later calls (every call owns its host blocks)
     keep = out[0][1][0].copy()
     model.get_all_outputs_batch(frames[2:], [[list(r) for r in fr] for fr in rects[2:]])
