@@ -618,6 +618,7 @@ class SynergyNet(nn.Module):
         # Chunks of consecutive frames (>= chunk_faces faces each; one chunk below 2 x chunk_faces): while the device crops / runs /
         # downloads chunk k (downloads on a stream of their own, behind an event), the host stages chunk k + 1 into its page-locked
         # block -- the 37 MB memcpy of 16 full-HD frames and the 82 MB mesh download were one after the other before.
+        chunk_faces = max(1, int(chunk_faces))
         chunks, f_lo, lo, acc = [], 0, 0, 0
         for fi, c in enumerate(counts):
             acc += c
