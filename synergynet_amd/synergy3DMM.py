@@ -550,6 +550,20 @@ class SynergyNet(nn.Module):
         return [float(v) for v in roi_box[:5]], (sx, sy, ex, ey)
 
     @staticmethod
+    def _chunks(counts, chunk_faces):
+        """Consecutive frames -> chunks (frame_lo, frame_hi, face_lo, face_hi): every chunk holds at least chunk_faces faces (a chunk
+        costs a small-batch forward of its own), the frames are never split, a call below 2 x chunk_faces faces is one chunk."""
+        chunk_faces, n = max(1, int(chunk_faces)), int(sum(counts))
+        chunks, f_lo, lo, acc = [], 0, 0, 0
+        for fi, c in enumerate(counts):
+            acc += c
+            if acc >= chunk_faces and n - (lo + acc) >= chunk_faces:
+                chunks.append((f_lo, fi + 1, lo, lo + acc))
+                f_lo, lo, acc = fi + 1, lo + acc, 0
+        chunks.append((f_lo, len(counts), lo, n))
+        return chunks
+
+    @staticmethod
     def _face_tables(rects, n):
         """_roi_and_box + the Lanczos tap tables for ALL faces of a call in array arithmetic (the per-face Python loop was 9 of the
         ~21 us of host work per face): the same IEEE double operations in the same order as the scalar code -- `//` is floor division
@@ -618,14 +632,7 @@ class SynergyNet(nn.Module):
         # Chunks of consecutive frames (>= chunk_faces faces each; one chunk below 2 x chunk_faces): while the device crops / runs /
         # downloads chunk k (downloads on a stream of their own, behind an event), the host stages chunk k + 1 into its page-locked
         # block -- the 37 MB memcpy of 16 full-HD frames and the 82 MB mesh download were one after the other before.
-        chunk_faces = max(1, int(chunk_faces))
-        chunks, f_lo, lo, acc = [], 0, 0, 0
-        for fi, c in enumerate(counts):
-            acc += c
-            if acc >= chunk_faces and n - (lo + acc) >= chunk_faces:
-                chunks.append((f_lo, fi + 1, lo, lo + acc))
-                f_lo, lo, acc = fi + 1, lo + acc, 0
-        chunks.append((f_lo, len(frames), lo, n))
+        chunks = self._chunks(counts, chunk_faces)
         tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16, np.dtype(np.int64): torch.int64}
         with torch.cuda.device(self.device):
             host = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)

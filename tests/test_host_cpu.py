@@ -260,3 +260,26 @@ def test_face_tables_equal_the_per_face_arithmetic():
     assert rects == want_rects
     with pytest.raises(ValueError):
         SynergyNet._face_tables([[[10.0, 10.0, 20.0, 10.2, 0.9]]], 1)
+
+
+def test_frame_chunks_partition_the_call():
+    """get_all_outputs_batch's chunking (synergy3DMM.py _chunks): consecutive whole frames, every face exactly once and in order, at least
+    chunk_faces faces per chunk whenever there is more than one chunk, frames without faces anywhere."""
+    from synergynet_amd.synergy3DMM import SynergyNet
+    rng = np.random.default_rng(9)
+    cases = [[8] * 16, [0, 0, 5], [3], [0, 7, 0, 0, 9, 1, 0], [1] * 40, [64, 64], [63, 64], [200, 1, 1]]
+    cases += [list(rng.integers(0, 12, size=int(rng.integers(1, 30)))) for _ in range(50)]
+    for counts in cases:
+        n = int(sum(counts))
+        if n == 0:
+            continue
+        for cf in (1, 2, 5, 32, 64, 1000, 0):
+            ch = SynergyNet._chunks(counts, cf)
+            assert ch[0][0] == 0 and ch[0][2] == 0 and ch[-1][1] == len(counts) and ch[-1][3] == n
+            for (a0, a1, l0, l1), (b0, b1, m0, m1) in zip(ch, ch[1:]):
+                assert a1 == b0 and l1 == m0
+            for f0, f1, l0, l1 in ch:
+                assert f0 < f1 and l1 - l0 == sum(counts[f0:f1])
+                assert len(ch) == 1 or l1 - l0 >= max(1, cf)
+            if n < 2 * max(1, cf):
+                assert len(ch) == 1
