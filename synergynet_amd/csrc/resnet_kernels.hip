@@ -570,9 +570,9 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(W3), 0, 0x7fffffff, 0x00027000);
-    // LDS slot (16 bytes) of fragment lane (pixel r, k-group gg): gg 16 + ((r + 4 gg) & 15) -- the rotation keeps both the 8-byte
-    // writes of a staging instruction (4 pixels x 8 chunks per 32 lanes) and the 16-byte reads of a fragment (16 pixels of one k-group
-    // per 16 lanes) on distinct banks
+    // LDS slot (16 bytes) of fragment lane (pixel r, k-group gg): gg 16 + ((r + 4 gg) & 15) -- the rotation spreads the 8-byte writes of
+    // a staging instruction (2 pixels x 8 chunks per 16 lanes: without it all k-groups of a pixel share a bank) and keeps the 16-byte
+    // fragment reads at most 2-way conflicting in the hardware's lane groups (MI355X_MICROARCH LDS table)
     auto slot = [](int r, int gg) { return gg * 16 + ((r + 4 * gg) & 15); };
     int woff[2];                                                  // dword offset of this lane's 8 bytes inside a fragment, pixel halves 0 / 1
 #pragma unroll
@@ -697,7 +697,7 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         });
     LT_LAP(0);
     if (LT_PROF && blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 5) && steps >= 16)
-        printf("lt<%d> M %d N %d steps %d wave %d: mfma %llu barrier %llu park %llu fetch %llu dsread %llu  (cycles/step x100MHz ticks)\n", MTW, M, N, steps, wave,
+        printf("lt<%d> M %d N %d steps %d wave %d: mfma %llu barrier %llu park %llu fetch %llu dsread %llu  (shader cycles per step)\n", MTW, M, N, steps, wave,
                pt_[0] / steps, pt_[1] / steps, pt_[2] / steps, pt_[3] / steps, pt_[4] / steps);
     const int mw = m0 + wm * (MTW * 16), nw = n0 + wn * 64;
     if (mw >= M) return;
