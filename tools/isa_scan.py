@@ -1,0 +1,84 @@
+"""CPU-only (hipcc cross-compiles): the load / wait / matrix-instruction SEQUENCE of every loop of a kernel, one line per loop:
+
+    python tools/isa_scan.py resnet_kernels.hip "conv_lt_kernel<4>" "conv_h2s_kernel<2, 4, 2>"
+    python tools/isa_scan.py fused_block_lb.hip fused_chain_lb_kernel
+
+  L = global / buffer load, S = store, | = s_barrier, wN = s_waitcnt vmcnt(N), Mk = k matrix instructions in a row.
+
+What to look for: `L w0` right behind each other inside a loop -- something consumes a loaded register at once (a
+select that implements zero padding, a BN shift loaded at the top of its tile) and, vector memory retiring in order, drains every load in
+flight behind it; `w0` at the top of a loop whose steady state would allow `w8` -- the loop is entered with other loads in flight than
+the back edge leaves (peel the first iteration), or its body has a conditional fetch (the wait-count bookkeeping gives up at joins)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scan(text, want):
+    funcs = re.split(r'\n(?=_ZN3syn[^\n]*:\s*(?:;.*)?\n)', text)
+    for fn in funcs:
+        m = re.match(r'(_ZN3syn\S+):', fn)
+        if not m:
+            continue
+        name = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()
+        short = re.sub(r'\(.*', '', name)
+        if want and not any(w in short for w in want):
+            continue
+        lines = fn.split('\n')
+        labels = {}
+        for i, l in enumerate(lines):
+            mm = re.match(r'(\.LBB\d+_\d+):', l)
+            if mm:
+                labels[mm.group(1)] = i
+        loops = set()
+        for i, l in enumerate(lines):
+            mm = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+                loops.add((labels[mm.group(1)], i))
+        print('==', short[:140])
+        for a, b in sorted(loops):
+            body = lines[a:b + 1]
+            nm = sum('v_mfma' in l for l in body)
+            if nm < 4:
+                continue
+            seq = []
+            for l in body:
+                if re.search(r'\b(global_load|buffer_load|scratch_load)', l):
+                    seq.append('L')
+                elif re.search(r'\b(global_store|buffer_store|scratch_store)', l):
+                    seq.append('S')
+                elif 's_barrier' in l:
+                    seq.append('|')
+                else:
+                    mm = re.search(r's_waitcnt.*vmcnt\((\d+)\)', l)
+                    if mm:
+                        seq.append('w' + mm.group(1))
+                    elif 'v_mfma' in l:
+                        if seq and seq[-1].startswith('M'):
+                            seq[-1] = 'M%d' % (int(seq[-1][1:]) + 1)
+                        else:
+                            seq.append('M1')
+            print('  loop @%d-%d, %d mfma: %s' % (a, b, nm, ' '.join(seq)))
+
+
+def main():
+    if len(sys.argv) < 2:
+        sys.exit(__doc__)
+    src = sys.argv[1]
+    path = src if os.path.isfile(src) else os.path.join(ROOT, 'synergynet_amd', 'csrc', src)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'k.s')
+        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w',
+                            '-I' + os.path.join(ROOT, 'synergynet_amd', 'csrc'), '-I' + os.path.join(ROOT, 'include'), '-o', out, path] +
+                           [a for a in sys.argv[2:] if a.startswith('-D')], capture_output=True, text=True)
+        if r.returncode:
+            sys.exit(r.stderr[-3000:])
+        scan(open(out).read(), [a for a in sys.argv[2:] if not a.startswith('-D')])
+
+
+if __name__ == '__main__':
+    main()
