@@ -87,3 +87,25 @@ json.dump(out, open(os.path.join('profiles', f'traffic_{name}.json'), 'w'), inde
 print('launches/forward', n_launch, 'read MB', rd / 1e6, 'write MB', wr / 1e6, 'family MFMA pipe busy', out['fused_block_mfma_pipe_busy'])
 d = json.load(open(os.path.join(dst, 'bench_b1024.json')))
 print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], {k: v for k, v in d.get('cpu_baseline', {}).items() if k in ('value', 'cores', 'kind')})
+
+# ResNet-50 counters (tools/pmc_resnet.sh prints per-kernel averages to gpurun_out/pmc_resnet.txt): a compact table next to the bundle
+pmc_txt = os.path.join(os.path.dirname(src.rstrip('/')), 'pmc_resnet.txt')
+if os.path.isfile(pmc_txt):
+    import ast
+    import re
+    rows = {}
+    for line in open(pmc_txt):
+        m = re.match(r'(mfma|wait|valu) (.*?) (\{.*\}) launches (\d+)', line.strip())
+        if m:
+            k = re.sub(r'\(.*', '', m.group(2).replace('void syn::', '').replace('syn::', ''))
+            rows.setdefault(k, {}).update(ast.literal_eval(m.group(3)))
+    tab = ['# ResNet-50 B = 512, per-launch averages of the PMC passes of tools/pmc_resnet.sh (one pass per counter group, kernel-trace only).',
+           '# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_BUSY_CU_CYCLES)   (matrix pipe busy share of the SIMD cycles of busy CUs)',
+           '# wait = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES',
+           '%-36s %9s %9s %12s %12s' % ('kernel', 'mfma_busy', 'wait', 'insts_valu', 'lds_idx_act')]
+    for k, v in rows.items():
+        if 'SQ_BUSY_CU_CYCLES' in v and 'SQ_WAVE_CYCLES' in v and 'SQ_INSTS_VALU' in v:
+            tab.append('%-36s %9.3f %9.3f %12d %12d' % (k[:36], v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * v['SQ_BUSY_CU_CYCLES']),
+                                                       v['SQ_WAIT_INST_ANY'] / v['SQ_WAVE_CYCLES'], v['SQ_INSTS_VALU'], v['SQ_LDS_IDX_ACTIVE']))
+    open(os.path.join(dst, 'resnet50_pmc_b512.txt'), 'w').write('\n'.join(tab) + '\n')
+    print('resnet50_pmc_b512.txt:', len(tab) - 4, 'kernels')
