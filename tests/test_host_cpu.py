@@ -283,3 +283,32 @@ def test_frame_chunks_partition_the_call():
                 assert len(ch) == 1 or l1 - l0 >= max(1, cf)
             if n < 2 * max(1, cf):
                 assert len(ch) == 1
+
+
+def test_hot_loops_never_drain_their_loads_in_flight():
+    """ISA regression guard for round 3's main finding: in the steady-state loops of the LDS-tiled ResNet GEMM and of the
+    MobileNetV2 tail no `s_waitcnt vmcnt(0)` may appear and no wait may sit directly behind a load -- a select behind a buffer load, a
+    conditional fetch inside the loop, or a loop header whose entry state differs from its back edge each made the compiler drain every
+    load in flight once per step (92 -> 55 us for layer 3's conv1).  Cross-compiles on the CPU (hipcc -S), no GPU."""
+    import shutil
+    import sys
+    if not (shutil.which('hipcc') or os.path.isfile('/opt/rocm/bin/hipcc')):
+        pytest.skip('no hipcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    try:
+        import isa_scan
+    finally:
+        sys.path.pop(0)
+    checks = [('resnet_kernels.hip', ['conv_lt_kernel<4>', 'conv_lt_kernel<2>'], 48), ('head_kernel.hip', ['head_f16x2_kernel<1, 4, 8>'], 100)]
+    for src, kernels, min_mfma in checks:
+        loops = isa_scan.loop_sequences(isa_scan.compile_to_asm(src), kernels)
+        assert len(loops) == len(kernels), (src, list(loops))
+        for name, ls in loops.items():
+            main = [l for l in ls if l[2] >= min_mfma]
+            assert main, f'{name}: no steady-state loop found'
+            for a, b, nm, seq in main:
+                assert 'w0' not in seq, f'{name}: vmcnt(0) inside the loop at lines {a}-{b}: {" ".join(seq)}'
+                for x, y in zip(seq, seq[1:]):
+                    assert not (x == 'L' and y.startswith('w') and int(y[1:]) <= 1), f'{name}: a wait right behind a load: {" ".join(seq)}'
+                assert any(t.startswith('w') and int(t[1:]) >= 6 for t in seq), f'{name}: no counted wait (loads in flight across steps) left: {" ".join(seq)}'

@@ -18,7 +18,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def scan(text, want):
+def loop_sequences(text, want):
+    """{demangled kernel name: [(first line, last line, n_mfma, [tokens]) per loop with >= 4 matrix instructions]}"""
+    out = {}
     funcs = re.split(r'\n(?=_ZN3syn[^\n]*:\s*(?:;.*)?\n)', text)
     for fn in funcs:
         m = re.match(r'(_ZN3syn\S+):', fn)
@@ -39,7 +41,7 @@ def scan(text, want):
             mm = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
             if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
                 loops.add((labels[mm.group(1)], i))
-        print('==', short[:140])
+        res = []
         for a, b in sorted(loops):
             body = lines[a:b + 1]
             nm = sum('v_mfma' in l for l in body)
@@ -62,22 +64,35 @@ def scan(text, want):
                             seq[-1] = 'M%d' % (int(seq[-1][1:]) + 1)
                         else:
                             seq.append('M1')
+            res.append((a, b, nm, seq))
+        out[short] = res
+    return out
+
+
+def scan(text, want):
+    for short, loops in loop_sequences(text, want).items():
+        print('==', short[:140])
+        for a, b, nm, seq in loops:
             print('  loop @%d-%d, %d mfma: %s' % (a, b, nm, ' '.join(seq)))
+
+
+def compile_to_asm(src, defines=()):
+    path = src if os.path.isfile(src) else os.path.join(ROOT, 'synergynet_amd', 'csrc', src)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'k.s')
+        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w',
+                            '-I' + os.path.join(ROOT, 'synergynet_amd', 'csrc'), '-I' + os.path.join(ROOT, 'include'), '-o', out, path] + list(defines),
+                           capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr[-3000:])
+        return open(out).read()
 
 
 def main():
     if len(sys.argv) < 2:
         sys.exit(__doc__)
-    src = sys.argv[1]
-    path = src if os.path.isfile(src) else os.path.join(ROOT, 'synergynet_amd', 'csrc', src)
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, 'k.s')
-        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-w',
-                            '-I' + os.path.join(ROOT, 'synergynet_amd', 'csrc'), '-I' + os.path.join(ROOT, 'include'), '-o', out, path] +
-                           [a for a in sys.argv[2:] if a.startswith('-D')], capture_output=True, text=True)
-        if r.returncode:
-            sys.exit(r.stderr[-3000:])
-        scan(open(out).read(), [a for a in sys.argv[2:] if not a.startswith('-D')])
+    text = compile_to_asm(sys.argv[1], [a for a in sys.argv[2:] if a.startswith('-D')])
+    scan(text, [a for a in sys.argv[2:] if not a.startswith('-D')])
 
 
 if __name__ == '__main__':
