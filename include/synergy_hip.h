@@ -89,6 +89,13 @@ int syn_set_schedule(syn_handle *h, int fusion);
  * output, 1 + i = convolution i in state_dict order; unguarded slots read 1) and returns the number of tensors outside the window;
  * with fallback != 0 a violation switches the handle to the exact fp32-MFMA convolutions for all later forwards.  0 for MobileNetV2. */
 int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, int fallback);
+/* The same switch happens by itself: the head kernel of a poisoned forward also writes a page-locked word of the handle, which the
+ * NEXT syn_backbone_forward* reads at its entry (no synchronisation) -- from then on the handle runs the exact convolutions.  A
+ * caller that never asks sees one NaN batch (as many as were already in flight), not NaN for ever (reference behaviour being
+ * replaced: synergy3DMM.py:156-164 loads any checkpoint and always answers).  syn_backbone_range_events returns how many such
+ * automatic or requested switches happened since the weights were loaded (0 | 1); after a switch syn_backbone_range_status
+ * reports 0 violations and maxima of 1 (the guard is no longer armed). */
+int syn_backbone_range_events(syn_handle *h);
 
 /* BASELINE config 5: the ResNet-50 backbone (reference backbone_nets/resnet_backbone.py:139-254, resnet50 :304-312).
  * `flat` = conv1.weight, bn1.{weight,bias,running_mean,running_var}, then per block of layer1..layer4:

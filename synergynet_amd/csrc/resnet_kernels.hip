@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ residual, float *__restrict__ out, int M,
                                                    int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                   int act, int n_tiles, int m_tiles) {
+                                                   int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int nt_idx = q % n_tiles;
     const int mt_idx = (q / n_tiles) * 8 + xcd;           // all channel tiles of one pixel tile share an XCD's L2
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
 #pragma unroll
         for (int j = 0; j < MT; ++j) af[j] = an[j];
     }
+    float vmax = 0.f;                                     // range guard: a later fp16 x2 convolution may split this output
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + i * 16 + 4 * g;
@@ -120,29 +121,32 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vmax = fmaxf(vmax, fabsf(v[t]));
             *(f32x4 *)&out[(size_t)m * N + n] = v;
         }
     }
+    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition; the early returns above are wave-uniform)
 }
 
 template <int MT, int NT>
 static void launch_conv_t(const float *in, const float *W, const float *scale, const float *shift, const float *residual,
                           float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                          int act, hipStream_t s) {
+                          int act, hipStream_t s, float *stat) {
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     conv_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                             act, n_tiles, m_tiles);
+                                             act, n_tiles, m_tiles, stat);
 }
 
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
-                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s) {
+                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s, float *stat) {
     const int M = B * Hout * Hout;
     const long tiles64 = ((long)M + 255) / 256 * ((N + 63) / 64);      // every ResNet-50 Cout is a multiple of 64
-    if (tiles64 >= 2048) launch_conv_t<4, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
-    else if (tiles64 >= 512) launch_conv_t<2, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
-    else launch_conv_t<1, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s);
+    if (tiles64 >= 2048) launch_conv_t<4, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    else if (tiles64 >= 512) launch_conv_t<2, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    else launch_conv_t<1, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
 }
 
 // =====================================================================================
@@ -1143,7 +1147,7 @@ void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, 
 __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__restrict__ feat, const float *__restrict__ Wfc,
                                                               const float *__restrict__ bias, float *__restrict__ param,
                                                               float *__restrict__ pool, int P, int C, int n_out, int out_stride,
-                                                              const float *__restrict__ stat, int n_stat) {
+                                                              const float *__restrict__ stat, int n_stat, unsigned *guard_word) {
     __shared__ __attribute__((aligned(16))) float sp[2048];
     const int b = blockIdx.x;
     // range guard: a tensor that some fp16 x2 convolution split left the fp16 window (kRangeHi / kRangeLo) -> the results of this
@@ -1157,7 +1161,11 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
         m = fmaxf(m, __shfl_xor(m, 1));
         m = fmaxf(m, __shfl_xor(m, 2));
         const int bad = t < n_stat && (!(m <= kRangeHi) || !(m >= kRangeLo));
-        if (__syncthreads_or(bad)) poison = __builtin_nanf("");
+        if (__syncthreads_or(bad)) {
+            poison = __builtin_nanf("");
+            // ... and tell the host (page-locked mapped word, read at the entry of the handle's next forward: synergy_abi.hip run_resnet50)
+            if (guard_word && b == 0 && threadIdx.x == 0) __hip_atomic_store(guard_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     const float *f = feat + (size_t)b * P * C;
     const float inv = 1.0f / (float)P;
@@ -1185,8 +1193,8 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
 }
 
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
-                            int C, int n_out, int out_stride, hipStream_t s, const float *stat, int n_stat) {
-    pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride, stat, n_stat);
+                            int C, int n_out, int out_stride, hipStream_t s, const float *stat, int n_stat, unsigned *guard_word) {
+    pool_fc_generic_kernel<<<B, 256, 0, s>>>(feat, Wfc, bias, param, pool, P, C, n_out, out_stride, stat, n_stat, guard_word);
 }
 
 // =====================================================================================

@@ -14,8 +14,8 @@
 //   * depthwise 3x3 scattered into three row accumulators, neighbours through wave_shr / wave_shl, filter from LDS
 //     (broadcast reads); ReLU6 -> in-place fp16 x2 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
-//   * ONE service wave per workgroup keeps the image rows of all units flowing: global dwords -> fp16 -> LDS row ring
-//     (8 slots per unit), one barrier per output row.
+//   * ONE service wave per workgroup keeps the image rows of all units flowing: buffer loads one stage ahead (counted vmcnt, no
+//     branches) -> fp16 -> LDS row ring (8 slots per unit), one barrier per output row.
 // fp32 crops (forward_test) keep the tiled kernel of stem_block1.hip: arbitrary floats need the 3-way split on both sides.
 #include "syn_internal.h"
 
@@ -90,43 +90,66 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     if (service) {
         __builtin_amdgcn_s_setprio(3);          // every compute wave waits for this wave at the row barrier
         // ---- image rows -> fp16 -> ring: row iy of unit u lands in slot iy & 7 ----
-        // two image rows of every unit per call: all dword loads first (one global round trip), then byte -> float -> fp16 pairs
-        // (exact) and one 8-byte LDS store per dword
-        constexpr int PER_ROW = kImgW * 3 / 4;                     // 90 dwords
+        // A "stage" = image rows 2k, 2k+1 of the U faces of a group (k = 0 .. 59; stage k is what compute step k adds).  The
+        // loads of stage k+1 are ISSUED before stage k is converted, so a global round trip has a whole row step to land instead
+        // of standing in every step (round 3: 12 conditional loads, then s_waitcnt vmcnt(0) -- the load latency WAS the step).
+        // For the compiler to emit counted waits the loop body has no branches: buffer loads whose out-of-range lanes (faces
+        // past the batch, the surplus lanes of the last 64-lane round) return zeros, their conversions land in a dump dword
+        // pair nobody reads, and the slot offsets are immediates (four stages per loop iteration).
+        constexpr int PER_ROW = kImgW * 3 / 8;                     // 45 eight-byte pieces per image row
         constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
-        auto stage_rows = [&](int fb, int iy0) {                   // rows iy0, iy0+1 of faces fb .. fb+U-1
-            const uint8_t *fbase = img + (size_t)fb * kImgW * kImgW * 3;
-            unsigned v[ITER];
+        constexpr unsigned FACE_B = kImgW * kImgW * 3, ROW2_B = 2 * kImgW * 3;
+        unsigned gofs[ITER], lofs[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = lane + 64 * it;
+            const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+            const bool ok = i < TOTAL;
+            gofs[it] = ok ? (unsigned)(u * FACE_B + r * (kImgW * 3) + 8 * d) : 0x80000000u;
+            // dword of element 4 + 8d of the row slot; surplus lanes: dwords 188..191 of unit 0's slot (elements 376.., read by nobody)
+            lofs[it] = ok ? (unsigned)(u * C::UNIT_DW + r * (kRowEl / 2) + 2 + 4 * d) : (unsigned)(kRowEl / 2 - 4);
+        }
+        int ifb = blockIdx.x * C::U, ik = 0;                       // the stage `issue` requests next
+        auto issue = [&](u32x2 (&v)[ITER]) {
+            // base = row 2 ik of face ifb; records = what is left of the group's faces inside the batch (<= 0: everything reads as zero)
+            long long left = ((long long)B - ifb) * (long long)FACE_B;
+            if (left > (long long)(C::U * FACE_B)) left = C::U * FACE_B;
+            left -= (long long)ik * ROW2_B;
+            const int nrec = left > 0 ? (int)left : 0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t *>(img) + ((size_t)ifb * FACE_B + (size_t)ik * ROW2_B), 0, nrec, 0x00027000);
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b64(rs, gofs[it], 0, 0);
+            if (++ik == kHid) { ik = 0; ifb += gridDim.x * C::U; }
+        };
+        auto consume = [&](const u32x2 (&v)[ITER], int slot /*compile-time after unrolling*/) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const int i = lane + 64 * it;
-                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
-                const int f = fb + u, iy = iy0 + r;
-                v[it] = 0u;
-                // uniform 64-bit base + 32-bit lane offset: one address register per load instead of two
-                const unsigned off = (unsigned)((u * kImgW + iy) * kImgW * 3 + 4 * d);
-                if (i < TOTAL && f < B && iy < kImgW) v[it] = *reinterpret_cast<const unsigned *>(fbase + off);
-            }
+                u32x4 o;
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = lane + 64 * it;
-                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
-                const int iy = iy0 + r;
-                if (i < TOTAL && iy < kImgW) {
-                    u32x2 o;
-                    o[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)(v[it] & 0xff), (float)((v[it] >> 8) & 0xff)));
-                    o[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz((float)((v[it] >> 16) & 0xff), (float)(v[it] >> 24)));
-                    *reinterpret_cast<u32x2 *>(smem + u * C::UNIT_DW + (iy & (kSlots - 1)) * (kRowEl / 2) + 2 + 2 * d) = o;   // elements 4 + 4d ..
+                for (int w = 0; w < 2; ++w) {
+                    // bytes -> fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
+                    const unsigned lo = __builtin_amdgcn_perm(0x64646464u, v[it][w], 0x04010400u);
+                    const unsigned hi = __builtin_amdgcn_perm(0x64646464u, v[it][w], 0x04030402u);
+                    const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
+                    o[2 * w] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, lo) - k1024);
+                    o[2 * w + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, hi) - k1024);
                 }
+                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * (kRowEl / 2));
+                dst[0] = (u32x2){o[0], o[1]};
+                dst[1] = (u32x2){o[2], o[3]};
             }
         };
+        u32x2 va[ITER], vb[ITER];
+        issue(va);
         for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
-            stage_rows(fb, 0);
-            __syncthreads();                                   // (P) image rows 0, 1
-            for (int hy = 0; hy < kHid; ++hy) {
-                stage_rows(fb, 2 * hy + 2);                    // what output row hy+1 adds; the slots were last read in step hy-2
-                __syncthreads();
+            for (int k = 0; k < kHid; k += 4) {            // barrier (P), then the barriers that end compute steps 0 .. 58
+                issue(vb); __builtin_amdgcn_sched_barrier(0); consume(va, 0); __syncthreads();
+                issue(va); __builtin_amdgcn_sched_barrier(0); consume(vb, 2); __syncthreads();
+                issue(vb); __builtin_amdgcn_sched_barrier(0); consume(va, 4); __syncthreads();
+                issue(va); __builtin_amdgcn_sched_barrier(0); consume(vb, 6); __syncthreads();   // k + 3 == 59: the next group's stage 0
             }
+            __syncthreads();                                   // ends compute step 59
         }
         return;
     }
@@ -279,6 +302,7 @@ static void launch_stem_cfg(const uint8_t *img8, const unsigned *As3, const floa
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                     const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
     if (!img8 || !As3 || !Ap3 || !scl_p) return false;
+    if (reinterpret_cast<uintptr_t>(img8) & 7) return false;       // the service wave fetches eight-byte pieces of the image rows
     // like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
     // threshold, the spatially tiled kernel (stem_block1.hip)
     constexpr int min4 = 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)

@@ -128,7 +128,8 @@ void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, cons
 // ---- ResNet-50 variant (resnet_kernels.hip) ----
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
-                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s);
+                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s,
+                 float *stat = nullptr /* range-guard slot of the output, see launch_conv_f16x2 */);
 // same conv on the bf16 matrix pipe (exact 3-way operand split): W3 [N/16][taps*Cin/32][3][64][4] dwords, Cin % 32 == 0
 // stat (nullable): one float of the per-forward range-guard array -- max |output| is folded into it (resnet_kernels.hip range_note)
 void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
@@ -163,7 +164,8 @@ bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const flo
                              float *stat = nullptr);
 void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat = nullptr);
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
-                            int C, int n_out, int out_stride, hipStream_t s, const float *stat = nullptr, int n_stat = 0);
+                            int C, int n_out, int out_stride, hipStream_t s, const float *stat = nullptr, int n_stat = 0,
+                            unsigned *guard_word = nullptr /* host-mapped word: set to 1 by a forward the range guard poisoned */);
 
 // ---- reconstruction -----------------------------------------------------------------
 // basis: pre-packed per 32-vertex tile in MFMA-operand lane order (see recon_kernels.hip):

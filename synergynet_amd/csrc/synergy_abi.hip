@@ -306,6 +306,10 @@ struct syn_handle {
     int resnet_gemm = 1;           // SYNERGY_HIP_RESNET_GEMM=0: every convolution on conv_h2s_kernel (cross-check of conv_lt_kernel; 2: its 128-pixel tiles only)
     int resnet_fuse = 1;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel)
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
+    unsigned *guard_word = nullptr;    // page-locked host word the head kernel of a poisoned forward writes (mapped: guard_word_dev is its device
+    unsigned *guard_word_dev = nullptr; // alias); read WITHOUT synchronisation at the entry of the next forward -> automatic switch to fp32-MFMA
+    int guard_armed = 0;           // the last forward ran with the guard (syn_backbone_range_status reports nothing otherwise)
+    int range_events = 0;          // automatic switches since the weights were loaded (syn_backbone_range_events)
     RangeInfo ri;                  // mobilenet_v2: which blocks may run the fp16 x2 kernels (set by syn_load_backbone / syn_import_constants)
     int range_guard = 1;           // SYNERGY_HIP_RANGE_GUARD=0: ignore the verdict (tests use it to show that the adversarial cases do break the unguarded schedule)
     int fusion = 2;                // SYNERGY_HIP_FUSION: 2 (default) fused blocks / chains, every GEMM on the fp16 matrix instructions with
@@ -656,6 +660,11 @@ constexpr size_t kRangeFloats = (size_t)64 * syn::kRangeSub * syn::kRangeStride;
 float *range_slot(float *base, int t) { return base + (size_t)t * syn::kRangeSub * syn::kRangeStride; }
 int ensure_range(syn_handle *h) {
     if (h->d_range) return SYN_OK;
+    if (!h->guard_word) {
+        HIP_TRY(hipHostMalloc((void **)&h->guard_word, 64, hipHostMallocMapped));
+        h->guard_word[0] = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **)&h->guard_word_dev, h->guard_word, 0));
+    }
     HIP_TRY(hipMalloc((void **)&h->d_range, 2 * kRangeFloats * sizeof(float)));      // live copy | initial values
     std::vector<float> init(kRangeFloats, 0.f);
     for (int t = 0; t < 64; ++t)
@@ -677,8 +686,16 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     // ReLU activations have no static bound, so the fp16 x2 convolutions are guarded at run time: every tensor they split reports
     // its max |x| (resnet_kernels.hip range_note), the head kernel turns the results into NaN when one left [kRangeLo, kRangeHi],
     // and syn_backbone_range_status() lets the host switch the handle to the exact fp32-MFMA convolutions for good.
+    // A forward that left the window poisoned its results AND wrote the handle's page-locked word (head kernel); seen here, without
+    // a synchronisation, the handle runs the exact fp32-MFMA convolutions from now on -- a caller that never looks at
+    // syn_backbone_range_status gets a NaN batch (more while poisoned forwards are still in flight), not NaN for ever.
+    if (h->guard_word && *(volatile unsigned *)h->guard_word != 0 && h->range_guard) {
+        *(volatile unsigned *)h->guard_word = 0;
+        if (!h->resnet_fp32) { h->resnet_fp32 = 1; h->range_events += 1; }
+    }
     const bool f16 = h->fusion >= 2 && !h->resnet_fp32;
     const bool guard = f16 && h->range_guard;
+    h->guard_armed = guard;
     float *stat = nullptr;
     if (guard) {
         rc = ensure_range(h);
@@ -694,8 +711,10 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                                  stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr, h->resnet_gemm);
             return;
         }
+        // (a convolution whose WEIGHTS failed the fp16 criterion runs the exact kernel, but a later fp16 x2 convolution still splits its
+        // output: it reports into its slot like the others -- left at 0 the slot read as "below the window" on every forward)
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
-                         c.stride, c.pad, act, s);
+                         c.stride, c.pad, act, s, stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr);
     };
     const RConv &st = n.convs[0];
     // conv1+bn1+relu (:231-233): uint8 crops on the bf16 matrix pipe (batches that give every CU a workgroup), else the direct kernel
@@ -748,7 +767,8 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         float *t = X; X = Y; Y = t;
     }
     // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
-    syn::launch_pool_fc_generic(X, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, 16, 2048, n_out, n_out, s, stat, stat ? kResnetStat : 0);
+    syn::launch_pool_fc_generic(X, P + n.dst_fc_w, P + n.dst_fc_b, param, pool, B, 16, 2048, n_out, n_out, s, stat, stat ? kResnetStat : 0,
+                                stat ? h->guard_word_dev : nullptr);
     HIP_TRY(hipGetLastError());
     return SYN_OK;
 }
@@ -778,6 +798,7 @@ int syn_create(int device, syn_handle **out) {
 
 int syn_destroy(syn_handle *h) {
     if (h && h->d_range) { DeviceGuard g(h->device); (void)hipFree(h->d_range); h->d_range = nullptr; }
+    if (h && h->guard_word) { DeviceGuard g(h->device); (void)hipDeviceSynchronize(); (void)hipHostFree(h->guard_word); h->guard_word = h->guard_word_dev = nullptr; }
     if (!h) return SYN_OK;
     DeviceGuard g(h->device);
     if (h->d_backbone) (void)hipFree(h->d_backbone);
@@ -1371,6 +1392,10 @@ int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, i
     DeviceGuard g(h->device);
     float st[64];
     HIP_TRY(hipDeviceSynchronize());
+    if (!h->guard_armed) {          // the last forward ran the exact convolutions (or unguarded): the array still holds an EARLIER forward's maxima
+        for (int i = 0; layer_max && i < max_layers && i < 64; ++i) layer_max[i] = 1.0f;
+        return 0;
+    }
     {
         std::vector<float> raw(kRangeFloats);
         HIP_TRY(hipMemcpy(raw.data(), h->d_range, kRangeFloats * sizeof(float), hipMemcpyDeviceToHost));
@@ -1382,8 +1407,17 @@ int syn_backbone_range_status(syn_handle *h, float *layer_max, int max_layers, i
     int bad = 0;
     for (int i = 0; i < kResnetStat; ++i) bad += !(st[i] <= syn::kRangeHi) || !(st[i] >= syn::kRangeLo);
     for (int i = 0; layer_max && i < max_layers && i < 64; ++i) layer_max[i] = st[i];
-    if (bad && fallback) h->resnet_fp32 = 1;
+    if (bad && fallback) {
+        if (!h->resnet_fp32) h->range_events += 1;
+        h->resnet_fp32 = 1;
+        if (h->guard_word) *(volatile unsigned *)h->guard_word = 0;      // (the device is idle: the word of this forward has landed)
+    }
     return bad;
+}
+
+int syn_backbone_range_events(syn_handle *h) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_backbone_range_events: NULL handle");
+    return h->range_events;
 }
 
 size_t syn_resnet50_flat_count(void) { return resnet50().flat_count; }
@@ -1538,7 +1572,7 @@ int syn_load_backbone_resnet50(syn_handle *h, const float *flat, size_t n_floats
     HIP_TRY(hipMemcpy(h->d_backbone, pk.data(), n.packed_count * sizeof(float), hipMemcpyHostToDevice));
     h->arch = 1;
     h->ri = RangeInfo{};
-    h->resnet_fp32 = 0;
+    h->resnet_fp32 = 0; h->range_events = 0; h->guard_armed = 0; if (h->guard_word) { (void)hipDeviceSynchronize(); *(volatile unsigned *)h->guard_word = 0; }
     memcpy(h->resnet_w_unsafe, pk.data() + n.dst_range, sizeof h->resnet_w_unsafe);
     return SYN_OK;
 }
@@ -1718,7 +1752,7 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
         if (!h->d_backbone) HIP_TRY(hipMalloc((void **)&h->d_backbone, hd.backbone_floats * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(h->d_backbone, d, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
         h->ri = RangeInfo{};
-        h->resnet_fp32 = 0;
+        h->resnet_fp32 = 0; h->range_events = 0; h->guard_armed = 0; if (h->guard_word) { (void)hipDeviceSynchronize(); *(volatile unsigned *)h->guard_word = 0; }
         h->resnet_w_unsafe[0] = h->resnet_w_unsafe[1] = 0;
         if (h->arch == 0) {          // the sender's verdict on its weights rides in the blob
             HIP_TRY(hipMemcpyAsync(&h->ri, d + net().dst_range * sizeof(float), sizeof h->ri, hipMemcpyDeviceToHost, s));

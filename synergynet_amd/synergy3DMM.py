@@ -244,20 +244,30 @@ class SynergyNet(nn.Module):
             abi.check(self._lib.syn_load_backbone(self._h, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._have_backbone = True
         self._range_checked = False
+        self._range_events = 0
         self._warn_numerics()
 
     def _guarded(self, launch):
         """Runs a backbone launch.  ResNet-50 has no static activation bound, so its fp16 convolutions are guarded at run time
         (include/synergy_hip.h syn_backbone_range_status): the FIRST forward after a weight load is checked on the host, and a tensor
         outside the fp16 window switches the handle to the exact fp32-MFMA convolutions and repeats the launch; any later forward that
-        leaves the window returns NaN (checked on the device, no synchronisation) -- call `range_status(fallback=True)` then."""
+        leaves the window returns NaN (checked on the device, no synchronisation) AND tells the library through a page-locked word,
+        which switches the handle by itself at the entry of the next forward (syn_backbone_range_events; a warning here): a caller
+        sees the NaN batch(es) already in flight, never NaN for ever."""
         launch()
-        if self.arch == 'resnet50' and not self._range_checked:
+        if self.arch != 'resnet50':
+            return
+        if not self._range_checked:
             self._range_checked = True
             if self.range_status(fallback=True)[0] > 0:
+                self._range_events = self._lib.syn_backbone_range_events(self._h)
                 warnings.warn('SynergyNet(resnet50): activations leave the range of the fp16x2 convolutions; '
                               'this model now runs the exact fp32-MFMA convolutions')
                 launch()
+        elif self._lib.syn_backbone_range_events(self._h) > getattr(self, '_range_events', 0):
+            self._range_events = self._lib.syn_backbone_range_events(self._h)
+            warnings.warn('SynergyNet(resnet50): an earlier batch left the range of the fp16x2 convolutions (its results are NaN); '
+                          'this model now runs the exact fp32-MFMA convolutions')
 
     def range_status(self, fallback=False):
         """(number of guarded tensors outside the fp16 window in the last forward, per-tensor max |x| [54]); synchronises."""

@@ -203,6 +203,30 @@ def test_reconstruction_degenerate_coefficients(pack):
 
 # ---- ResNet-50: no static bound (ReLU), guarded at run time ----
 
+def test_resnet50_weight_unsafe_convolution_runs_exact_and_stays_guarded(pack):
+    """one filter row 1e-25 times its neighbours fails the fp16 weight criterion -> that convolution runs the fp32-MFMA kernel.
+    Its range slot used to stay 0 (= below the window) on every forward: NaN through the C ABI, a false 'activations leave the range'
+    warning and an all-fp32 handle through the class.  Now the exact kernel reports into the slot like the others."""
+    import torch
+    import warnings
+    from oracle import resnet_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = {k: np.array(v, copy=True) for k, v in synth.make_resnet50_state().items()}
+    sd['layer2.1.conv2.weight'][5] *= np.float32(1e-25)
+    crops = synth.make_crops(9, seed=4)
+    x = synth.normalize_crops(crops)
+    want = resnet_torch.resnet50_forward(sd, x)[0].numpy()[:, :62]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        m = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+        got = m.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
+    n_fb, report = m.numerics_report()
+    assert n_fb == 1, report                       # exactly that convolution fell back, not the handle
+    assert not any('activations leave the range' in str(x.message) for x in w)
+    assert m.range_status()[0] == 0 and np.isfinite(got).all()
+    assert per_face_err(got, want).max() < TOL
+
 def test_resnet50_runtime_guard(pack):
     import torch
     import warnings
@@ -237,3 +261,11 @@ def test_resnet50_runtime_guard(pack):
         got2 = m2.forward_crops_u8(cd).cpu().numpy()
         assert np.isnan(got2).all()
         assert m2.range_status()[0] > 0
+        # (3) ... and the handle recovers BY ITSELF: the poisoned forward told the library through its page-locked word, the next
+        # forward runs the exact convolutions (one NaN batch, not NaN for ever); the caller never touched range_status(fallback=True)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            got3 = m2.forward_crops_u8(cd).cpu().numpy()
+        assert w and 'earlier batch' in str(w[0].message)
+        assert per_face_err(got3, want).max() < TOL, s
+        assert m2.range_status()[0] == 0 and m2.numerics_report()[0] > 0        # guard no longer armed: nothing stale is reported
