@@ -121,6 +121,17 @@ int syn_load_basis(syn_handle *h, const float *w_shp, const float *w_exp, const 
 size_t syn_constants_bytes(syn_handle *h);
 int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream);
 int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void *stream);
+/* The same hand-off in ONE call for a caller that holds an RCCL communicator instead of torch.distributed (what replaces the
+ * reference's nn.DataParallel replication, benchmark.py:112 / main_train.py:176): collective over `nccl_comm` (an ncclComm_t; every
+ * rank calls it with its own handle, on the device the communicator was created for) -- rank `root` exports, ncclBroadcast ships the
+ * size and then the blob, every other rank imports; returns after the stream has drained.  The library does not link RCCL: it
+ * calls the instance the process already holds (the caller's, or torch's librccl.so.1), so the communicator and the code that
+ * uses it always belong together.  SYN_ERR_INVALID for a NULL communicator, SYN_ERR_NOT_LOADED when the process holds no RCCL
+ * (or the root handle no constants). */
+int syn_bcast_constants(syn_handle *h, void *nccl_comm, int root, void *stream);
+/* The 256-byte header syn_export_constants would write for this handle NOW (what it holds: arch, backbone / basis present, vertex and
+ * landmark counts, total bytes), into HOST memory, no device call -- how a host mirror learns what a syn_bcast_constants import gave it. */
+int syn_describe_constants(syn_handle *h, void *host_header, size_t bytes);
 
 /* Device-free twins of the hand-off: neither makes a HIP call, so a loader process (or a test) without a GPU can produce and
  * vet the blob.  syn_pack_constants_host writes, from HOST arrays (same meaning as syn_load_backbone / _resnet50 / syn_load_basis;

@@ -43,6 +43,8 @@ _SIGS = {
     'syn_constants_bytes': (C.c_size_t, [C.c_void_p]),
     'syn_export_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'syn_import_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'syn_bcast_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'syn_describe_constants': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'syn_pack_constants_host_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'syn_pack_constants_host': (C.c_int, [C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     'syn_check_constants_host': (C.c_int, [C.c_void_p, C.c_size_t]),

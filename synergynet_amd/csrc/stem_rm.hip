@@ -9,8 +9,11 @@
 //     B = the raw pixel bytes as fp16 -- every integer 0..255 IS an fp16 number, so only the filter is carried as two fp16
 //     pieces (22 bits, scaled by a power of two; 2 MFMAs per step).  The normalisation is folded: (2p-255)/256 = p/128 - 255/256, i.e. the packed filter is w/128
 //     (exact) and the accumulator starts at shift - 255/256 * sum(w); zero padding (0 in normalised space) is the raw value
-//     127.5, also exact in fp16.  K-slot layout chosen so that a lane's sixteen taps are two runs of consecutive
-//     bytes: lane half 0 carries kernel row 0 (9 taps) + the first 5 taps of row 1, half 1 carries row 2 + the last 4 of row 1;
+//     127.5, also exact in fp16.  The LDS row ring holds a pixel as FOUR fp16 (R, G, B, -), so a lane's window of three pixels
+//     starts on a 16-byte boundary and is read by aligned ds_read_b128 / b64 (round 2-3: packed RGB, a lane's nine taps started at
+//     an odd fp16 and the compiler's merged 16-byte reads were misaligned -- 20 of the kernel's 130 us, tools: the `ral` variant
+//     of DESIGN 7).  K is then 9 pixel quads of 4 slots (the fourth has zero weight): lane half 0 carries kernel row 0 and the
+//     first two pixels of row 1, half 1 kernel row 2 and the last pixel of row 1 -- three k16 steps (the third half empty);
 //   * depthwise 3x3 scattered into three row accumulators, neighbours through wave_shr / wave_shl, filter from LDS
 //     (broadcast reads); ReLU6 -> in-place fp16 x2 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
@@ -50,7 +53,7 @@ __device__ __forceinline__ float right_of(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
 constexpr int kImgW = 120, kHid = 60;
-constexpr int kRowEl = 384;               // fp16 elements per image-row slot: [0] unused, [1..3] left padding pixel, [4 + 3x + c], tail
+constexpr int kRowDw = 244;               // dwords per image-row slot: 122 pixels x (R, G, B, -) fp16; pixel t = image column t - 1 (t = 0: left padding)
 constexpr int kSlots = 8;                 // image-row ring per unit
 constexpr unsigned kPadF16 = 0x57F8u;     // 127.5 as fp16: the raw value of a zero in normalised space
 }  // namespace
@@ -59,14 +62,14 @@ template <int U_, int WPE_>
 struct StemRmCfg {
     static constexpr int U = U_, WPE = WPE_;                                  // faces (units) per workgroup
     static constexpr int NCW = 2 * U, NT = (NCW + 1) * 64;         // compute waves (face, half) + one service wave
-    static constexpr int UNIT_DW = (kSlots + 1) * kRowEl / 2;      // ring + one all-padding row (image row -1)
+    static constexpr int UNIT_DW = (kSlots + 1) * kRowDw;          // ring + one all-padding row (image row -1)
     static constexpr int LDS_DW = U * UNIT_DW + 10 * 32 + 32 + 32; // + depthwise filter 9x32 | depthwise shift | stem shift | project shift
     static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
 };
 
 template <class C>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, 3)))
-void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][2][64][4]*/,
+void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[3][2][64][4]*/,
                     const float *__restrict__ s_shift /*[32] folded, then {S, 1/S, 6 S} of the stem filter*/, const float *__restrict__ Wd /*[9][32] scaled*/,
                     const float *__restrict__ d_shift, const unsigned *__restrict__ Ap3 /*[1][2][2][64][4]*/,
                     const float *__restrict__ p_shift /*[16]*/, const float *__restrict__ scl_p, float *__restrict__ Y /*[B,60,60,16]*/, int B) {
@@ -82,8 +85,8 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     const float Ss = s_shift[32], inv_ss = s_shift[33], c6s = s_shift[34], Sp = scl_p[0], inv_sp = scl_p[1];
     for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i] * inv_ss;
     if (tid < 32) { Filt[DSH + tid] = d_shift[tid]; Ssh[tid] = s_shift[tid] * Ss; Psh[tid] = tid < 16 ? p_shift[tid] * Sp : 0.f; }
-    // padding row (image row -1) and the left padding pixel / tails of every ring slot: 127.5 everywhere, then the service wave only
-    // ever rewrites elements 4 .. 363
+    // padding row (image row -1), the left padding pixel, the fourth element of every pixel and the tails of every ring slot: 127.5
+    // everywhere, then the service wave only ever rewrites pixels 1 .. 120
     for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadF16 | (kPadF16 << 16);
     __syncthreads();
 
@@ -93,24 +96,25 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
         // A "stage" = image rows 2k, 2k+1 of the U faces of a group (k = 0 .. 59; stage k is what compute step k adds).  The
         // loads of stage k+1 are ISSUED before stage k is converted, so a global round trip has a whole row step to land instead
         // of standing in every step (round 3: 12 conditional loads, then s_waitcnt vmcnt(0) -- the load latency WAS the step).
-        // For the compiler to emit counted waits the loop body has no branches: buffer loads whose out-of-range lanes (faces
-        // past the batch, the surplus lanes of the last 64-lane round) return zeros, their conversions land in a dump dword
-        // pair nobody reads, and the slot offsets are immediates (four stages per loop iteration).
-        constexpr int PER_ROW = kImgW * 3 / 8;                     // 45 eight-byte pieces per image row
+        // For the compiler to emit counted waits the loop body has no vector-memory branches: buffer loads whose out-of-range lanes
+        // (faces past the batch, the surplus lanes of the last 64-lane round) return zeros, and the slot offsets are immediates
+        // (four stages per loop iteration).
+        constexpr int PER_ROW = kImgW / 8;                         // 15 lanes per image row: eight pixels = 24 bytes each
         constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
         constexpr unsigned FACE_B = kImgW * kImgW * 3, ROW2_B = 2 * kImgW * 3;
         unsigned gofs[ITER], lofs[ITER];
+        bool live[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int i = lane + 64 * it;
             const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
-            const bool ok = i < TOTAL;
-            gofs[it] = ok ? (unsigned)(u * FACE_B + r * (kImgW * 3) + 8 * d) : 0x80000000u;
-            // dword of element 4 + 8d of the row slot; surplus lanes: dwords 188..191 of unit 0's slot (elements 376.., read by nobody)
-            lofs[it] = ok ? (unsigned)(u * C::UNIT_DW + r * (kRowEl / 2) + 2 + 4 * d) : (unsigned)(kRowEl / 2 - 4);
+            live[it] = i < TOTAL;
+            gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * (kImgW * 3) + 24 * d) : 0x80000000u;
+            lofs[it] = (unsigned)(u * C::UNIT_DW + r * kRowDw + 2 + 16 * d);      // pixel t = 1 + 8 d of the row slot
         }
         int ifb = blockIdx.x * C::U, ik = 0;                       // the stage `issue` requests next
-        auto issue = [&](u32x2 (&v)[ITER]) {
+        struct Px8 { u32x2 q[3]; };                                // 24 bytes = eight packed RGB pixels
+        auto issue = [&](Px8 (&v)[ITER]) {
             // base = row 2 ik of face ifb; records = what is left of the group's faces inside the batch (<= 0: everything reads as zero)
             long long left = ((long long)B - ifb) * (long long)FACE_B;
             if (left > (long long)(C::U * FACE_B)) left = C::U * FACE_B;
@@ -119,28 +123,32 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t *>(img) + ((size_t)ifb * FACE_B + (size_t)ik * ROW2_B), 0, nrec, 0x00027000);
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) v[it] = __builtin_amdgcn_raw_buffer_load_b64(rs, gofs[it], 0, 0);
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v[it].q[w] = __builtin_amdgcn_raw_buffer_load_b64(rs, gofs[it] + 8 * w, 0, 0);
             if (++ik == kHid) { ik = 0; ifb += gridDim.x * C::U; }
         };
-        auto consume = [&](const u32x2 (&v)[ITER], int slot /*compile-time after unrolling*/) {
+        auto consume = [&](const Px8 (&v)[ITER], int slot /*compile-time after unrolling*/) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                u32x4 o;
+                const unsigned D[7] = {v[it].q[0][0], v[it].q[0][1], v[it].q[1][0], v[it].q[1][1], v[it].q[2][0], v[it].q[2][1], 0u};
+                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * kRowDw);
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    // bytes -> fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
-                    const unsigned lo = __builtin_amdgcn_perm(0x64646464u, v[it][w], 0x04010400u);
-                    const unsigned hi = __builtin_amdgcn_perm(0x64646464u, v[it][w], 0x04030402u);
+                for (int k = 0; k < 8; ++k) {
+                    // bytes 3k .. 3k+2 -> (R, G), (B, 0) as fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
+                    const int a = (3 * k) / 4, sft = (3 * k) % 4;
+                    const unsigned T = sft ? __builtin_amdgcn_alignbyte(D[a + 1], D[a], sft) : D[a];
+                    const unsigned rg = __builtin_amdgcn_perm(0x64646464u, T, 0x04010400u);
+                    const unsigned bx = __builtin_amdgcn_perm(0x64646464u, T, 0x040c0402u);
                     const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
-                    o[2 * w] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, lo) - k1024);
-                    o[2 * w + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, hi) - k1024);
+                    u32x2 o;
+                    o[0] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, rg) - k1024);
+                    o[1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, bx) - k1024);
+                    if (live[it]) dst[k] = o;
                 }
-                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * (kRowEl / 2));
-                dst[0] = (u32x2){o[0], o[1]};
-                dst[1] = (u32x2){o[2], o[3]};
             }
         };
-        u32x2 va[ITER], vb[ITER];
+        Px8 va[ITER], vb[ITER];
         issue(va);
         for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
             for (int k = 0; k < kHid; k += 4) {            // barrier (P), then the barriers that end compute steps 0 .. 58
@@ -160,18 +168,19 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     const int hc = 30 * c + j - 1;                                 // stem / hidden column of this lane
     const bool col_ok = (unsigned)hc < (unsigned)kHid;
     const bool out_lane = j >= 1 && j <= 30;
-    const unsigned short *ring = reinterpret_cast<const unsigned short *>(smem + uw * C::UNIT_DW);
-    // element offset of this lane's first tap inside a row slot: column 2*hc - 1 -> 4 + 3*(2hc - 1) = 6hc + 1 (clamped for the
-    // out-of-image lanes, whose result is forced to zero anyway)
-    const int run0 = 6 * (col_ok ? hc : 0) + 1;
-    u32x4 as[2][2], ap[2][2];
+    const unsigned *ring = smem + uw * C::UNIT_DW;
+    // dword offset of this lane's window inside a row slot: pixels t = 2 hc, 2 hc + 1, 2 hc + 2 (image columns 2 hc - 1 ..) = bytes
+    // 16 hc .. 16 hc + 23 (clamped for the out-of-image lanes, whose result is forced to zero anyway)
+    const int run0 = 4 * (col_ok ? hc : 0);
+    u32x4 as[3][2], ap[2][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) as[s][p] = *(const u32x4 *)(As3 + ((size_t)s * 2 + p) * 256 + lane * 4);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            as[s][p] = *(const u32x4 *)(As3 + ((size_t)s * 2 + p) * 256 + lane * 4);
-            ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)s * 2 + p) * 256 + lane * 4);
-        }
+        for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)s * 2 + p) * 256 + lane * 4);
     const int cb = 4 * h;
     auto opaque_cb = [&]() { int v = cb; asm volatile("" : "+v"(v)); return v; };
 
@@ -239,21 +248,19 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
         auto step = [&](int hy, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
             const int cbo = opaque_cb();
             // ---- im2col B operand: image rows 2hy-1 (kernel row 0), 2hy, 2hy+1 from the ring; row -1 = the padding row ----
-            const unsigned short *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * kRowEl + run0;
-            const unsigned short *r1 = ring + ((2 * hy) & (kSlots - 1)) * kRowEl + run0;
-            const unsigned short *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * kRowEl + run0;
-            // lane half 0: slots 0..8 = kernel row 0 taps 0..8, slots 9..13 = row 1 taps 0..4; half 1: slots 0..8 = row 2 taps 0..8,
-            // slots 9..12 = row 1 taps 5..8 (the remaining slots have zero weights: any finite value will do)
-            const unsigned short *pa = h ? r2 : r0, *pb = h ? r1 - 4 : r1 - 9;
-            u32x4 xb[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int dq = 0; dq < 4; ++dq) {
-                    const int q0 = 8 * s + 2 * dq, q1 = q0 + 1;
-                    const unsigned lo = q0 < 9 ? pa[q0] : pb[q0 < 14 ? q0 : 13], hi = q1 < 9 ? pa[q1] : pb[q1 < 14 ? q1 : 13];
-                    xb[s][dq] = lo | (hi << 16);
-                }
+            const unsigned *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * kRowDw + run0;
+            const unsigned *r1 = ring + ((2 * hy) & (kSlots - 1)) * kRowDw + run0;
+            const unsigned *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * kRowDw + run0;
+            // lane half 0: kernel row 0 (three pixels) + pixels 0, 1 of kernel row 1; half 1: kernel row 2 + pixel 2 of row 1 (and one
+            // pixel past the window under zero weights).  K slots: step 0 = pixels 0, 1 of pa, step 1 = pixel 2 of pa | first pixel of
+            // pb, step 2 = second pixel of pb | (zero weights)
+            const unsigned *pa = h ? r2 : r0, *pb = h ? r1 + 4 : r1;
+            const u32x4 wa = *(const u32x4 *)pa, wb = *(const u32x4 *)pb;
+            const u32x2 wc = *(const u32x2 *)(pa + 4);
+            u32x4 xb[3];
+            xb[0] = wa;
+            xb[1] = (u32x4){wc[0], wc[1], wb[0], wb[1]};
+            xb[2] = (u32x4){wb[2], wb[3], wb[2], wb[3]};
             f32x16 e;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -262,7 +269,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
                 for (int t = 0; t < 4; ++t) e[4 * q + t] = sh[t];
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < 3; ++s) {
                 e = mfma32s(as[s][1], xb[s], e);
                 e = mfma32s(as[s][0], xb[s], e);
             }

@@ -107,7 +107,7 @@ void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const 
 //   with m = 3*kx + ci (the byte order of a pixel triple in the HWC image); the other slots are zero.
 // s_shift [32]: BN shift - 255/256 * sum of the (scaled) filter, then {S, 1/S, 6 S}; Ap3: the 32->16 projection in rm_project order
 // (1 group), scl_p its scales.
-constexpr int rm_stem_dwords() { return 2 * 2 * 256 + 32 + 4; }
+constexpr int rm_stem_dwords() { return 3 * 2 * 256 + 32 + 4; }
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                     const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s);
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -264,7 +265,7 @@ struct ConstHeader {   // first 256 bytes of an exported constants buffer
 };
 static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
 constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
-constexpr uint32_t kConstVersion = 2;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict)
+constexpr uint32_t kConstVersion = 3;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring)
 
 // verdict of the load-time range analysis of the fp16 x2 schedule (analyze_mbv2_ranges below); 64 dwords at Net::dst_range
 struct RangeInfo {
@@ -482,7 +483,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
             if (h->fusion >= 2 && img8 && (h->early_rm & 8) && !(u1 & 1u) &&
-                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 2 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
+                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 3 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
                                     reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s)) {
                 li += 2;
                 mark(1);
@@ -1116,22 +1117,25 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
         }
         if (L.dst_wrm && L.kind == STEM) {   // row-marching stem (stem_rm.hip): filter / 128 x S as two fp16 pieces in its K-slot order + folded shift + scales
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
-            float *fsh = pk.data() + L.dst_wrm + 2 * 2 * 256;
-            auto tapw = [&](int co, int ky, int m) { return w[co * 27 + (m % 3) * 9 + ky * 3 + m / 3] * bn_scale[co]; };   // m = 3*kx + ci
+            float *fsh = pk.data() + L.dst_wrm + 3 * 2 * 256;
+            auto tapw = [&](int co, int ky, int kx, int ci) { return w[co * 27 + ci * 9 + ky * 3 + kx] * bn_scale[co]; };
             float mx = 0.f;
             for (int co = 0; co < 32; ++co)
                 for (int t = 0; t < 27; ++t) mx = fmaxf(mx, fabsf(w[co * 27 + t] * bn_scale[co] * (1.0f / 128.0f)));
                         const float S = pow2_scale(mx);
-            for (int st = 0; st < 2; ++st)
+            // K slots of (lane half hh, k16 step st): two pixel quads (R, G, B, -) each -- the LDS ring of stem_rm.hip holds a pixel as four
+            // fp16.  (ky, kx) per quad, ky < 0 = zero weights: half 0 kernel row 0 and pixels 0, 1 of row 1; half 1 row 2 and pixel 2 of row 1
+            static const int quad_tap[2][3][2][2] = {{{{0, 0}, {0, 1}}, {{0, 2}, {1, 0}}, {{1, 1}, {-1, 0}}},
+                                                     {{{2, 0}, {2, 1}}, {{2, 2}, {1, 2}}, {{-1, 0}, {-1, 0}}}};
+            for (int st = 0; st < 3; ++st)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int d = 0; d < 4; ++d) {
                         float x[2];
                         const int co = lane & 31, hh = lane >> 5;
                         for (int e = 0; e < 2; ++e) {
-                            const int q = 8 * st + 2 * d + e;
-                            float v = 0.f;
-                            if (hh == 0) { if (q < 9) v = tapw(co, 0, q); else if (q < 14) v = tapw(co, 1, q - 9); }
-                            else { if (q < 9) v = tapw(co, 2, q); else if (q < 13) v = tapw(co, 1, q - 4); }
+                            const int slot = 2 * d + e, qd = slot >> 2, ci = slot & 3;
+                            const int ky = quad_tap[hh][st][qd][0], kx = quad_tap[hh][st][qd][1];
+                            const float v = (ky >= 0 && ci < 3) ? tapw(co, ky, kx, ci) : 0.f;
                             x[e] = v * (1.0f / 128.0f) * S;           // powers of two: exact
                         }
                         const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
@@ -1705,15 +1709,74 @@ int syn_check_constants_host(const void *host_blob, size_t bytes) {
     return check_const_header(hd, bytes, "syn_check_constants_host");
 }
 
+// ---- the broadcast itself, for a caller without torch.distributed (syn_bcast_constants(h, ncclComm_t, root, stream)) ----
+// The communicator belongs to the caller's RCCL instance, so this library must call THAT instance: nothing is linked; the three entry
+// points are resolved at the first call from what the process already holds (global scope, then librccl.so.1 as loaded by the caller
+// or by torch -- RTLD_NOLOAD finds a library whatever scope it was loaded into), and only then from the ROCm installation.
+namespace {
+struct RcclApi {
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclBroadcast
+    int (*CommUserRank)(void *, int *) = nullptr;                                                 // ncclCommUserRank
+    const char *(*GetErrorString)(int) = nullptr;                                                 // ncclGetErrorString
+    bool ok = false;
+};
+const RcclApi &rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        void *cands[4] = {RTLD_DEFAULT, dlopen("librccl.so.1", RTLD_LAZY | RTLD_NOLOAD), dlopen("librccl.so", RTLD_LAZY | RTLD_NOLOAD), nullptr};
+        for (int i = 0; i < 4 && !a.ok; ++i) {
+            void *lib = i < 3 ? cands[i] : dlopen("librccl.so.1", RTLD_LAZY | RTLD_GLOBAL);
+            if (i > 0 && !lib) continue;
+            a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(lib, "ncclBroadcast"));
+            a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
+            a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+            a.ok = a.Broadcast && a.CommUserRank && a.GetErrorString;
+        }
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
+int syn_bcast_constants(syn_handle *h, void *nccl_comm, int root, void *stream) {
+    if (!h) return fail(SYN_ERR_INVALID, "syn_bcast_constants: NULL handle");
+    if (!nccl_comm) return fail(SYN_ERR_INVALID, "syn_bcast_constants: NULL communicator");
+    if (root < 0) return fail(SYN_ERR_INVALID, "syn_bcast_constants: root %d", root);
+    const RcclApi &R = rccl_api();
+    if (!R.ok) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: no RCCL in this process (ncclBroadcast / ncclCommUserRank not found, librccl.so.1 not loadable)");
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    int rank = -1;
+    if (int e = R.CommUserRank(nccl_comm, &rank)) return fail(SYN_ERR_HIP, "syn_bcast_constants: ncclCommUserRank: %s", R.GetErrorString(e));
+    // two collectives, both on device memory: the blob's size (a replica that has loaded nothing cannot know it), then the blob
+    unsigned long long n_host = rank == root ? (unsigned long long)syn_constants_bytes(h) : 0ull, *n_dev = nullptr;
+    if (rank == root && !h->d_backbone && !h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: the root handle has loaded nothing");
+    HIP_TRY(hipMalloc((void **)&n_dev, 256));
+    char *blob = nullptr;
+    int rc = SYN_OK;
+    auto finish = [&](int code) { if (n_dev) (void)hipFree(n_dev); if (blob) (void)hipFree(blob); return code; };
+    if (hipMemcpyAsync(n_dev, &n_host, sizeof n_host, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: staging the size failed"));
+    if (int e = R.Broadcast(n_dev, n_dev, sizeof n_host, 1 /*ncclUint8*/, root, nccl_comm, s))
+        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: ncclBroadcast(size): %s", R.GetErrorString(e)));
+    if (hipMemcpyAsync(&n_host, n_dev, sizeof n_host, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: reading the size back failed"));
+    if (n_host < sizeof(ConstHeader) || n_host > (1ull << 34)) return finish(fail(SYN_ERR_INVALID, "syn_bcast_constants: implausible blob size %llu", n_host));
+    if (hipMalloc((void **)&blob, n_host) != hipSuccess) return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: %llu bytes of staging", n_host));
+    if (rank == root && (rc = syn_export_constants(h, blob, n_host, stream))) return finish(rc);
+    if (int e = R.Broadcast(blob, blob, n_host, 1 /*ncclUint8*/, root, nccl_comm, s))
+        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: ncclBroadcast(%llu bytes): %s", n_host, R.GetErrorString(e)));
+    if (rank != root && (rc = syn_import_constants(h, blob, n_host, stream))) return finish(rc);
+    if (hipStreamSynchronize(s) != hipSuccess) return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: stream synchronisation failed"));
+    return finish(SYN_OK);
+}
+
 size_t syn_constants_bytes(syn_handle *h) {
     if (!h) return 0;
     return sizeof(ConstHeader) + ((h->d_backbone ? backbone_floats(h->arch) : 0) + (h->d_basis ? h->basis_floats : 0)) * sizeof(float);
 }
 
-int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream) {
-    if (!h || !dev_dst) return fail(SYN_ERR_INVALID, "syn_export_constants: NULL argument");
-    const size_t need = syn_constants_bytes(h);
-    if (bytes < need) return fail(SYN_ERR_INVALID, "syn_export_constants: buffer %zu < %zu bytes", bytes, need);
+static ConstHeader make_const_header(syn_handle *h) {
     ConstHeader hd{};
     hd.magic = kMagic; hd.version = kConstVersion;
     hd.has_backbone = h->d_backbone ? 1 : 0; hd.has_basis = h->d_basis ? 1 : 0;
@@ -1721,7 +1784,23 @@ int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *strea
     hd.arch = h->arch;
     hd.backbone_floats = hd.has_backbone ? backbone_floats(h->arch) : 0;
     hd.basis_floats = hd.has_basis ? h->basis_floats : 0;
-    hd.total_bytes = need;
+    hd.total_bytes = syn_constants_bytes(h);
+    return hd;
+}
+
+int syn_describe_constants(syn_handle *h, void *host_header, size_t bytes) {
+    if (!h || !host_header) return fail(SYN_ERR_INVALID, "syn_describe_constants: NULL argument");
+    if (bytes < sizeof(ConstHeader)) return fail(SYN_ERR_INVALID, "syn_describe_constants: %zu bytes is smaller than the header (%zu)", bytes, sizeof(ConstHeader));
+    const ConstHeader hd = make_const_header(h);
+    memcpy(host_header, &hd, sizeof hd);
+    return SYN_OK;
+}
+
+int syn_export_constants(syn_handle *h, void *dev_dst, size_t bytes, void *stream) {
+    if (!h || !dev_dst) return fail(SYN_ERR_INVALID, "syn_export_constants: NULL argument");
+    const size_t need = syn_constants_bytes(h);
+    if (bytes < need) return fail(SYN_ERR_INVALID, "syn_export_constants: buffer %zu < %zu bytes", bytes, need);
+    ConstHeader hd = make_const_header(h);
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)stream;
     char *d = (char *)dev_dst;

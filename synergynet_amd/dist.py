@@ -42,6 +42,19 @@ def broadcast_constants(model, src: int = 0, group=None):
     return int(n.item())
 
 
+def broadcast_constants_rccl(model, nccl_comm: int, root: int = 0):
+    """The same hand-off through the library's own collective (include/synergy_hip.h syn_bcast_constants): `nccl_comm` is the
+    address of an ncclComm_t of the RCCL instance this process holds (a C host's, or one made through ctypes on torch's
+    librccl.so.1); every rank calls it, rank `root` is the one that loaded.  For hosts without torch.distributed."""
+    import ctypes as C
+
+    from . import abi
+    with torch.cuda.device(model.device):
+        s = torch.cuda.current_stream(model.device).cuda_stream
+        abi.check(abi.lib().syn_bcast_constants(model._h, C.c_void_p(nccl_comm), int(root), C.c_void_p(s)))
+    model._after_import()
+
+
 def pack_constants_host(pack=None, backbone_state=None, arch: str = 'mobilenet_v2', data_dir=None):
     """The constants blob of `SynergyNet(...).export_constants()` built WITHOUT a device (syn_pack_constants_host): a uint8
     numpy array [header 256 B | folded backbone | MFMA-ordered basis], byte-identical to the device export after the same

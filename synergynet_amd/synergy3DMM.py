@@ -43,7 +43,7 @@ def parse_param_62(param):
 
 
 _HDR_MAGIC = 0x53594e4833353558          # "SYNH355X" (csrc/synergy_abi.hip ConstHeader)
-_HDR_VERSION = 2                         # kConstVersion: bumped whenever the packed encoding changes
+_HDR_VERSION = 3                         # kConstVersion: bumped whenever the packed encoding changes
 
 
 def parse_constants_header(raw: bytes) -> dict:
@@ -353,6 +353,15 @@ class SynergyNet(nn.Module):
         hdr = parse_constants_header(buf[:256].cpu().numpy().tobytes())
         abi.check(self._lib.syn_import_constants(self._h, buf.data_ptr(), buf.numel(), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()
+        self._follow_constants(hdr)
+
+    def _after_import(self):
+        """The C handle has imported constants on its own (syn_bcast_constants): read back what it holds now."""
+        raw = C.create_string_buffer(256)
+        abi.check(self._lib.syn_describe_constants(self._h, raw, 256))
+        self._follow_constants(parse_constants_header(raw.raw))
+
+    def _follow_constants(self, hdr):
         if hdr['has_backbone']:
             # the blob decides which backbone the C handle now runs: follow it, or pool buffers would be sized for the wrong one
             self.arch = ('mobilenet_v2', 'resnet50')[hdr['arch']]

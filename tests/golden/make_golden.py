@@ -396,6 +396,37 @@ def main_evaluate():
     print('wrote', path, nme.shape, stats)
 
 
+def main_write_obj():
+    """The reference's own write_obj (utils/inference.py:8-23) on a seeded mesh: the bytes of the file it writes."""
+    import tempfile
+    pack = synth.make_3dmm(SEED_3DMM)
+    sd = synth.make_backbone_state(SEED_W)
+    ref_loader.build_reference_model(pack, sd)
+    inf = ref_loader._REF_MODULES['utils.inference']
+    rng = np.random.default_rng(77)
+    nv, nt = 2500, 4100
+    # magnitudes of a posed mesh in image space, values that round at the fourth decimal, negative zero, exact halves
+    vert = (rng.standard_normal((3, nv)) * np.array([[60.0], [60.0], [40.0]]) + np.array([[60.0], [60.0], [0.0]])).astype(np.float32)
+    vert[:, :6] = np.array([[0.00005, -0.00005, 0.12345, -0.0, 1e-7, 119.99995], [0.5, -2.5, 1234.56785, 0.0, -1e-7, 3.00005],
+                            [1e5, -1e5, 0.99995, -0.99995, 2.00015, 7.0]], dtype=np.float32)
+    tri = rng.integers(1, nv + 1, size=(3, nt)).astype(np.int32)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, arg in (('plain', 'mesh'), ('with_ext', 'mesh2.obj')):
+            cwd = os.getcwd()
+            os.chdir(td)
+            try:
+                inf.write_obj(arg, vert, tri)
+            finally:
+                os.chdir(cwd)
+            fn = arg if arg.endswith('.obj') else arg + '.obj'
+            out['bytes_' + name] = np.frombuffer(open(os.path.join(td, fn), 'rb').read(), dtype=np.uint8)
+            out['name_' + name] = np.array(fn)
+    path = os.path.join(HERE, 'write_obj_golden.npz')
+    np.savez_compressed(path, vertices=vert, triangles=tri, **out)
+    print('wrote', path, out['bytes_plain'].size, 'bytes of OBJ')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                      # python make_golden.py main_pose_mat main_faceboxes_real ...: only those fixtures
         for name in sys.argv[1:]:
@@ -408,3 +439,4 @@ if __name__ == '__main__':
     main_faceboxes()
     main_faceboxes_real()
     main_evaluate()
+    main_write_obj()

@@ -430,6 +430,39 @@ def test_constants_export_import_roundtrip(model, golden):
         other.import_constants(buf[:buf.numel() - 64].contiguous())          # truncated blob: refused, nothing read past the end
 
 
+def test_bcast_constants_through_the_c_abi_on_a_single_rank_communicator(model):
+    """syn_bcast_constants: the library's own RCCL collective, for hosts without torch.distributed.  A 1-GPU box can hold
+    one rank only (RCCL refuses duplicate devices), so this drives the ROOT leg on hardware -- run-time resolution of the process's
+    RCCL, ncclCommUserRank, both ncclBroadcast calls, the export -- through a communicator made with ctypes on the librccl.so.1 torch
+    ships; the import leg is syn_import_constants (test above) and the N > 1 plumbing tests/test_dist_cpu.py."""
+    import ctypes as C
+    import glob
+    import torch
+    from synergynet_amd import abi, dist
+    libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so*')) + ['/opt/rocm/lib/librccl.so.1']
+    rccl = C.CDLL(libs[0], mode=C.RTLD_GLOBAL)
+    uid = C.create_string_buffer(128)
+    assert rccl.ncclGetUniqueId(uid) == 0
+
+    class Uid(C.Structure):
+        _fields_ = [('b', C.c_char * 128)]
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    with torch.cuda.device(0):
+        assert rccl.ncclCommInitRank(C.byref(comm), 1, Uid.from_buffer_copy(uid.raw), 0) == 0
+        try:
+            before = model.forward_crops_u8(np.zeros((3, 120, 120, 3), np.uint8) + 7).clone()
+            dist.broadcast_constants_rccl(model, comm.value, root=0)
+            assert model._have_backbone and model._have_basis and model.arch == 'mobilenet_v2'
+            assert torch.equal(model.forward_crops_u8(np.zeros((3, 120, 120, 3), np.uint8) + 7), before)
+            lib = abi.lib()
+            assert lib.syn_bcast_constants(model._h, None, 0, None) == -1 and b'NULL communicator' in lib.syn_last_error()
+            assert lib.syn_bcast_constants(model._h, comm, -1, None) == -1
+        finally:
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            rccl.ncclCommDestroy(comm)
+
+
 def test_import_constants_follows_the_blobs_arch(resnet_model):
     """A rank built with the default arch and no assets that receives a ResNet-50 blob becomes a ResNet-50 replica: `arch` and
     the pooled-feature width follow the header (a 1280-wide buffer under a 2048-wide kernel write would be out of bounds)."""

@@ -312,3 +312,37 @@ def test_hot_loops_never_drain_their_loads_in_flight():
                 for x, y in zip(seq, seq[1:]):
                     assert not (x == 'L' and y.startswith('w') and int(y[1:]) <= 1), f'{name}: a wait right behind a load: {" ".join(seq)}'
                 assert any(t.startswith('w') and int(t[1:]) >= 6 for t in seq), f'{name}: no counted wait (loads in flight across steps) left: {" ".join(seq)}'
+
+
+def test_write_obj_files_are_byte_identical_to_the_reference(tmp_path):
+    """`write_obj` (reference utils/inference.py:8-23).  Golden = the bytes the reference's OWN function wrote for
+    a seeded mesh (tests/golden/make_golden.py main_write_obj): values that round at the fourth decimal, negative zero, 1e5."""
+    from synergynet_amd.inference import write_obj
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'write_obj_golden.npz'))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        write_obj('mesh', g['vertices'], g['triangles'])                 # '.obj' is appended
+        write_obj('mesh2.obj', g['vertices'], g['triangles'])            # ... only where it is missing
+        write_obj('empty', g['vertices'][:, :0], g['triangles'][:, :0])
+    finally:
+        os.chdir(cwd)
+    assert str(g['name_plain']) == 'mesh.obj' and open(tmp_path / 'mesh.obj', 'rb').read() == g['bytes_plain'].tobytes()
+    assert open(tmp_path / 'mesh2.obj', 'rb').read() == g['bytes_with_ext'].tobytes()
+    assert open(tmp_path / 'empty.obj', 'rb').read() == b''
+    # float-typed triangle indices print their repr in the reference ('{}'.format): kept
+    write_obj(str(tmp_path / 'f'), g['vertices'][:, :2], np.array([[1.0], [2.0], [1.0]]))
+    assert open(tmp_path / 'f.obj').read().splitlines()[-1] == 'f 1.0 2.0 1.0'
+
+
+def test_bcast_constants_rejects_null_arguments_without_a_device():
+    """syn_bcast_constants exists in the C ABI and refuses NULL arguments before touching RCCL or HIP."""
+    from synergynet_amd.build import build_library
+    lib = ctypes.CDLL(build_library())
+    lib.syn_last_error.restype = ctypes.c_char_p
+    lib.syn_bcast_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    assert lib.syn_bcast_constants(None, None, 0, None) == -1
+    assert b'syn_bcast_constants' in lib.syn_last_error()
+    hdr = ctypes.create_string_buffer(256)
+    lib.syn_describe_constants.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    assert lib.syn_describe_constants(None, hdr, 256) == -1
