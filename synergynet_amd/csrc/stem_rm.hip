@@ -52,6 +52,13 @@ __device__ __forceinline__ float left_of(float v) {
 __device__ __forceinline__ float right_of(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
 }
+// ReLU6 without an instruction of its own (tools/ubench/valu_issue.hip: v_med3_f32 costs 1.85 ns of a SIMD, a plain fp32 multiply or FMA
+// 1.25): activations are carried as relu6(x) / 6 in [0, 1], which is what the `clamp` output modifier produces -- on the multiply that
+// rescales the expand accumulator, and on the LAST FMA of a depthwise accumulator; the 6 rides on constants that are applied anyway.
+// (written as med3(x, 0, 1) of the product: the compiler folds that into the producer's clamp bit -- and, unlike for inline assembly,
+// keeps the wait states a vector instruction needs behind the matrix instruction whose result it reads)
+__device__ __forceinline__ float mul_clamp01(float a, float b) { return __builtin_amdgcn_fmed3f(a * b, 0.0f, 1.0f); }
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) { return __builtin_amdgcn_fmed3f(__builtin_fmaf(a, b, c), 0.0f, 1.0f); }
 constexpr int kImgW = 120, kHid = 60;
 constexpr int kRowDw = 244;               // dwords per image-row slot: 122 pixels x (R, G, B, -) fp16; pixel t = image column t - 1 (t = 0: left padding)
 constexpr int kSlots = 8;                 // image-row ring per unit
@@ -82,9 +89,12 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     constexpr int DSH = 9 * 32;
     // power-of-two scales of the fp16 weight pieces: stem accumulators start at Ss x shift, ReLU6 clamps at 6 Ss, the depthwise filter
     // carries 1 / Ss; the projection starts at Sp x shift and is rescaled before the store
-    const float Ss = s_shift[32], inv_ss = s_shift[33], c6s = s_shift[34], Sp = scl_p[0], inv_sp = scl_p[1];
-    for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i] * inv_ss;
-    if (tid < 32) { Filt[DSH + tid] = d_shift[tid]; Ssh[tid] = s_shift[tid] * Ss; Psh[tid] = tid < 16 ? p_shift[tid] * Sp : 0.f; }
+    // stem output e' = relu6(.) / 6 = clamp(acc / (6 Ss)); depthwise d' = relu6(d) / 6 = clamp(sum e' Wd + shift / 6): the filter is the
+    // plain one; the projection contracts d' and its accumulator (started at Sp shift / 6) is rescaled by 6 / Sp before the store
+    const float Ss = s_shift[32], c6s = s_shift[34], Sp = scl_p[0], inv_sp6 = 6.0f * scl_p[1];
+    const float inv_c6s = 1.0f / c6s;
+    for (int i = tid; i < 9 * 32; i += C::NT) Filt[i] = Wd[i];
+    if (tid < 32) { Filt[DSH + tid] = d_shift[tid] * (1.0f / 6.0f); Ssh[tid] = s_shift[tid] * Ss; Psh[tid] = tid < 16 ? p_shift[tid] * Sp * (1.0f / 6.0f) : 0.f; }
     // padding row (image row -1), the left padding pixel, the fourth element of every pixel and the tails of every ring slot: 127.5
     // everywhere, then the service wave only ever rewrites pixels 1 .. 120
     for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadF16 | (kPadF16 << 16);
@@ -186,11 +196,11 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
 
     for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
         const int f = fb + uw;
-        const float ehi = (col_ok && f < B) ? c6s : 0.0f;
+        const float emul = (col_ok && f < B) ? inv_c6s : 0.0f;        // 0 on the out-of-image lanes: the depthwise zero padding
         const bool st_ok = out_lane && f < B;
         const int yofs = (30 * c + j - 1) * 16 + 4 * h;             // (column, channel quad) inside an output row; < 2^31 elements per face
 
-        auto finalize = [&](f32x16 &d, int oy) {
+        auto finalize = [&](f32x16 &d, int oy, bool clamped = true) {
             const int cbo = opaque_cb();
             f32x16 acc;
 #pragma unroll
@@ -204,7 +214,9 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
                 u32x4 db[2];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
+                    // (clamped by the FMA that completed the row; the last image row has no row below it to do so)
+                    const float v0 = clamped ? d[8 * s + 2 * t] : __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 1.0f);
+                    const float v1 = clamped ? d[8 * s + 2 * t + 1] : __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 1.0f);
                     unsigned ha, hb;
                     split2s(v0, v1, ha, hb);
                     db[0][t] = ha; db[1][t] = hb;
@@ -215,18 +227,19 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             }
             if (st_ok) {
                 float *dst = Y + ((size_t)f * kHid + oy) * kHid * 16 + yofs;
-                *(f32x4 *)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]} * inv_sp;              // channels 4h .. 4h+3
-                *(f32x4 *)(dst + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]} * inv_sp;        // channels 8 + 4h ..
+                *(f32x4 *)dst = (f32x4){acc[0], acc[1], acc[2], acc[3]} * inv_sp6;             // channels 4h .. 4h+3
+                *(f32x4 *)(dst + 8) = (f32x4){acc[4], acc[5], acc[6], acc[7]} * inv_sp6;       // channels 8 + 4h ..
             }
         };
-        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init, bool last = false) {
             const f32x4 w0 = *(const f32x4 *)(wq + (3 * ky + 0) * 32), w1 = *(const f32x4 *)(wq + (3 * ky + 1) * 32), w2 = *(const f32x4 *)(wq + (3 * ky + 2) * 32);
             f32x4 base;
             if (init) base = *(const f32x4 *)(wq + DSH);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float b0 = init ? base[t] : d[4 * q + t];
-                d[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0)));
+                const float p2 = __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0));
+                d[4 * q + t] = last ? fma_clamp01(r4[t], w2[t], p2) : __builtin_fmaf(r4[t], w2[t], p2);     // last: the row is complete -> ReLU6 (as [0, 1])
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
@@ -274,7 +287,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
                 e = mfma32s(as[s][0], xb[s], e);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehi);
+            for (int r = 0; r < 16; ++r) e[r] = mul_clamp01(e[r], emul);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 c4, l4, r4;
@@ -283,7 +296,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
                 const float *wq = Filt + cbo + 8 * q;
                 taps3(dn, q, wq, 0, l4, c4, r4, true);
                 taps3(dc, q, wq, 1, l4, c4, r4, false);
-                taps3(dm, q, wq, 2, l4, c4, r4, false);
+                taps3(dm, q, wq, 2, l4, c4, r4, false, true);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (hy >= 1) finalize(dm, hy - 1);
@@ -294,7 +307,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             step(hy + 1, d0, d1, d2);
             step(hy + 2, d1, d2, d0);
         }
-        finalize(d2, kHid - 1);              // (60 - 1) % 3 == 2
+        finalize(d2, kHid - 1, false);       // (60 - 1) % 3 == 2
     }
 }
 
