@@ -341,6 +341,25 @@ def per_rank_report(dist, rank, world, own_rate, numa, dev):
 
 
 # ------------------------------------------------------------------------------------------------ timing helpers
+def _recon_rocprof():
+    """(average ms of syn::recon_f16_kernel<4, true, ...> in the newest committed one-stream kernel-stats bundle, its path) -- a second,
+    dispatch-free measurement of the kernel extra.reconstruction_alone.kernel times with HIP events."""
+    import csv
+    for rnd in ('r4', 'r3'):
+        fp = os.path.join(ROOT, 'profiles', rnd, 'kernel_stats_b1024_one_stream.csv')
+        if os.path.isfile(fp):
+            try:
+                for row in csv.DictReader(open(fp)):
+                    if 'recon_f16_kernel<4, true' in row['Name']:
+                        return round(float(row['AverageNs']) * 1e-6, 4), 'profiles/%s/kernel_stats_b1024_one_stream.csv' % rnd
+            except Exception:
+                pass
+    return None, None
+
+
+RECON_ROCPROF = _recon_rocprof()
+
+
 def time_steps(fn, steps, warmup, sync):
     for _ in range(warmup):
         fn()
@@ -552,14 +571,24 @@ def main():
         # HBM bytes / MFMA-pipe occupancy come from rocprofv3 --pmc passes of THIS command taken in separate runs (tools/round_profile.sh ->
         # tools/make_profiles.py -> profiles/traffic_rN.json).  They are NOT measured by this run: counters_source says which file,
         # which commit and which box they are from, so a reader can tell a stale bundle from a fresh one.
-        traffic = pipe_busy = counters_source = None
-        for name in ('traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
+        traffic = pipe_busy = counters_source = traffic_fwd = None
+        for name in ('traffic_r4.json', 'traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
             tfp = os.path.join(ROOT, 'profiles', name)
             if os.path.isfile(tfp) and B == 1024:
                 try:
                     tj = json.load(open(tfp))
                     traffic = tj.get('fused_block_bytes_per_launch')
                     pipe_busy = tj.get('fused_block_mfma_pipe_busy')
+                    # the whole forward (stem + family + head), read + written, per 1024-face forward -- the figure to hold against the
+                    # compulsory bytes of the path (43.2 KB of uint8 crop in, 62 parameters out per face)
+                    pk_ = tj.get('per_kernel')
+                    pk_ = pk_.items() if isinstance(pk_, dict) else pk_
+                    fam_b = tj.get('fused_block_bytes_per_forward') or {}
+                    one = [v for k_, v in pk_ if 'stem_rm_kernel' in k_ or 'head_f16x2_kernel' in k_]      # one launch per forward each
+                    rd = fam_b.get('read', 0) + sum(v.get('read_bytes', 0) for v in one)
+                    wr = fam_b.get('write', 0) + sum(v.get('write_bytes', 0) for v in one)
+                    if rd and wr:
+                        traffic_fwd = dict(read=round(rd), write=round(wr))
                     counters_source = dict(file='profiles/' + name, commit=tj.get('commit'), box=tj.get('box'), collected=tj.get('collected'),
                                            measured_by_this_run=False,
                                            fields=['roofline.traffic', 'roofline.mfma_pipe_busy'])
@@ -575,7 +604,16 @@ def main():
                            f'results on v_mfma_f32_{{32x32x16,16x16x32}}_f16 with every operand as two fp16 pieces (3 MFMAs per block product): '
                            f'algorithmic fp32 FLOPs priced against the dense fp16 MFMA peak / 3',
                     achieved=round(achieved, 3), peak=round(ceiling, 1), unit='TFLOP/s',
-                    frac=round(achieved / ceiling, 4), traffic=traffic, counters_source=counters_source,
+                    frac=round(achieved / ceiling, 4), traffic=traffic,
+                    traffic_unit=f'HBM bytes (read + written) per LAUNCH of the family, average over its {len(fam)} launches -- the unit of '
+                                 f'`achieved` (x {len(fam)} = the family per forward); the whole forward is backbone_traffic',
+                    backbone_traffic=None if traffic_fwd is None else dict(
+                        bytes_per_forward=traffic_fwd, faces=B,
+                        algorithmic_bytes_per_forward=B * (120 * 120 * 3 + 62 * 4),
+                        ratio=round((traffic_fwd['read'] + traffic_fwd['write']) / (B * (120 * 120 * 3 + 62 * 4)), 1),
+                        what='stem + fused blocks + head, all launches of one 1024-face forward; algorithmic = the uint8 crops in and the '
+                             '62 parameters out (SURVEY 8d); the excess is the fp32 block-boundary activations of the 60x60 / 30x30 / 15x15 stages'),
+                    counters_source=counters_source,
                     # what the pipe sees: 3 fp16 MFMAs per fp32 block product; mfma_pipe_busy is the same share of the pipe from
                     # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE (profiles/, separate PMC run).  Matrix and vector instructions of the waves of
                     # a SIMD do not overlap (tools/ubench/mfma_valu_kinds.hip), so frac = t_mfma / (t_mfma + t_valu + t_exposed).
@@ -620,6 +658,8 @@ def main():
             extra['fp32_ingest_packed_output_one_stream'] = dict(rate(B, ref_api_step, steps=10, warmup=2),
                                                                  what='forward_test(fp32 [B,3,120,120]) + reconstruct into the packed [B,3,53215] layout '
                                                                       '(synergy3DMM.py:131-147), one stream: the step exactly as the reference API shapes it')
+            # first-class alias: what a caller of the reference's own entry points gets, next to the headline `value` (uint8 crops, pitched rows, two replicas)
+            extra['reference_api_step'] = dict(extra['fp32_ingest_packed_output_one_stream'], same_as='fp32_ingest_packed_output_one_stream')
             pk = OverlappedPipeline(model, overlap=bool(args.overlap), rec_priority=args.rec_priority)
             extra['packed_output'] = rate(B, lambda: pk.submit(crops, rois, lmk_out=lmk, mesh_out=packed), steps=10, warmup=2)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -645,8 +685,13 @@ def main():
                                                  packed_ms=round(t_pack, 4), packed_tb_s=round(mesh_bytes / t_pack / 1e9, 3),
                                                  mesh_bytes=mesh_bytes, peak_tb_s=PEAK_HBM_GBS / 1e3,
                                                  what='pitched_ms / packed_ms: one reconstruct() call = prologue kernel + contraction kernel + the launch '
-                                                      'bubbles between dependent kernels, back to back; kernel: the contraction kernel alone (HIP events in the library)',
+                                                      'bubbles between dependent kernels, back to back; kernel: the contraction kernel alone, event to event',
                                                  kernel=dict(bound='hbm', name='syn::recon_f16_kernel', ms=round(k_main, 4), prologue_ms=round(k_prep, 4),
+                                                             timing='HIP events recorded by the library around the launch (syn_reconstruct_profile): INCLUDES the dispatch '
+                                                                    'latency of the launch, i.e. an upper bound of the kernel time; the rocprofv3 kernel-trace average of the '
+                                                                    'same kernel is rocprof_ms (from the committed bundle named in rocprof_source, another box / run)',
+                                                             rocprof_ms=RECON_ROCPROF[0], rocprof_source=RECON_ROCPROF[1],
+                                                             rocprof_tb_s=None if RECON_ROCPROF[0] is None else round(mesh_bytes / RECON_ROCPROF[0] / 1e9, 3),
                                                              achieved=round(mesh_bytes / k_main / 1e6, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                                              frac=round(mesh_bytes / k_main / 1e6 / PEAK_HBM_GBS, 4)))
             extra['fp32_ingest_backbone_ms'] = round(ev_ms(lambda: model.forward_test(xf), 5), 4)

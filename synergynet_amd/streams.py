@@ -100,8 +100,9 @@ class ReplicaRing:
             pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
             done.record(st)
-        for t in (crops_u8, rois):
-            t.record_stream(st)
+        for t in (crops_u8, rois):              # (numpy inputs / roi=None are staged by the calls above into tensors of their own)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
         return param, lmk, mesh, pose, done
 
     def wait(self):

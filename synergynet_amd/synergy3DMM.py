@@ -590,7 +590,18 @@ class SynergyNet(nn.Module):
         (tests/test_host_cpu.py::test_face_tables_equal_the_per_face_arithmetic).  The detection lists are mutated into the ROI as before."""
         from .inference import lanczos4_tables
         flat = [r for fr in rects for r in fr]
-        d = np.array([r[:5] for r in flat], dtype=np.float64).reshape(n, 5)
+        # the scalar statement computes in the type of the detections' elements: Python floats / float64 -> double, numpy float32 scalars
+        # (what FaceBoxes returns, here and in the reference) -> float32 (NumPy 2: `np.float32 * 1.2` stays float32).  The array form
+        # follows suit; anything mixed goes through the scalar statement itself (ADVICE r3: all-double arithmetic moved 1 crop box in 10^4
+        # by a pixel for float32 detections)
+        kinds = {type(x) for r in flat for x in r[:4]}
+        if kinds <= {np.float32}:
+            dt = np.float32
+        elif kinds <= {float, int, np.float64}:
+            dt = np.float64
+        else:
+            return SynergyNet._face_tables_scalar(flat, n)
+        d = np.array([r[:5] for r in flat], dtype=dt).reshape(n, 5)
         hc = (d[:, 1] + d[:, 3]) / 2
         wc = (d[:, 0] + d[:, 2]) / 2
         margin = np.floor_divide((d[:, 3] - d[:, 1]) * 1.2, 2)
@@ -602,10 +613,23 @@ class SynergyNet(nn.Module):
         w, h = box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]
         if np.any(w <= 0) or np.any(h <= 0):
             raise ValueError('degenerate detection box')
-        vals = r4.tolist()
+        vals = r4.tolist() if dt is np.float64 else [list(v) for v in r4]      # (float32 detections keep float32 scalars, as the scalar statement does)
         for r, v in zip(flat, vals):
             r[0], r[1], r[2], r[3] = v
         roi = np.concatenate([r4, d[:, 4:5]], axis=1).astype(np.float32)
+        return SynergyNet._tap_tables(roi, box, w, h, n)
+
+    @staticmethod
+    def _face_tables_scalar(flat, n):
+        """_face_tables for detections of mixed element types: the scalar statement (_roi_and_box) per face."""
+        rb = [SynergyNet._roi_and_box(None, r) for r in flat]
+        roi = np.array([x[0] for x in rb], dtype=np.float32).reshape(n, 5)
+        box = np.array([x[1] for x in rb], dtype=np.int32).reshape(n, 4)
+        return SynergyNet._tap_tables(roi, box, box[:, 2] - box[:, 0], box[:, 3] - box[:, 1], n)
+
+    @staticmethod
+    def _tap_tables(roi, box, w, h, n):
+        from .inference import lanczos4_tables
         sides, inv = np.unique(np.concatenate([w, h]), return_inverse=True)
         tabs = [lanczos4_tables(int(sd)) for sd in sides]
         o_u = np.stack([t[0] for t in tabs])

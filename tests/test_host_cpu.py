@@ -260,6 +260,25 @@ def test_face_tables_equal_the_per_face_arithmetic():
     assert rects == want_rects
     with pytest.raises(ValueError):
         SynergyNet._face_tables([[[10.0, 10.0, 20.0, 10.2, 0.9]]], 1)
+    # detections as numpy float32 scalars (what FaceBoxes returns, here and in the reference): the scalar statement then computes in
+    # float32 (the array form in double moved the ROI by an ulp in a third of the cases, a crop box by a pixel in 1 of 10^4);
+    # and mixed element types go through the scalar statement itself
+    for mode in ('f32', 'mixed'):
+        rng = np.random.default_rng(11)
+        r32 = []
+        for i in range(4000):
+            x, y, s_ = rng.uniform(-40, 400), rng.uniform(-40, 300), rng.uniform(20, 260)
+            v = [np.float32(x), np.float32(y), np.float32(x + s_), np.float32(y + s_ * rng.uniform(0.9, 1.2)), np.float32(rng.uniform(0.5, 1))]
+            if mode == 'mixed' and i % 3 == 0:
+                v[2] = float(v[2])
+            r32.append(v)
+        want32 = copy.deepcopy(r32)
+        wroi = np.empty((len(r32), 5), np.float32); wbox = np.empty((len(r32), 4), np.int32)
+        for k, rect in enumerate(want32):
+            wroi[k], wbox[k] = SynergyNet._roi_and_box(None, rect)
+        groi, gbox, _, _ = SynergyNet._face_tables([r32], len(r32))
+        assert np.array_equal(groi, wroi) and np.array_equal(gbox, wbox), mode
+        assert all(type(a) is type(b) and a == b for ra, rb in zip(r32, want32) for a, b in zip(ra, rb)), mode
 
 
 def test_frame_chunks_partition_the_call():
