@@ -19,7 +19,7 @@
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
 //   * ONE service wave per workgroup keeps the image rows of all units flowing: buffer loads one stage ahead (counted vmcnt, no
 //     branches) -> fp16 -> LDS row ring (8 slots per unit), one barrier per output row.
-// fp32 crops (forward_test) keep the tiled kernel of stem_block1.hip: arbitrary floats need the 3-way split on both sides.
+// fp32 crops (forward_test): the F32 instantiation below (round 4); the tiled kernel of stem_block1.hip serves small batches.
 #include "syn_internal.h"
 
 #include <cstdlib>
@@ -65,18 +65,26 @@ constexpr int kSlots = 8;                 // image-row ring per unit
 constexpr unsigned kPadF16 = 0x57F8u;     // 127.5 as fp16: the raw value of a zero in normalised space
 }  // namespace
 
-template <int U_, int WPE_>
+// F32 (round 4): normalised fp32 NCHW crops (forward_test, reference synergy3DMM.py:151-154) through the same march.  Arbitrary floats
+// need BOTH operands as two fp16 pieces (three products per k16 step instead of two): the service wave splits every value once and the
+// ring holds two planes per image row, high pieces | low pieces, in the same (R, G, B, -) pixel layout; the filter is the plain BN-folded
+// one (nothing to fold the normalisation into) and the padding value is 0.  Domain: |x| < 6e4 (the reference's own normalisation gives
+// [-1, 1]); replaces the spatially tiled bf16 x3 kernel of stem_block1.hip for batches that fill the chip.
+template <int U_, int WPE_, bool F32_ = false>
 struct StemRmCfg {
     static constexpr int U = U_, WPE = WPE_;                                  // faces (units) per workgroup
-    static constexpr int NCW = 2 * U, NT = (NCW + 1) * 64;         // compute waves (face, half) + one service wave
-    static constexpr int UNIT_DW = (kSlots + 1) * kRowDw;          // ring + one all-padding row (image row -1)
+    static constexpr bool F32 = F32_;
+    static constexpr int NSV = F32 ? 2 : 1;                        // service waves (F32: splitting 2 x 360 floats per face and step is two waves' work)
+    static constexpr int NCW = 2 * U, NT = (NCW + NSV) * 64;       // compute waves (face, half) + the service wave(s)
+    static constexpr int SLOT_DW = (F32 ? 2 : 1) * kRowDw;         // one image row: plane of high pieces | (F32) plane of low pieces
+    static constexpr int UNIT_DW = (kSlots + 1) * SLOT_DW;         // ring + one all-padding row (image row -1)
     static constexpr int LDS_DW = U * UNIT_DW + 10 * 32 + 32 + 32; // + depthwise filter 9x32 | depthwise shift | stem shift | project shift
     static_assert(NT <= 1024 && LDS_DW * 4 <= 160 * 1024, "workgroup size / LDS budget");
 };
 
 template <class C>
 __global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, 3)))
-void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[3][2][64][4]*/,
+void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32: float [B,3,120,120]*/, const unsigned *__restrict__ As3 /*[3][2][64][4]*/,
                     const float *__restrict__ s_shift /*[32] folded, then {S, 1/S, 6 S} of the stem filter*/, const float *__restrict__ Wd /*[9][32] scaled*/,
                     const float *__restrict__ d_shift, const unsigned *__restrict__ Ap3 /*[1][2][2][64][4]*/,
                     const float *__restrict__ p_shift /*[16]*/, const float *__restrict__ scl_p, float *__restrict__ Y /*[B,60,60,16]*/, int B) {
@@ -97,7 +105,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
     if (tid < 32) { Filt[DSH + tid] = d_shift[tid] * (1.0f / 6.0f); Ssh[tid] = s_shift[tid] * Ss; Psh[tid] = tid < 16 ? p_shift[tid] * Sp * (1.0f / 6.0f) : 0.f; }
     // padding row (image row -1), the left padding pixel, the fourth element of every pixel and the tails of every ring slot: 127.5
     // everywhere, then the service wave only ever rewrites pixels 1 .. 120
-    for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = kPadF16 | (kPadF16 << 16);
+    for (int i = tid; i < C::U * C::UNIT_DW; i += C::NT) smem[i] = C::F32 ? 0u : kPadF16 | (kPadF16 << 16);
     __syncthreads();
 
     if (service) {
@@ -109,6 +117,64 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
         // For the compiler to emit counted waits the loop body has no vector-memory branches: buffer loads whose out-of-range lanes
         // (faces past the batch, the surplus lanes of the last 64-lane round) return zeros, and the slot offsets are immediates
         // (four stages per loop iteration).
+        if constexpr (C::F32) {
+            // a work item = four pixels of one image row: R[4], G[4], B[4] from the three planes of the NCHW crop (16-byte loads)
+            constexpr int PER_ROW = kImgW / 4;                         // 30 items per image row
+            constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 64 * C::NSV - 1) / (64 * C::NSV);
+            constexpr unsigned ROW_B = kImgW * 4, PLANE_B = kImgW * ROW_B, FACE_B = 3 * PLANE_B;
+            const int sv = wave_wg - C::NCW;                               // the service waves deal the items 64 at a time
+            unsigned gofs[ITER], lofs[ITER];
+            bool live[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * (it * C::NSV + sv);
+                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                live[it] = i < TOTAL;
+                gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * ROW_B + 16 * d) : 0x80000000u;
+                lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 8 * d);        // pixel t = 1 + 4 d of the row slot
+            }
+            int ifb = blockIdx.x * C::U, ik = 0;
+            struct Px4 { f32x4 c[3]; };
+            auto issue = [&](Px4 (&v)[ITER]) {
+                // records = the group's faces inside the batch (the range check is on the lane offset, which names the face; plane and row ride
+                // in the scalar offset and stay inside that face)
+                long long left = ((long long)B - ifb) * (long long)FACE_B;
+                if (left > (long long)(C::U * FACE_B)) left = C::U * FACE_B;
+                const int nrec = left > 0 ? (int)left : 0;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img) + (size_t)ifb * FACE_B, 0, nrec, 0x00027000);
+#pragma unroll
+                for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        v[it].c[ch] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, gofs[it], ch * PLANE_B + ik * 2 * ROW_B, 0));
+                if (++ik == kHid) { ik = 0; ifb += gridDim.x * C::U; }
+            };
+            auto consume = [&](const Px4 (&v)[ITER], int slot) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        unsigned a_rg, b_rg, a_b, b_b;
+                        split2s(v[it].c[0][k], v[it].c[1][k], a_rg, b_rg);
+                        split2s(v[it].c[2][k], 0.0f, a_b, b_b);
+                        if (live[it]) { dst[k] = (u32x2){a_rg, a_b}; dst[kRowDw / 2 + k] = (u32x2){b_rg, b_b}; }
+                    }
+                }
+            };
+            Px4 va[ITER], vb[ITER];
+            issue(va);
+            for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
+                for (int k = 0; k < kHid; k += 4) {
+                    issue(vb); __builtin_amdgcn_sched_barrier(0); consume(va, 0); __syncthreads();
+                    issue(va); __builtin_amdgcn_sched_barrier(0); consume(vb, 2); __syncthreads();
+                    issue(vb); __builtin_amdgcn_sched_barrier(0); consume(va, 4); __syncthreads();
+                    issue(va); __builtin_amdgcn_sched_barrier(0); consume(vb, 6); __syncthreads();
+                }
+                __syncthreads();
+            }
+            return;
+        } else {
         constexpr int PER_ROW = kImgW / 8;                         // 15 lanes per image row: eight pixels = 24 bytes each
         constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
         constexpr unsigned FACE_B = kImgW * kImgW * 3, ROW2_B = 2 * kImgW * 3;
@@ -120,7 +186,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
             live[it] = i < TOTAL;
             gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * (kImgW * 3) + 24 * d) : 0x80000000u;
-            lofs[it] = (unsigned)(u * C::UNIT_DW + r * kRowDw + 2 + 16 * d);      // pixel t = 1 + 8 d of the row slot
+            lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 16 * d);      // pixel t = 1 + 8 d of the row slot
         }
         int ifb = blockIdx.x * C::U, ik = 0;                       // the stage `issue` requests next
         struct Px8 { u32x2 q[3]; };                                // 24 bytes = eight packed RGB pixels
@@ -142,7 +208,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const unsigned D[7] = {v[it].q[0][0], v[it].q[0][1], v[it].q[1][0], v[it].q[1][1], v[it].q[2][0], v[it].q[2][1], 0u};
-                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * kRowDw);
+                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // bytes 3k .. 3k+2 -> (R, G), (B, 0) as fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
@@ -170,6 +236,7 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             __syncthreads();                                   // ends compute step 59
         }
         return;
+        }
     }
 
     // ---- compute wave: half c of face (fb + uw) ----
@@ -261,19 +328,22 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
         auto step = [&](int hy, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
             const int cbo = opaque_cb();
             // ---- im2col B operand: image rows 2hy-1 (kernel row 0), 2hy, 2hy+1 from the ring; row -1 = the padding row ----
-            const unsigned *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * kRowDw + run0;
-            const unsigned *r1 = ring + ((2 * hy) & (kSlots - 1)) * kRowDw + run0;
-            const unsigned *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * kRowDw + run0;
+            const unsigned *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * C::SLOT_DW + run0;
+            const unsigned *r1 = ring + ((2 * hy) & (kSlots - 1)) * C::SLOT_DW + run0;
+            const unsigned *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * C::SLOT_DW + run0;
             // lane half 0: kernel row 0 (three pixels) + pixels 0, 1 of kernel row 1; half 1: kernel row 2 + pixel 2 of row 1 (and one
             // pixel past the window under zero weights).  K slots: step 0 = pixels 0, 1 of pa, step 1 = pixel 2 of pa | first pixel of
             // pb, step 2 = second pixel of pb | (zero weights)
             const unsigned *pa = h ? r2 : r0, *pb = h ? r1 + 4 : r1;
-            const u32x4 wa = *(const u32x4 *)pa, wb = *(const u32x4 *)pb;
-            const u32x2 wc = *(const u32x2 *)(pa + 4);
-            u32x4 xb[3];
-            xb[0] = wa;
-            xb[1] = (u32x4){wc[0], wc[1], wb[0], wb[1]};
-            xb[2] = (u32x4){wb[2], wb[3], wb[2], wb[3]};
+            u32x4 xb[C::F32 ? 2 : 1][3];
+#pragma unroll
+            for (int pl = 0; pl < (C::F32 ? 2 : 1); ++pl) {
+                const u32x4 wa = *(const u32x4 *)(pa + pl * kRowDw), wb = *(const u32x4 *)(pb + pl * kRowDw);
+                const u32x2 wc = *(const u32x2 *)(pa + pl * kRowDw + 4);
+                xb[pl][0] = wa;
+                xb[pl][1] = (u32x4){wc[0], wc[1], wb[0], wb[1]};
+                xb[pl][2] = (u32x4){wb[2], wb[3], wb[2], wb[3]};
+            }
             f32x16 e;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -283,8 +353,9 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
             }
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                e = mfma32s(as[s][1], xb[s], e);
-                e = mfma32s(as[s][0], xb[s], e);
+                e = mfma32s(as[s][1], xb[0][s], e);
+                if (C::F32) e = mfma32s(as[s][0], xb[1][s], e);
+                e = mfma32s(as[s][0], xb[0][s], e);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) e[r] = mul_clamp01(e[r], emul);
@@ -312,23 +383,34 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const uns
 }
 
 template <class C>
-static void launch_stem_cfg(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+static void launch_stem_cfg(const void *img, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                             const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
     const int wgs = (B + C::U - 1) / C::U;
     const int grid = wgs < 256 ? wgs : 256;
-    stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B);
+    stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(static_cast<const uint8_t *>(img), As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B);
 }
+
+// like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
+// threshold, the spatially tiled kernel (stem_block1.hip)
+constexpr int kStemMin4 = 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)
+constexpr int kStemMin2 = 480;
 
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                     const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
     if (!img8 || !As3 || !Ap3 || !scl_p) return false;
     if (reinterpret_cast<uintptr_t>(img8) & 7) return false;       // the service wave fetches eight-byte pieces of the image rows
-    // like fused_block_rm.hip: persistent over faces, so small batches take fewer faces per workgroup and, below the last
-    // threshold, the spatially tiled kernel (stem_block1.hip)
-    constexpr int min4 = 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)
-    constexpr int min2 = 480;
-    if (B >= min4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
-    if (B >= min2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    if (B >= kStemMin4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    if (B >= kStemMin2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    return false;
+}
+
+// fp32 NCHW crops (As3 / s_shift: the second constant set of rm_stem_dwords, filter not divided by 128, plain BN shift)
+bool launch_stem_rm_f32(const float *img, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                        const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
+    if (!img || !As3 || !Ap3 || !scl_p) return false;
+    if (reinterpret_cast<uintptr_t>(img) & 15) return false;       // sixteen-byte loads of four pixels of a plane
+    if (B >= kStemMin4) { launch_stem_cfg<StemRmCfg<4, 2, true>>(img, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    if (B >= kStemMin2) { launch_stem_cfg<StemRmCfg<2, 2, true>>(img, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     return false;
 }
 

@@ -107,9 +107,13 @@ void launch_stem_block1(const float *img_nchw, const uint8_t *img_hwc_u8, const 
 //   with m = 3*kx + ci (the byte order of a pixel triple in the HWC image); the other slots are zero.
 // s_shift [32]: BN shift - 255/256 * sum of the (scaled) filter, then {S, 1/S, 6 S}; Ap3: the 32->16 projection in rm_project order
 // (1 group), scl_p its scales.
-constexpr int rm_stem_dwords() { return 3 * 2 * 256 + 32 + 4; }
+constexpr int rm_stem_set_dwords() { return 3 * 2 * 256 + 32 + 4; }      // fragments [3][2][64][4] | shift [32] | {S, 1/S, 6 S, -}
+constexpr int rm_stem_dwords() { return 2 * rm_stem_set_dwords(); }      // the uint8 set (filter / 128, shift with the folded -255/256 sum) | the fp32 set (plain)
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                     const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s);
+// the same march for normalised fp32 NCHW crops [B,3,120,120] (forward_test): As3 / s_shift = the second constant set
+bool launch_stem_rm_f32(const float *img, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
+                        const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s);
 
 // features.18 + global average pool + the three heads fused (head_kernel.hip): NHWC [B,4,4,320] -> param [B,62].
 void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const float *scale, const float *shift,

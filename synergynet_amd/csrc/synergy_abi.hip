@@ -482,9 +482,12 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // fused network head: stem conv + features.1 (dw + linear project) in one launch
         if (h->fusion && L.kind == STEM && stop_feature != 0) {
             const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            if (h->fusion >= 2 && img8 && (h->early_rm & 8) && !(u1 & 1u) &&
-                syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 3 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
-                                    reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s)) {
+            const float *set32 = P + L.dst_wrm + syn::rm_stem_set_dwords();      // fp32 crops: the second constant set
+            if (h->fusion >= 2 && (h->early_rm & 8) && !(u1 & 1u) &&
+                (img8 ? syn::launch_stem_rm(img8, reinterpret_cast<const unsigned *>(P + L.dst_wrm), P + L.dst_wrm + 3 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
+                                            reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s)
+                      : syn::launch_stem_rm_f32(img, reinterpret_cast<const unsigned *>(set32), set32 + 3 * 2 * 256, P + D.dst_wpk, P + D.dst_shift,
+                                                reinterpret_cast<const unsigned *>(P + Pj.dst_wrm), P + Pj.dst_shift, P + Pj.dst_scl, X, B, s))) {
                 li += 2;
                 mark(1);
                 if (stop_feature == 1) {
@@ -935,6 +938,7 @@ static void analyze_mbv2_ranges(const float *flat, RangeInfo &ri) {
             gemm_itv(w, sc, sh, 32, 27, px, e);
             for (Itv &v : e) v = clip6(v);
             float werr = weight_check(w, sc, sh, 32, 27, 1.0f / 128.0f, 255.0f);      // stem_rm.hip: filter / 128 against raw bytes
+            werr = fmaxf(werr, weight_check(w, sc, sh, 32, 27, 1.0f, 1.0f));          // ... and its fp32-crop instantiation: the plain filter against [-1, 1]
             const Layer &D = n.layers[li + 1], &P = n.layers[li + 2];
             std::vector<float> dsc, dsh;
             bn(D, dsc, dsh);
@@ -1149,6 +1153,32 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 fsh[co] = (float)((double)(beta[co] - mean[co] * bn_scale[co]) - 255.0 / 256.0 * sum);
             }
             fsh[32] = S; fsh[33] = 1.0f / S; fsh[34] = 6.0f * S;
+            // second set, for normalised fp32 crops (stem_rm.hip F32): the BN-folded filter itself x its own power of two, the plain BN shift
+            {
+                unsigned *dp2 = dp + syn::rm_stem_set_dwords();
+                float *fsh2 = fsh + syn::rm_stem_set_dwords();
+                float mx2 = 0.f;
+                for (int co = 0; co < 32; ++co)
+                    for (int t = 0; t < 27; ++t) mx2 = fmaxf(mx2, fabsf(w[co * 27 + t] * bn_scale[co]));
+                const float S2 = pow2_scale(mx2);
+                for (int st = 0; st < 3; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int d = 0; d < 4; ++d) {
+                            float x[2];
+                            const int co = lane & 31, hh = lane >> 5;
+                            for (int e = 0; e < 2; ++e) {
+                                const int slot = 2 * d + e, qd = slot >> 2, ci = slot & 3;
+                                const int ky = quad_tap[hh][st][qd][0], kx = quad_tap[hh][st][qd][1];
+                                x[e] = ((ky >= 0 && ci < 3) ? tapw(co, ky, kx, ci) : 0.f) * S2;
+                            }
+                            const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
+                            const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
+                            dp2[((size_t)(st * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                            dp2[((size_t)(st * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+                        }
+                for (int co = 0; co < 32; ++co) fsh2[co] = beta[co] - mean[co] * bn_scale[co];
+                fsh2[32] = S2; fsh2[33] = 1.0f / S2; fsh2[34] = 6.0f * S2;
+            }
         } else if (L.dst_wrm) {          // row-marching early blocks: v_mfma_f32_32x32x16_* fragments (syn_internal.h)
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + L.dst_wrm);
             auto split = [](float x, unsigned (&pc)[3]) {

@@ -110,6 +110,32 @@ def test_distinct_faces_whole_chain_matches_oracle(model, basis, backbone_sd, B)
     print(f'B={B}: worst per-face mesh rel err {worst:.3e}')
 
 
+@pytest.mark.parametrize('B', [480, 515, 1024])
+def test_fp32_crops_take_the_row_marching_stem_and_match_oracle(model, backbone_sd, B):
+    """forward_test (reference synergy3DMM.py:151-154: normalised fp32 NCHW crops) at batches that fill the chip runs the F32
+    instantiation of the row-marching stem (stem_rm.hip, round 4: both operands as two fp16 pieces) instead of the tiled bf16 x3 kernel:
+    every face against the oracle on distinct faces, and against the uint8 ingest of the same pixels (another stem arithmetic: 1e-5)."""
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    crops = synth.make_crops(B, seed=4242)
+    crops[: B // 2] = synth.make_crops(B // 2, seed=4243, smooth=True)
+    crops[0] = 0; crops[1] = 255                                   # flat images: the padding value must be exact
+    x = synth.normalize_crops(crops)
+    got = model.forward_test(torch.from_numpy(x).cuda()).cpu().numpy()
+    via_u8 = model.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert (np.abs(got - via_u8).max(axis=1) / np.abs(via_u8).max(axis=1)).max() < 1e-5
+    idx = np.r_[0:8, B // 2 - 3:B // 2 + 3, B - 9:B]               # the oracle on the first / middle / last faces (first and last workgroup rounds)
+    want = backbone_torch.mobilenet_v2_forward(backbone_sd, x[idx])[0].numpy()
+    assert (np.abs(got[idx] - want).max(axis=1) / np.abs(want).max(axis=1)).max() < 1e-4
+    # values far outside [-1, 1] but inside the documented domain (|x| < 6e4): still the fp32-class result of the same linear map + ReLU6
+    xs = (x[:B] * np.float32(100.0)).astype(np.float32)
+    got2 = model.forward_test(torch.from_numpy(xs).cuda()).cpu().numpy()
+    want2 = backbone_torch.mobilenet_v2_forward(backbone_sd, xs[idx])[0].numpy()
+    assert (np.abs(got2[idx] - want2).max(axis=1) / np.abs(want2).max(axis=1)).max() < 1e-4
+
+
 def test_resnet50_b512_distinct_faces_match_oracle(pack, basis):
     """BASELINE configs[4]: ResNet-50, B = 512 distinct faces + the full mesh, per face vs the oracle."""
     import torch
