@@ -207,13 +207,14 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
         auto consume = [&](const Px8 (&v)[ITER], int slot /*compile-time after unrolling*/) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const unsigned D[7] = {v[it].q[0][0], v[it].q[0][1], v[it].q[1][0], v[it].q[1][1], v[it].q[2][0], v[it].q[2][1], 0u};
+                // dword a of the item's 24 bytes (a compile-time index after unrolling: an indexed local array went to scratch memory)
+                auto Dw = [&](int a) __attribute__((always_inline)) { return a < 6 ? v[it].q[a >> 1][a & 1] : 0u; };
                 u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     // bytes 3k .. 3k+2 -> (R, G), (B, 0) as fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
                     const int a = (3 * k) / 4, sft = (3 * k) % 4;
-                    const unsigned T = sft ? __builtin_amdgcn_alignbyte(D[a + 1], D[a], sft) : D[a];
+                    const unsigned T = sft ? __builtin_amdgcn_alignbyte(Dw(a + 1), Dw(a), sft) : Dw(a);
                     const unsigned rg = __builtin_amdgcn_perm(0x64646464u, T, 0x04010400u);
                     const unsigned bx = __builtin_amdgcn_perm(0x64646464u, T, 0x040c0402u);
                     const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
