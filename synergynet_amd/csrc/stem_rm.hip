@@ -175,21 +175,25 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
             }
             return;
         } else {
-        constexpr int PER_ROW = kImgW / 8;                         // 15 lanes per image row: eight pixels = 24 bytes each
-        constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 63) / 64;
+        // a work item = ONE pixel: lane stride 8 bytes in the row slot, so the 64 ds_write_b64 of an instruction fall into distinct banks
+        // (items of eight pixels, 64 bytes apart, put sixteen lanes on every bank: the service wave's stores alone kept the LDS busy a
+        // fifth of a row step).  A pixel's three bytes start anywhere in a dword: the dword that holds the first byte and the next one
+        // (two loads: the second one of the very last pixel of a batch is out of range and reads 0), v_alignbyte by the lane's own shift.
+        constexpr int TOTAL = C::U * 2 * kImgW, ITER = (TOTAL + 63) / 64;
         constexpr unsigned FACE_B = kImgW * kImgW * 3, ROW2_B = 2 * kImgW * 3;
         unsigned gofs[ITER], lofs[ITER];
         bool live[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int i = lane + 64 * it;
-            const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+            const int u = i / (2 * kImgW), r = (i / kImgW) % 2, px = i % kImgW;
             live[it] = i < TOTAL;
-            gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * (kImgW * 3) + 24 * d) : 0x80000000u;
-            lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 16 * d);      // pixel t = 1 + 8 d of the row slot
+            gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * (kImgW * 3) + ((3 * px) & ~3)) : 0x80000000u;
+            lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 2 * px);       // pixel t = 1 + px of the row slot
         }
+        const unsigned sft = (3u * (lane & 3)) & 3u;               // (3 px) & 3 with px = (lane + 64 it) % 120: 64 and 120 are multiples of 4
         int ifb = blockIdx.x * C::U, ik = 0;                       // the stage `issue` requests next
-        struct Px8 { u32x2 q[3]; };                                // 24 bytes = eight packed RGB pixels
+        struct Px8 { unsigned lo, hi; };
         auto issue = [&](Px8 (&v)[ITER]) {
             // base = row 2 ik of face ifb; records = what is left of the group's faces inside the batch (<= 0: everything reads as zero)
             long long left = ((long long)B - ifb) * (long long)FACE_B;
@@ -199,30 +203,24 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t *>(img) + ((size_t)ifb * FACE_B + (size_t)ik * ROW2_B), 0, nrec, 0x00027000);
 #pragma unroll
-            for (int it = 0; it < ITER; ++it)
-#pragma unroll
-                for (int w = 0; w < 3; ++w) v[it].q[w] = __builtin_amdgcn_raw_buffer_load_b64(rs, gofs[it] + 8 * w, 0, 0);
+            for (int it = 0; it < ITER; ++it) {
+                v[it].lo = __builtin_amdgcn_raw_buffer_load_b32(rs, gofs[it], 0, 0);
+                v[it].hi = __builtin_amdgcn_raw_buffer_load_b32(rs, gofs[it] + 4, 0, 0);
+            }
             if (++ik == kHid) { ik = 0; ifb += gridDim.x * C::U; }
         };
         auto consume = [&](const Px8 (&v)[ITER], int slot /*compile-time after unrolling*/) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                // dword a of the item's 24 bytes (a compile-time index after unrolling: an indexed local array went to scratch memory)
-                auto Dw = [&](int a) __attribute__((always_inline)) { return a < 6 ? v[it].q[a >> 1][a & 1] : 0u; };
-                u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    // bytes 3k .. 3k+2 -> (R, G), (B, 0) as fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
-                    const int a = (3 * k) / 4, sft = (3 * k) % 4;
-                    const unsigned T = sft ? __builtin_amdgcn_alignbyte(Dw(a + 1), Dw(a), sft) : Dw(a);
-                    const unsigned rg = __builtin_amdgcn_perm(0x64646464u, T, 0x04010400u);
-                    const unsigned bx = __builtin_amdgcn_perm(0x64646464u, T, 0x040c0402u);
-                    const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
-                    u32x2 o;
-                    o[0] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, rg) - k1024);
-                    o[1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, bx) - k1024);
-                    if (live[it]) dst[k] = o;
-                }
+                // bytes (R, G, B) -> (R, G), (B, 0) as fp16, exactly: 0x64pp is the fp16 number 1024 + p (ulp 1 there); minus 1024 leaves p
+                const unsigned T = __builtin_amdgcn_alignbyte(v[it].hi, v[it].lo, sft);
+                const unsigned rg = __builtin_amdgcn_perm(0x64646464u, T, 0x04010400u);
+                const unsigned bx = __builtin_amdgcn_perm(0x64646464u, T, 0x040c0402u);
+                const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
+                u32x2 o;
+                o[0] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, rg) - k1024);
+                o[1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, bx) - k1024);
+                if (live[it]) *reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW) = o;
             }
         };
         Px8 va[ITER], vb[ITER];
