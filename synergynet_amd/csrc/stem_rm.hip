@@ -118,9 +118,9 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
         // (faces past the batch, the surplus lanes of the last 64-lane round) return zeros, and the slot offsets are immediates
         // (four stages per loop iteration).
         if constexpr (C::F32) {
-            // a work item = four pixels of one image row: R[4], G[4], B[4] from the three planes of the NCHW crop (16-byte loads)
-            constexpr int PER_ROW = kImgW / 4;                         // 30 items per image row
-            constexpr int TOTAL = C::U * 2 * PER_ROW, ITER = (TOTAL + 64 * C::NSV - 1) / (64 * C::NSV);
+            // a work item = one pixel: R, G, B from the three planes of the NCHW crop (dword loads, 256 contiguous bytes per instruction);
+            // lane stride 8 bytes in the row slot -> conflict-free ds_write_b64 (see the uint8 service wave below)
+            constexpr int TOTAL = C::U * 2 * kImgW, ITER = (TOTAL + 64 * C::NSV - 1) / (64 * C::NSV);
             constexpr unsigned ROW_B = kImgW * 4, PLANE_B = kImgW * ROW_B, FACE_B = 3 * PLANE_B;
             const int sv = wave_wg - C::NCW;                               // the service waves deal the items 64 at a time
             unsigned gofs[ITER], lofs[ITER];
@@ -128,13 +128,13 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int i = lane + 64 * (it * C::NSV + sv);
-                const int u = i / (2 * PER_ROW), r = (i / PER_ROW) % 2, d = i % PER_ROW;
+                const int u = i / (2 * kImgW), r = (i / kImgW) % 2, px = i % kImgW;
                 live[it] = i < TOTAL;
-                gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * ROW_B + 16 * d) : 0x80000000u;
-                lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 8 * d);        // pixel t = 1 + 4 d of the row slot
+                gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * ROW_B + 4 * px) : 0x80000000u;
+                lofs[it] = (unsigned)(u * C::UNIT_DW + r * C::SLOT_DW + 2 + 2 * px);       // pixel t = 1 + px of the row slot
             }
             int ifb = blockIdx.x * C::U, ik = 0;
-            struct Px4 { f32x4 c[3]; };
+            struct Px4 { float c[3]; };
             auto issue = [&](Px4 (&v)[ITER]) {
                 // records = the group's faces inside the batch (the range check is on the lane offset, which names the face; plane and row ride
                 // in the scalar offset and stay inside that face)
@@ -146,20 +146,17 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
                 for (int it = 0; it < ITER; ++it)
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)
-                        v[it].c[ch] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, gofs[it], ch * PLANE_B + ik * 2 * ROW_B, 0));
+                        v[it].c[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, gofs[it], ch * PLANE_B + ik * 2 * ROW_B, 0));
                 if (++ik == kHid) { ik = 0; ifb += gridDim.x * C::U; }
             };
             auto consume = [&](const Px4 (&v)[ITER], int slot) {
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
                     u32x2 *dst = reinterpret_cast<u32x2 *>(smem + lofs[it] + slot * C::SLOT_DW);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        unsigned a_rg, b_rg, a_b, b_b;
-                        split2s(v[it].c[0][k], v[it].c[1][k], a_rg, b_rg);
-                        split2s(v[it].c[2][k], 0.0f, a_b, b_b);
-                        if (live[it]) { dst[k] = (u32x2){a_rg, a_b}; dst[kRowDw / 2 + k] = (u32x2){b_rg, b_b}; }
-                    }
+                    unsigned a_rg, b_rg, a_b, b_b;
+                    split2s(v[it].c[0], v[it].c[1], a_rg, b_rg);
+                    split2s(v[it].c[2], 0.0f, a_b, b_b);
+                    if (live[it]) { dst[0] = (u32x2){a_rg, a_b}; dst[kRowDw / 2] = (u32x2){b_rg, b_b}; }
                 }
             };
             Px4 va[ITER], vb[ITER];
