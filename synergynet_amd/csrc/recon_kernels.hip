@@ -342,7 +342,14 @@ __global__ __launch_bounds__(64) void recon_prep_f16_kernel(const float *__restr
 // FAST: every face tile in [ft_lo, ft_hi) is whole (32 faces) and the padded tile columns fit in the pitch -> the stores are 12
 // unconditional instructions in straight-line code, the only shape for which the compiler's wait-count bookkeeping stays exact
 // (see the store phase).  The launcher runs the ragged last face tile / packed outputs through the guarded instantiation.
-template <int WPG, bool FAST, bool PROF = false>
+// PK (round 4, the reference's PACKED [B,3,n_vert] layout, synergy3DMM.py:131-147): rows are n_vert floats apart, so row r starts
+// 4 r n_vert bytes into the tensor and a fixed 128-vertex run shares its first and last 128-byte line with the neighbouring
+// workgroups' runs -- partial lines written at different times, which HBM takes as read-modify-writes (same bytes through L2 as the
+// pitched layout by the counters, 3.0-3.5 TB/s against 4.4-5.4).  Here a workgroup still COMPUTES 128 vertices, [96 g, 96 g + 128),
+// but STORES per row the 96 of them that start on a line boundary of THAT row: [96 g + s_r, 96 g + 96 + s_r), s_r = -r n_vert mod 32
+// (96 = three whole lines, so every group shares the shift of its row and the windows tile the row; group 0 also writes the s_r
+// vertices in front of its window).  +33 % arithmetic for whole-line stores: the kernel is bound by the stores, not by the pipes.
+template <int WPG, bool FAST, bool PROF = false, bool PK = false>
 __global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
                      int n_vert, int pitch, int n_tiles, int n_split, int ftiles_per_split, int ft_lo, int ft_hi, int n_units,
@@ -358,7 +365,8 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
     const int tg = unit / n_split, split = unit - tg * n_split;
     constexpr int RUN = WPG * 32;                                             // vertices per row and workgroup
-    int T = tg * WPG + wave;
+    static_assert(!PK || (!FAST && WPG == 4), "the packed-row schedule stores 96 of 128 vertices per workgroup through the guarded path");
+    int T = tg * (PK ? 3 : WPG) + wave;
     T = T < n_tiles ? T : n_tiles - 1;
     const int j = lane & 31, h = lane >> 5;
 
@@ -376,7 +384,7 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
     const int ft0 = ft_lo + split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
     ft1 = ft1 < ft_hi ? ft1 : ft_hi;
-    const int v_base = tg * RUN;
+    const int v_base = tg * (PK ? 96 : RUN);
     if (ft0 >= ft1) return;                          // (workgroup-uniform)
 
     u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
@@ -455,6 +463,51 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
             // allocates dense outputs with such a pitch unless the caller brings a packed buffer.
             // Nothing of this addressing may stay live across the tile loop (the compiler once hoisted 12 offsets, spilled
             // them, and every scratch reload's s_waitcnt vmcnt(0) waited for all stores in flight): hence the opaque thread id.
+            if constexpr (PK) {
+                // 24 lanes x float4 = the 96-vertex window of one row, 10 rows per instruction (240 of the 256 threads), 10 instructions.
+                // The stores are BUFFER stores on a per-tile resource and unconditional: a lane that must not write (row past the batch,
+                // float4 not wholly inside the row, surplus thread) gets an out-of-range offset and the hardware drops it -- straight-line
+                // code, so park()'s wait is a counted vmcnt and the stores stay in flight into the next tile (with branches around them
+                // every tile waited for the acknowledgement of its stores: 0.180 ms).  What is left -- the vertices in front of the
+                // first window (group 0) and a row's ragged last float4 (last group) -- follows park() under a workgroup-uniform branch.
+                int tid_ = threadIdx.x;
+                asm volatile("" : "+v"(tid_));
+                const int seg = tid_ % 24, rsub = tid_ / 24;
+                const int nv32 = n_vert & 31;
+                const long long r0 = 3ll * f0;
+                long long tile_rows = 3ll * B - r0;
+                tile_rows = tile_rows < 96 ? tile_rows : 96;
+                const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)r0 * n_vert, 0, (int)(tile_rows * n_vert * 4), 0x00027000);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    const int rr = 10 * k + rsub;                                  // row of the face tile: face f0 + rr / 3, coordinate rr % 3
+                    const int sh = (32 - (int)(((r0 + rr) * nv32) & 31)) & 31;     // the row's line boundaries lie at vertices = sh mod 32
+                    const int vq = v_base + sh + 4 * seg;
+                    const float *sp = &stage[(rr < 96 ? rr : 95) * SS + sh + 4 * seg];     // (4-byte aligned: sh is any number)
+                    const f32x4 vv = {sp[0], sp[1], sp[2], sp[3]};
+                    const bool ok = rsub < 10 && rr < 96 && vq + 3 < n_vert;       // (rows past the batch are past the resource)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rs_o, ok ? (unsigned)(rr * n_vert + vq) * 4u : 0x80000000u, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                park(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tg == 0 || v_base + 96 + 31 + 3 >= n_vert) {                    // (workgroup-uniform) first / last group of the rows
+#pragma unroll 1
+                    for (int k = 0; k < 10; ++k) {
+                        const int rr = 10 * k + rsub;
+                        const long long r = r0 + rr;
+                        if (rsub >= 10 || rr >= 96 || r >= 3ll * B) continue;
+                        const int sh = (32 - (int)((r * nv32) & 31)) & 31;
+                        const int vq = v_base + sh + 4 * seg;
+                        if (vq < n_vert && vq + 3 >= n_vert) {                      // the ragged last float4 of the row
+                            for (int t = 0; t < 4; ++t) if (vq + t < n_vert) out[(size_t)r * n_vert + vq + t] = stage[rr * SS + sh + 4 * seg + t];
+                        }
+                        if (tg == 0 && 4 * seg < sh) {                              // the vertices in front of the first window of the row
+                            for (int t = 0; t < 4; ++t) if (4 * seg + t < sh) out[(size_t)r * n_vert + 4 * seg + t] = stage[rr * SS + 4 * seg + t];
+                        }
+                    }
+                }
+            } else {
             constexpr int LPR = RUN / 4, RPI = WPG * 64 / LPR;
             int tid_ = threadIdx.x;
             asm volatile("" : "+v"(tid_));
@@ -486,6 +539,7 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
             }
             __builtin_amdgcn_sched_barrier(0);       // park() must stay BELOW the stores (its wait counts them)
             park(buf ^ 1);
+            }
         }
         RLAP(5);
         lds_barrier();     // the stage is rewritten by the next face tile
@@ -507,7 +561,9 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
     if (marks) (void)hipEventRecord(marks[1], s);
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
-    const int n_groups = (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles
+    // the reference's packed rows (pitch == n_vert, dense mesh, a line-aligned tensor): the whole-line schedule PK of the kernel
+    const bool pk = pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !getenv("SYN_RECON_NO_PK");
+    const int n_groups = pk ? (n_vert + 95) / 96 : (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles (PK: a stride of three)
     static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 1664;   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
     static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
     // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
@@ -534,6 +590,8 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
             fprintf(stderr, "recon prof workgroups %llu\n", hst[7]);
         } else if (fast)
             recon_f16_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+        else if (pk)
+            recon_f16_kernel<WPG, false, false, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
         else
             recon_f16_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
     };
