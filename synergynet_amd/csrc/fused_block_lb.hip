@@ -93,6 +93,17 @@ __device__ __forceinline__ f32x2 dpp2(f32x2 v) {
     r[1] = dpp1<CTRL>(v[1]);
     return r;
 }
+// ReLU6 without instructions of its own (round 4, tools/ubench/valu_issue.hip: v_med3_f32 costs 1.85 ns of a SIMD, an fp32 multiply 1.25, a
+// packed FMA 2.2): activations are carried as relu6(x) / 6 in [0, 1] = what the `clamp` output modifier leaves -- on the multiply that
+// rescales the expand accumulator (compiler-made: a vector instruction that reads a matrix result needs wait states only the compiler
+// inserts) and on the LAST packed FMA of a depthwise output (inline assembly: its operands are vector results).  The 6 rides on the
+// constants: expand multiplier 1 / (96 Se), the plain depthwise filter, depthwise shift / 6, output rescale 6 / Sp (synergy_abi.hip).
+__device__ __forceinline__ float relu01(float d, float m) { return __builtin_amdgcn_fmed3f(d * m, 0.0f, 1.0f); }
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 constexpr int kRowShr1 = 0x111, kRowShl1 = 0x101, kRowShr8 = 0x118, kRowShl8 = 0x108;   // lane n <- n-1 | n+1 | n-8 | n+8 of its 16-lane row, else 0
 constexpr int kRowShr4 = 0x114, kRowShr5 = 0x115;
 }  // namespace
@@ -302,8 +313,8 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
             f32x2 E[4], O[NB];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                E[r][0] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf], 0.0f, c6e);
-                E[r][1] = __builtin_amdgcn_fmed3f(D[t][r][2 * hf + 1], 0.0f, c6e);
+                E[r][0] = relu01(D[t][r][2 * hf], c6e);
+                E[r][1] = relu01(D[t][r][2 * hf + 1], c6e);
             }
 #pragma unroll
             for (int r = 0; r < NB; ++r) O[r] = dsh;
@@ -319,7 +330,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 asm volatile("" : "+v"(O[0]));
                 O[0] += dpp2<kRowShr1>(E[3]) * w[6];
                 O[0] += E[2] * w[7];
-                O[0] += E[3] * w[8];
+                O[0] = pk_fma_clamp01(E[3], w[8], O[0]);
             } else {
             // input rows q = -1 .. 4 of the block rows (row q feeds outputs q - dy, dy = 0..2: ascending dy per output).  The pins
             // chain the rows: unchained arithmetic is otherwise scheduled all rows at once.
@@ -335,14 +346,16 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                     if (r < 0 || r > 3) continue;
                     O[r] += l * w[3 * dy];
                     O[r] += c * w[3 * dy + 1];
-                    O[r] += rt * w[3 * dy + 2];
+                    // dy == 2 (input row r + 2) is the last kernel row an output row receives: its last FMA clamps
+                    if (dy == 2) O[r] = pk_fma_clamp01(rt, w[3 * dy + 2], O[r]);
+                    else O[r] += rt * w[3 * dy + 2];
                     asm volatile("" : "+v"(O[r]));
                 }
             }
             }
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                split2v(__builtin_amdgcn_fmed3f(O[r][0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[r][1], 0.0f, 96.0f), Bd[r], th);
+                split2v(O[r][0], O[r][1], Bd[r], th);
                 if (hf) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(Bd[r][p]));
@@ -619,8 +632,8 @@ __device__ __forceinline__ void lb7_stage(unsigned *smem, const LbStageArgs &sa,
             for (int dy = 0; dy < 3; ++dy) w[3 * dy] *= mL;
             auto relu = [&](const f32x4 &d, float ceil) __attribute__((always_inline)) {
                 f32x2 e;
-                e[0] = __builtin_amdgcn_fmed3f(d[2 * hf], 0.0f, ceil);
-                e[1] = __builtin_amdgcn_fmed3f(d[2 * hf + 1], 0.0f, ceil);
+                e[0] = relu01(d[2 * hf], ceil);
+                e[1] = relu01(d[2 * hf + 1], ceil);
                 return e;
             };
             f32x2 up2, up3;                              // the odd-row classes' block before this wave's first block (wave 1), lanes 8-15 -> 0-7
@@ -647,8 +660,8 @@ __device__ __forceinline__ void lb7_stage(unsigned *smem, const LbStageArgs &sa,
                 asm volatile("" : "+v"(O));
                 O += dpp2<kRowShr1>(E3) * w[6];
                 O += E2 * w[7];
-                O += E3 * w[8];
-                split2v(__builtin_amdgcn_fmed3f(O[0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[1], 0.0f, 96.0f), Bd[k], th);
+                O = pk_fma_clamp01(E3, w[8], O);
+                split2v(O[0], O[1], Bd[k], th);
                 if (k == 0) { up2 = dpp2<kRowShl8>(E2); up3 = dpp2<kRowShl8>(E3); }
             }
             SYNL_FENCE();

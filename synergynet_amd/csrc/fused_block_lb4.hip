@@ -212,8 +212,9 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
             f32x2 E;
-            E[0] = __builtin_amdgcn_fmed3f(D[2 * hf], 0.0f, c6e);
-            E[1] = __builtin_amdgcn_fmed3f(D[2 * hf + 1], 0.0f, c6e);
+            // ReLU6 as clamp modifiers (fused_block_lb.hip): E = relu6 / 6 = clamp(D / (96 Se)); the last add of the output clamps too
+            E[0] = __builtin_amdgcn_fmed3f(D[2 * hf] * c6e, 0.0f, 1.0f);
+            E[1] = __builtin_amdgcn_fmed3f(D[2 * hf + 1] * c6e, 0.0f, 1.0f);
             // horizontal first (two lane shifts), then the three row sums shifted vertically (two more): 8 DPP moves per channel pair
             // instead of 16.  (Summation order differs from the other kernels': dx inside dy inside the vertical sum.)
             const f32x2 l = dppq2<kShr1>(E), rt = dppq2<kShl1>(E);
@@ -226,9 +227,12 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
             }
             f32x2 O = dsh + dppq2<kShr4>(H[0]);          // kernel row 0 applies to the input row above: take it from lane n - 4
             O += H[1];
-            O += dppq2<kShl4>(H[2]);
+            {
+                const f32x2 h2 = dppq2<kShl4>(H[2]);
+                asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(O) : "v"(O), "v"(h2));
+            }
             unsigned a, b;
-            split2q(__builtin_amdgcn_fmed3f(O[0], 0.0f, 96.0f), __builtin_amdgcn_fmed3f(O[1], 0.0f, 96.0f), a, b);
+            split2q(O[0], O[1], a, b);
             own[hf] = a; own[2 + hf] = b;
         }
         // ---- the partner's half: K slots 0-3 of a lane group are tile 0's channels, 4-7 tile 1's ----

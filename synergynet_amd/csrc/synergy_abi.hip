@@ -265,7 +265,7 @@ struct ConstHeader {   // first 256 bytes of an exported constants buffer
 };
 static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
 constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
-constexpr uint32_t kConstVersion = 3;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring)
+constexpr uint32_t kConstVersion = 4;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring; 4: clamp-form constants of the register-resident blocks)
 
 // verdict of the load-time range analysis of the fp16 x2 schedule (analyze_mbv2_ranges below); 64 dwords at Net::dst_range
 struct RangeInfo {
@@ -1285,10 +1285,12 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                     put(dst, 0, lane, d, x[0], x[1]);
                 }
         };
+        // round 4: ReLU6 through clamp modifiers -- E' = clamp(D / (96 Se)) = relu6 / 6, O' = dshift / 6 + sum taps E' (the PLAIN filter),
+        // B' = clamp(O') = relu6 / 6 in [0, 1]; acc = (Sp / 6) (Wp o);  y = acc (6 / Sp) + pshift (+ x)
         auto put_t = [&](float *tb, int g) {
             for (int c = 0; c < 32; ++c) {
-                for (int k = 0; k < 9; ++k) tb[k * 32 + c] = pk[D.dst_wpk + (size_t)k * hid + 32 * g + c] / Se;
-                tb[9 * 32 + c] = 16.0f * pk[D.dst_shift + 32 * g + c];
+                for (int k = 0; k < 9; ++k) tb[k * 32 + c] = pk[D.dst_wpk + (size_t)k * hid + 32 * g + c];
+                tb[9 * 32 + c] = pk[D.dst_shift + 32 * g + c] * (1.0f / 6.0f);
                 tb[10 * 32 + c] = 16.0f * Se * pk[L.dst_shift + 32 * g + c];
             }
         };
@@ -1302,7 +1304,7 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
                 for (int mt = 0; mt < mtn; ++mt) put_p(bp + (size_t)mt * 512, g, mt);
                 float *tb = reinterpret_cast<float *>(bp + (size_t)mtn * 512);
                 put_t(tb, g);
-                if (g == 0) { tb[11 * 32 + 0] = 96.0f * Se; tb[11 * 32 + 1] = 1.0f / (16.0f * Sp); }
+                if (g == 0) { tb[11 * 32 + 0] = 1.0f / (96.0f * Se); tb[11 * 32 + 1] = 6.0f / Sp; }
             }
             continue;
         }
@@ -1314,8 +1316,8 @@ static void pack_backbone_mbv2(const float *flat, std::vector<float> &pk) {
             for (int mt = 0; mt < mtn; ++mt) put_p(dq + (size_t)(g * mtn + mt) * 512, g, mt);
         float *tb = pk.data() + L.dst_tlb;
         for (int g = 0; g < ng; ++g) put_t(tb + (size_t)g * 12 * 32, g);
-        tb[11 * 32 + 0] = 96.0f * Se;               // ReLU6 ceiling of the scaled expand output
-        tb[11 * 32 + 1] = 1.0f / (16.0f * Sp);      // project accumulator -> output
+        tb[11 * 32 + 0] = 1.0f / (96.0f * Se);      // scaled expand output -> relu6 / 6 (with the clamp modifier)
+        tb[11 * 32 + 1] = 6.0f / Sp;                // project accumulator (of relu6 / 6 activations) -> output
     }
     {   // features.18 (BN scale folded in), scaled by S = 2^e to max |w| in [2^13, 2^14) and split into two fp16 pieces per weight,
         // lane-ordered for v_mfma_f32_16x16x32_f16: [n_tile 80][k_chunk 10][piece 2][lane 64][4 dwords], lane (r16, g) holds
