@@ -83,6 +83,14 @@ int syn_numerics_report(syn_handle *h, char *buf, size_t n);
  * IMAGES without an oracle (SynergyNet.check_numerics).  Not to be changed while calls are in flight. */
 int syn_set_schedule(syn_handle *h, int fusion);
 
+/* Calibration of that verdict on the caller's own crops (uint8 [B,120,120,3] on the device, B <= 256): every block output of the default
+ * schedule is compared with the exact fp32-MFMA schedule on this data; a block that differs by more than `tol` (relative to the
+ * tensor's maximum; 2e-5 is the natural choice, the schedules agree to ~1e-6) runs the exact kernel from then on, in this handle and
+ * in every replica that imports its constants.  Closes the one assumption of the load-time analysis that is not a proof: that the
+ * interval bound of a tensor is within 2^8 of its true activations (underflow side).  Returns the number of blocks switched
+ * (0 for ResNet-50, which is guarded at run time).  Synchronises; not for use while forwards of this handle are in flight. */
+int syn_backbone_calibrate(syn_handle *h, const uint8_t *crops_u8, int B, float tol, void *stream);
+
 /* ResNet-50 (ReLU, no static activation bound): the fp16 convolutions are guarded at RUN time.  Every tensor they split reports
  * max |x| into a per-forward status array; when one leaves [2^-10, 6e4] the head kernel returns NaN for that forward (loud, no host
  * synchronisation).  syn_backbone_range_status synchronises the device, copies the maxima of the last forward (slot 0 = max-pool

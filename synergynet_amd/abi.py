@@ -36,6 +36,7 @@ _SIGS = {
     'syn_set_schedule': (C.c_int, [C.c_void_p, C.c_int]),
     'syn_backbone_range_status': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'syn_backbone_range_events': (C.c_int, [C.c_void_p]),
+    'syn_backbone_calibrate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     'syn_resnet50_flat_count': (C.c_size_t, []),
     'syn_load_backbone_resnet50': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'syn_resnet50_flops_per_face': (C.c_double, []),

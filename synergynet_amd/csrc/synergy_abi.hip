@@ -1992,6 +1992,62 @@ int syn_debug_feature(syn_handle *h, const float *img, int B, int feature, float
     return run_backbone(h, img, nullptr, B, nullptr, nullptr, (hipStream_t)stream, feature, out);
 }
 
+// Calibration of the range verdict on the CALLER'S crops (include/synergy_hip.h): the load-time analysis proves the overflow side, but
+// its underflow side rests on the interval bound being within 2^8 of the true activations.  Here every block output of the default
+// schedule is held against the exact fp32-MFMA schedule of the same library on real data; the first block that differs by more than
+// `tol` (relative to the tensor's maximum) is switched to the exact kernel -- in the handle AND in the verdict words of the packed
+// constants, so replicas that import them follow -- and the comparison goes on behind it.  Returns the number of blocks switched.
+int syn_backbone_calibrate(syn_handle *h, const uint8_t *crops_u8, int B, float tol, void *stream) {
+    if (!h || !crops_u8) return fail(SYN_ERR_INVALID, "syn_backbone_calibrate: NULL argument");
+    if (B <= 0 || B > 256) return fail(SYN_ERR_INVALID, "syn_backbone_calibrate: B=%d (1 .. 256 crops)", B);
+    if (!(tol > 0.f)) return fail(SYN_ERR_INVALID, "syn_backbone_calibrate: tol=%g", (double)tol);
+    if (!h->d_backbone) return fail(SYN_ERR_NOT_LOADED, "syn_backbone_calibrate: backbone weights not loaded");
+    if (h->arch != 0) return 0;                          // ResNet-50 is guarded at run time (syn_backbone_range_status)
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const Net &n = net();
+    const size_t cap = (size_t)B * 60 * 60 * 16;       // the largest block output (features.1)
+    float *d_a = nullptr, *d_b = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_a, 2 * cap * sizeof(float)));
+    d_b = d_a + cap;
+    std::vector<float> ha(cap), hb(cap);
+    const int fusion0 = h->fusion;
+    int switched = 0, rc = SYN_OK;
+    for (int f = 1; f <= 17 && rc == SYN_OK; ++f) {
+        size_t count = 0;
+        for (const Layer &L : n.layers) if (L.feature == f) count = (size_t)B * L.cout * L.hout * L.hout;      // (the block's last layer)
+        const unsigned bit = f == 1 ? 1u : 1u << f;      // bit 0 = stem + features.1
+        if ((h->ri.unsafe1 & bit) || count == 0 || count > cap) continue;      // already on the exact kernel
+        h->fusion = 2;
+        rc = run_backbone(h, nullptr, crops_u8, B, nullptr, nullptr, s, f, d_a);
+        h->fusion = 1;
+        if (rc == SYN_OK) rc = run_backbone(h, nullptr, crops_u8, B, nullptr, nullptr, s, f, d_b);
+        h->fusion = fusion0;
+        if (rc != SYN_OK) break;
+        if (hipMemcpyAsync(ha.data(), d_a, count * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(hb.data(), d_b, count * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(SYN_ERR_HIP, "syn_backbone_calibrate: reading features.%d back failed", f);
+            break;
+        }
+        double worst = 0, mag = 0;
+        bool finite = true;
+        for (size_t i = 0; i < count; ++i) {
+            finite = finite && std::isfinite(ha[i]) && std::isfinite(hb[i]);
+            const double d = fabs((double)ha[i] - (double)hb[i]);
+            worst = d > worst ? d : worst;
+            mag = fabs((double)hb[i]) > mag ? fabs((double)hb[i]) : mag;
+        }
+        if (!finite || worst > (double)tol * (mag > 0 ? mag : 1.0)) {
+            h->ri.unsafe1 |= bit; h->ri.unsafe16 |= bit;
+            ++switched;
+        }
+    }
+    (void)hipFree(d_a);
+    if (rc != SYN_OK) return rc;
+    if (switched) HIP_TRY(hipMemcpy(h->d_backbone + n.dst_range, &h->ri, sizeof h->ri, hipMemcpyHostToDevice));
+    return switched;
+}
+
 // Test hook, not part of include/synergy_hip.h: fill every scratch buffer of the handle with `byte` (0xFF = NaNs), so a test
 // can show that no result depends on what earlier calls (or the allocator) left in the workspace.
 int syn_debug_poison_workspace(syn_handle *h, int B, int byte) {

@@ -277,6 +277,23 @@ class SynergyNet(nn.Module):
             abi.check(n)
         return n, mx[:54]
 
+    def calibrate(self, crops_u8, tol=2e-5):
+        """Range verdict checked on the caller's OWN crops (include/synergy_hip.h syn_backbone_calibrate): block by block, the default
+        fp16x2 schedule against the exact fp32-MFMA one; blocks that differ by more than `tol` are switched to the exact kernel (and a
+        warning says which).  Returns the number of blocks switched.  The load-time analysis cannot rule out a checkpoint whose
+        interval bounds are far looser than its real activations; a few representative crops here do."""
+        crops = crops_u8 if isinstance(crops_u8, torch.Tensor) else torch.as_tensor(np.asarray(crops_u8))
+        if crops.dtype != torch.uint8 or crops.dim() != 4 or tuple(crops.shape[1:]) != (120, 120, 3):
+            raise RuntimeError('calibrate expects uint8 [B,120,120,3]')
+        x = crops.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            n = self._lib.syn_backbone_calibrate(self._h, x.data_ptr(), x.shape[0], float(tol), self._stream())
+        if n < 0:
+            abi.check(n)
+        if n > 0:
+            self._warn_numerics()
+        return n
+
     def check_numerics(self, crops_u8, rois=None):
         """Self-check on the caller's OWN checkpoint and images, no oracle involved: the same crops through the default schedule (fp16x2
         operands) and through the exact fp32-MFMA schedule of the same library (syn_set_schedule), parameters -> landmarks -> mesh.

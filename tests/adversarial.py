@@ -40,6 +40,27 @@ def scale_stream(sd: dict, group: str, s: float) -> dict:
     return out
 
 
+def loose_bound_stream(sd: dict, s: float = 2.0 ** -15, A: float = 24.0) -> dict:
+    """The 64-channel stream times s (scale_stream) AND a static bound on it that is ~2^12 looser than what features.7 really
+    produces: hidden channel 2i+1 of features.7 becomes an exact copy of channel 2i (expand, depthwise and their BatchNorms), and the
+    project weights of the pair get +A / -A.  The copies carry identical activations, so the pair contributes (w + A - A) d: the
+    network computes what the even channels alone would -- but interval arithmetic sees |w + A| + |A| per pair.  The load-time
+    analysis then finds a comfortable bound on a tensor whose real values are ~s: the case its underflow ESTIMATE cannot decide
+    (VERDICT r3 weak #1) and calibration on real crops does."""
+    out = {k: np.array(v, copy=True) for k, v in sd.items()}
+    expand, dw, proj = _block_keys(7)
+    for L in (expand, dw):
+        w = out[L['key'] + '.weight']
+        w[1::2] = w[0::2]
+        for q in ('weight', 'bias', 'running_mean', 'running_var'):
+            v = out[L['bn'] + '.' + q]
+            v[1::2] = v[0::2]
+    wp = out[proj['key'] + '.weight']
+    wp[:, 1::2] = np.float32(-A)
+    wp[:, 0::2] = wp[:, 0::2] + np.float32(A)
+    return scale_stream(out, '64', s)
+
+
 def spread_rows(sd: dict, feature: int, decades: float = 6.0, zero_shift: bool = False, seed: int = 3) -> dict:
     """Output rows of the EXPAND convolution of .features[feature] scaled by 10^-decades .. 1 with NO compensation anywhere: the
     hidden channels really are that far apart.  zero_shift: their BatchNorm bias / running mean are zeroed too, so that a small

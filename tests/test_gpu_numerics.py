@@ -201,6 +201,53 @@ def test_reconstruction_degenerate_coefficients(pack):
     assert per_face_err(got, want).max() < 2e-6
 
 
+def test_calibration_on_real_crops_decides_what_the_interval_estimate_cannot(pack, base_sd):
+    """VERDICT r3 weak #1 / next #6b: the underflow side of the load-time analysis assumes the interval bound of a tensor is within 2^8
+    of its real activations.  adv.loose_bound_stream builds a checkpoint where it is ~2^12+ looser: the static verdict accepts the
+    64-channel stream (comfortable bound), its real values sit around 1e-5, and the fp16x2 kernels are visibly wrong on it.
+    SynergyNet.calibrate (syn_backbone_calibrate: default vs exact schedule block by block on the caller's crops) finds the blocks
+    and switches them; a healthy checkpoint is left alone."""
+    import torch
+    import warnings
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    sd = adv.loose_bound_stream(base_sd)
+    crops = synth.make_crops(12, seed=91)
+    want, _, feats = backbone_torch.mobilenet_v2_forward(sd, synth.normalize_crops(crops), return_features=True)
+    want = want.numpy()
+    f7_out = [v for k, v in feats.items() if k.startswith('features.7.')][-1]        # the block output = the input of features.8
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        model = make_model(pack, sd)
+    n0, text = model.numerics_report()
+    # the interval bound on the input of features.8 against what the oracle really produces there: the slack the estimate cannot see
+    bound8 = float([l for l in text.splitlines() if l.startswith('features.8:')][0].split('input bound ')[1].split(',')[0])
+    true8 = float(f7_out.abs().max())
+    print('bound / true of the input of features.8:', bound8, true8, bound8 / true8, [l for l in text.splitlines() if l.startswith('features.8:')])
+    assert bound8 / true8 >= 2.0 ** 12, (bound8, true8)
+    assert 'features.8:' in text and [l for l in text.splitlines() if l.startswith('features.8:')][0].endswith('-> fp16x2'), text
+    cd = torch.from_numpy(crops).cuda()
+    before = per_face_err(model.forward_crops_u8(cd).cpu().numpy(), want)
+    print('before calibration', before.max())
+    assert before.max() > 10 * TOL, before.max()                  # the accepted schedule IS wrong on this checkpoint
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        n = model.calibrate(cd[:8])
+    assert n >= 1 and w and 'exact schedule' in str(w[0].message)
+    after = per_face_err(model.forward_crops_u8(cd).cpu().numpy(), want)
+    print('switched', n, 'after calibration', after.max())
+    assert after.max() < TOL, after.max()
+    assert model.numerics_report()[0] == n0 + n
+    # a replica that imports the calibrated constants follows the verdict
+    from synergynet_amd.synergy3DMM import SynergyNet
+    other = SynergyNet(device='cuda:0', load_constants=False)
+    other.import_constants(model.export_constants())
+    assert per_face_err(other.forward_crops_u8(cd).cpu().numpy(), want).max() < TOL
+    # ... and a healthy checkpoint is left alone
+    good = make_model(pack, base_sd)
+    assert good.calibrate(cd[:8]) == 0 and good.numerics_report()[0] == 0
+
+
 # ---- ResNet-50: no static bound (ReLU), guarded at run time ----
 
 def test_resnet50_weight_unsafe_convolution_runs_exact_and_stays_guarded(pack):
