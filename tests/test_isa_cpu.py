@@ -20,4 +20,4 @@ def test_no_kernel_spills_or_uses_scratch(capsys):
     rc = isa_lint.main()
     out = capsys.readouterr().out
     assert rc == 0, out[-4000:]
-    assert 'recon_f16_kernel<4, true, false>' in out and 'fused_block_early_kernel' in out      # the table really covers the hot kernels
+    assert 'recon_f16_kernel<4, true, false, false>' in out and 'recon_f16_kernel<4, false, false, true>' in out and 'fused_block_early_kernel' in out      # the table really covers the hot kernels
