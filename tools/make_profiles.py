@@ -14,6 +14,7 @@ def cp(a, b):
 cp('stats/k_kernel_stats.csv', 'kernel_stats_b1024.csv')
 cp('stats1/k_kernel_stats.csv', 'kernel_stats_b1024_one_stream.csv')
 cp('stats_r50/k_kernel_stats.csv', 'resnet50_kernel_stats_b512.csv')
+cp('stats_r50_1/k_kernel_stats.csv', 'resnet50_kernel_stats_b512_one_stream.csv')
 cp('stats_b128/k_kernel_stats.csv', 'kernel_stats_b128_lmk_only.csv')
 cp('stats/k_agent_info.csv', 'agent_info.csv')
 cp('bench.json', 'bench_b1024.json')

@@ -13,6 +13,7 @@ B="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- $B > $O/stats.log 2>&1; echo "stats rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o k -- $B --overlap 0 > $O/stats1.log 2>&1; echo "stats(one stream) rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50 -o k -- $B --arch resnet50 --batch 512 > $O/stats_r50.log 2>&1; echo "stats(resnet50) rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_r50_1 -o k -- $B --arch resnet50 --batch 512 --overlap 0 > $O/stats_r50_1.log 2>&1; echo "stats(resnet50, one stream) rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b128 -o k -- $B --lmk-only --batch 128 --steps 20 --overlap 0 > $O/stats_b128.log 2>&1; echo "stats(b128 lmk-only) rc=$?"
 P="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --overlap 0"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
