@@ -174,12 +174,12 @@ def test_documented_knobs_exist_in_the_sources():
 
 
 def test_committed_bench_line_keeps_the_driver_contract():
-    """profiles/r3/bench_b1024.json is a bench.py line from the GPU box: the fields the driver and the judge read must be there and consistent
+    """profiles/r4/bench_b1024.json is a bench.py line from the GPU box: the fields the driver and the judge read must be there and consistent
     (whole-job value = faces per step / step time, roofline fraction = achieved / peak, a bounded CPU baseline with its core count)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, 'profiles', 'r3', 'bench_b1024.json')))
+    d = json.load(open(os.path.join(root, 'profiles', 'r4', 'bench_b1024.json')))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
               'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -206,14 +206,14 @@ def test_committed_bench_line_keeps_the_driver_contract():
 
 def test_roofline_fraction_can_be_recomputed_from_the_committed_kernel_stats():
     """frac = algorithmic family FLOPs / sum of the family kernels' time per forward / ceiling, recomputed from
-    profiles/r3/kernel_stats_b1024_one_stream.csv (rocprofv3 --kernel-trace --stats of the same command), must agree with the printed
+    profiles/r4/kernel_stats_b1024_one_stream.csv (rocprofv3 --kernel-trace --stats of the same command), must agree with the printed
     roofline.frac within 8 % (the profiler's own slowdown is ~3-7 %)."""
     import csv
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, 'profiles', 'r3', 'bench_b1024.json')))
-    rows = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r3', 'kernel_stats_b1024_one_stream.csv'))))
+    d = json.load(open(os.path.join(root, 'profiles', 'r4', 'bench_b1024.json')))
+    rows = list(csv.DictReader(open(os.path.join(root, 'profiles', 'r4', 'kernel_stats_b1024_one_stream.csv'))))
     forwards = [int(r['Calls']) for r in rows if 'stem_rm_kernel' in r['Name']][0]
     fam_ns = sum(float(r['TotalDurationNs']) for r in rows if 'fused_block' in r['Name'] or 'fused_chain' in r['Name']) / forwards
     r = d['roofline']
