@@ -108,7 +108,7 @@ constexpr int kRowShr1 = 0x111, kRowShl1 = 0x101, kRowShr8 = 0x118, kRowShl8 = 0
 constexpr int kRowShr4 = 0x114, kRowShr5 = 0x115;
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_ = 2, bool S2_ = false>
+template <int CIN_, int HID_, int COUT_, bool RES_, int EPF_, int PPF_, int FPW_ = 2, bool S2_ = false, int NS_ = 2>
 struct LbCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, FPW = FPW_;
     static constexpr int PPF = PPF_;                     // output tiles the project fragments are fetched ahead (1 | 2)
@@ -121,17 +121,20 @@ struct LbCfg {
     static constexpr int KE = CIN / 32;                  // k32 steps of the expand GEMM
     static constexpr int NG = HID / 32;                  // hidden groups
     static constexpr int MT = COUT / 16;                 // output channel tiles
-    static constexpr int NS = 2;                         // waves per face (hidden groups s, s + 2, ...)
+    static constexpr int NS = NS_;                       // waves per face (hidden groups s, s + NS, ...).  4 (round 4): the small-batch chain --
+                                                         // one face per workgroup, four streams, all partial sums through LDS (below)
     static constexpr int NW = FPW * NS, NT = NW * 64;
     static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
-    static constexpr int RED_DW = MT * NB * 256;         // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]
+    static constexpr int KT = (MT + NS - 1) / NS;        // output tiles a wave keeps (mt % NS == its stream)
+    static constexpr int RED_DW = (NS == 2 ? 1 : NS) * MT * NB * 256;   // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]; NS > 2: [stream][MT][NB][lane][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
     static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
     static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
+    static_assert(NS == 2 || (NS == 4 && FPW == 1 && (HID / 32) >= NS), "four streams: the one-face-per-workgroup schedule of small batches");
     static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
     static_assert(!RES || (CIN == COUT && !S2), "residual only on same-width stride-1 blocks");
-    static_assert((FPW == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
+    static_assert((FPW == 4 || NS == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
 // compiler fence between the phases of a hidden group: without it every load of a group is hoisted to the top of the loop body
@@ -170,13 +173,14 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     constexpr int KE = C::KE, MT = C::MT, CIN = C::CIN, COUT = C::COUT, NB = C::NB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fl = wave >> 1, st = wave & 1;
+    const int fl = wave / C::NS, st = wave % C::NS;
     const int f = blockIdx.x * C::FPW + fl;
     const bool real = f < B;
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
     const unsigned l4 = lane * 4, g4 = g * 4;
     unsigned *Xf = smem + fl * FACE_DW;
+    constexpr int BPW = 4 / C::NS;                       // blocks of the block input a wave stages
     // input pixel of (block b, lane column n).  Stride 1: y = b + 4 (n >> 3), x = n & 7.  Stride 2: the blocks are the four parity
     // classes, b = 2 (y & 1) + (x & 1), and n = 4 (y >> 1) + (x >> 1) -- output pixel (oy, ox) = lane 4 oy + ox then takes its nine
     // taps from its own lane (rows 2 oy, 2 oy + 1 / columns 2 ox, 2 ox + 1) and from lanes n - 4 (row 2 oy - 1), n - 1 (column 2 ox - 1)
@@ -187,19 +191,19 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 
     // ---- stage: block input of this face -> pre-split B fragments (this wave: blocks 2 st, 2 st + 1) ----
     if (FIRST) {
-        f32x4 xv[KE][2][2];
+        f32x4 xv[KE][BPW][2];
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc)
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const float *src = X + ((size_t)fc * 64 + pix_in(2 * st + rr, n)) * CIN + 32 * kc + 8 * g;
+            for (int rr = 0; rr < BPW; ++rr) {
+                const float *src = X + ((size_t)fc * 64 + pix_in(BPW * st + rr, n)) * CIN + 32 * kc + 8 * g;
                 xv[kc][rr][0] = *(const f32x4 *)src;
                 xv[kc][rr][1] = *(const f32x4 *)(src + 4);
             }
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc)
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            for (int rr = 0; rr < BPW; ++rr) {
                 f32x4 a = xv[kc][rr][0], b = xv[kc][rr][1];
                 if (!real) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
                 a *= 16.0f; b *= 16.0f;
@@ -209,7 +213,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 split2v(b[0], b[1], pc, 2);
                 split2v(b[2], b[3], pc, 3);
 #pragma unroll
-                for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[((kc * 4 + 2 * st + rr) * 2 + p) * 256 + lane * 4] = pc[p];
+                for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[((kc * 4 + BPW * st + rr) * 2 + p) * 256 + lane * 4] = pc[p];
             }
     }
     const float mL = (C::S2 ? (n & 3) : (n & 7)) != 0 ? 1.f : 0.f, mR = (C::S2 || (n & 7) != 7) ? 1.f : 0.f;
@@ -413,16 +417,21 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     // stands between the second barrier and the stores).  Inside a chain the residual is what this wave stored one stage ago, into
     // a buffer this CU read two stages ago: the load goes past the vector cache (sc0: miss in the CU's cache, served by the XCD's L2, where the store landed).
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, 0x7fffffff, 0x00027000);
-    f32x4 rs[MT / 2][NB], psh[MT / 2];
+    constexpr int KT = C::KT, NSW = C::NS;
+    f32x4 rs[KT][NB], psh[KT];
 #pragma unroll
-    for (int i = 0; i < MT / 2; ++i) {
-        const int nch = 16 * (2 * i + st) + 4 * ge;
+    for (int i = 0; i < KT; ++i) {
+        const int mtk = NSW * i + st;                    // the i-th output tile this wave keeps (may not exist when MT % NS != 0)
+        const int nch = 16 * (mtk < MT ? mtk : MT - 1) + 4 * ge;
         psh[i] = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
         for (int r = 0; r < NB; ++r)
             if (C::RES && !PARTIAL) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
     }
     __syncthreads();                                     // every wave is done reading the fragments
+    constexpr bool HANDOFF = !__is_same(CN, void);
+    f32x4 vout[KT][NB];
+    if constexpr (NSW == 2) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) == st) continue;
@@ -430,8 +439,6 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         for (int r = 0; r < NB; ++r) *(f32x4 *)&Red[(((st * (MT / 2) + (mt >> 1)) * NB + r) * 64 + lane) * 4] = acc[mt][r];
     }
     __syncthreads();
-    constexpr bool HANDOFF = !__is_same(CN, void);
-    f32x4 vout[MT / 2][NB];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) != st) continue;
@@ -450,6 +457,33 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
             if (HANDOFF) vout[mt >> 1][r] = v;
         }
     }
+    } else {
+        // four streams: every wave publishes the tiles it does not keep, then adds the other three streams' copies of its own tiles in
+        // stream order 0 + 1 + 2 + 3 (fixed: results do not depend on the position in the batch)
+        static_assert(!PARTIAL, "the four-stream schedule reduces inside the workgroup");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt % NSW == st) continue;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) *(f32x4 *)&Red[(((st * MT + mt) * NB + r) * 64 + lane) * 4] = acc[mt][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt % NSW != st) continue;
+            const int nch = 16 * mt + 4 * ge;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                f32x4 v = st == 0 ? acc[mt][r] : *(const f32x4 *)&Red[(((0 * MT + mt) * NB + r) * 64 + lane) * 4];
+#pragma unroll
+                for (int so = 1; so < NSW; ++so) v += so == st ? acc[mt][r] : *(const f32x4 *)&Red[(((so * MT + mt) * NB + r) * 64 + lane) * 4];
+                v = v * inv_p + psh[mt / NSW];
+                if (C::RES) v += rs[mt / NSW][r];
+                if (STORE && real) *(f32x4 *)&Y[((size_t)f * C::PIXO + pixe + 8 * r) * COUT + nch] = v;
+                if (HANDOFF) vout[mt / NSW][r] = v;
+            }
+        }
+    }
     if constexpr (HANDOFF) {
         // ---- hand the block output to the next stage: x 16, split, into the fragment layout of ITS expand GEMM.  This lane holds
         //      channels 16 mt + 4 ge .. + 3 of pixel (r, ne): k32 step mt >> 1, lane group 2 (mt & 1) + (ge >> 1), dwords 2 (ge & 1), + 1 ----
@@ -457,11 +491,11 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         __syncthreads();                                 // everybody has read the exchange buffer (it aliases the fragments)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if ((mt & 1) != st) continue;
+            if (mt % C::NS != st) continue;
             const int kc = mt >> 1, lg = (2 * (mt & 1) + (ge >> 1)) * 16, dw = 2 * (ge & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4 v = real ? vout[mt >> 1][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = real ? vout[mt / C::NS][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
                 unsigned a0, b0, a1, b1;
                 split2h(v[0], v[1], a0, b0);
                 split2h(v[2], v[3], a1, b1);
@@ -785,6 +819,33 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
         lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
 }
 
+// Small batches (round 4; BASELINE configs[1] is 128 faces): features.8 .. 14 as ONE launch with ONE face per workgroup and FOUR waves
+// per face.  Below ~400 faces the chain above leaves most CUs empty and its workgroups walk 12-18 hidden groups per block with two
+// waves, so those batches ran the blocks one launch each, hidden-sliced over workgroups (PARTIAL) with a reduce launch behind every
+// block: 14 launches, 135 us at B = 128.  Four streams per face halve a face's critical path, the partial sums of the four streams
+// meet in LDS (no global round trip, no reduce kernel), and the block output stays on chip as the next stage's fragments.
+using L8s = LbCfg<     64, 384,  64, true,  2, SYN_L8_PPF, 1, false, 4>;
+using L11s = LbCfg<    64, 384,  96, false, 2, SYN_L11_PPF, 1, false, 4>;
+using L12s = LbCfg<    96, 576,  96, true,  1, 3, 1, false, 4>;
+using L14s = LbCfg<    96, 576, 160, false, 1, 2, 1, true, 4>;
+constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
+constexpr int kChainFaceDwS = cmax4(L8s::FACE_DW, L11s::FACE_DW, L12s::FACE_DW, L14s::FACE_DW);
+constexpr int kChainLdsDwS = L8s::FPW * kChainFaceDwS + L8s::NW * L8s::TB_DW;
+static_assert(kChainLdsDwS * 4 <= 160 * 1024, "one workgroup per CU");
+
+__global__ __launch_bounds__(L8s::NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void fused_chain_lb_small_kernel(LbChainArgs ca, int B) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDwS];
+    lb_stage<L8s, L8s, true, false, kChainFaceDwS>(smem, ca.s[1], B, pt_, tk);
+    lb_stage<L8s, L8s, false, false, kChainFaceDwS>(smem, ca.s[2], B, pt_, tk);
+    lb_stage<L8s, L11s, false, false, kChainFaceDwS>(smem, ca.s[3], B, pt_, tk);
+    lb_stage<L11s, L12s, false, false, kChainFaceDwS>(smem, ca.s[4], B, pt_, tk);
+    lb_stage<L12s, L12s, false, false, kChainFaceDwS>(smem, ca.s[5], B, pt_, tk);
+    lb_stage<L12s, L14s, false, false, kChainFaceDwS, false>(smem, ca.s[6], B, pt_, tk);
+    lb_stage<L14s, void, false, false, kChainFaceDwS>(smem, ca.s[7], B, pt_, tk);
+}
+
 // y = (slice 0 + slice 1 + ... in this order) / (16 Sp) + BN shift (+ x): one thread per four channels of a pixel
 template <class C>
 __global__ __launch_bounds__(256) void lb_reduce_kernel(const float *__restrict__ part, int S, const float *__restrict__ Tlb,
@@ -828,10 +889,12 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 }
 
 // The chain launch: mode 0 = off (one launch per block), 1 = features.8-13, 2 = features.8-14, 3 = features.7-14 (SYN_LB_CHAIN; default 3)
-int lb_chain_mode(int B) {
+constexpr int kChainMin = 384;          // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
+constexpr int kSmallChainMax = 256;     // the one-face-per-workgroup chain: one round of workgroups
+int lb_chain_mode(int B, bool small) {
     static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
-    constexpr int chain_min = 384;      // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
-    if (chain <= 0 || B < chain_min) return 0;
+    if (chain <= 0) return 0;
+    if (B < kChainMin) return (small && B <= kSmallChainMax) ? 2 : 0;      // (2 = features.8 .. 14: launch_fused_chain_lb picks the small-batch kernel)
     return chain > 3 ? 3 : chain;
 }
 // a[i] = the arguments of features.(first + i), first = 7 | 8, first + n_blocks - 1 = 13 | 14; false: not applicable
@@ -845,6 +908,11 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int
     }
     if (first == 8) ca.s[0] = ca.s[1];
     if (last == 13) ca.s[7] = ca.s[6];
+    if (B < kChainMin) {
+        if (first != 8 || last != 14) return false;
+        fused_chain_lb_small_kernel<<<B, L8s::NT, 0, s>>>(ca, B);
+        return true;
+    }
     const int grid = (B + L8::FPW - 1) / L8::FPW;
     if (first == 7) fused_chain_lb_kernel<true, true><<<grid, L8::NT, 0, s>>>(ca, B);
     else if (last == 14) fused_chain_lb_kernel<false, true><<<grid, L8::NT, 0, s>>>(ca, B);

@@ -83,7 +83,7 @@ constexpr int lb_table_floats(int hid) { return (hid / 32) * 12 * 32; }
 bool launch_fused_block_lb(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // features.first .. first + n - 1 of every face in ONE launch (a[i]: features.(first + i)).  lb_chain_mode: 3 = features.7-14,
 // 2 = features.8-14, 1 = features.8-13, 0 = batch too small / SYN_LB_CHAIN=0 (launch them one by one)
-int lb_chain_mode(int B);
+int lb_chain_mode(int B, bool small = true);       // small: batches below the chain threshold may take the one-face-per-workgroup chain (features.8-14, mode 2)
 bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int B, hipStream_t s);
 // 4x4 blocks (features.15-17), fused_block_lb4.hip: the same fragments and constants, but one contiguous run per hidden group
 // Glb [group HID/32]: Alb_e fragments of the group's two hidden tiles [tile 2][k32 step][piece 2][64][4] | Alb_p fragments

@@ -299,7 +299,7 @@ struct syn_handle {
     float *d_det = nullptr;
     void *dws = nullptr;
     size_t dws_bytes = 0;
-    int early_rm = 1023;            // SYNERGY_HIP_EARLY_RM (bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
+    int early_rm = 2047;            // SYNERGY_HIP_EARLY_RM (bit 10: features.8-14 of batches <= 256 as ONE four-stream chain launch, fused_block_lb.hip; bit 4: the ResNet-50 7x7 stem on the matrix pipe, resnet_kernels.hip; bits 5, 6: features.5, 6): bit (f-2) set -> features.f (f = 2..4) runs the row-marching kernel; bit 3: the
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
@@ -508,7 +508,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         }
         // features.7-14 (or 8-14, 8-13) as one chain launch (fused_block_lb.hip): every workgroup carries its faces through the blocks
         const int chain_mode = (h->fusion >= 2 && L.kind == PW && L.relu6 && (L.feature == 7 || L.feature == 8) && (h->early_rm & 128) && (h->early_rm & 512) &&
-                                prof_feature < 0) ? syn::lb_chain_mode(B) : 0;
+                                prof_feature < 0) ? syn::lb_chain_mode(B, (h->early_rm & 1024) != 0) : 0;
         const int chain_first = chain_mode == 3 ? 7 : 8, chain_last = chain_mode == 1 ? 13 : 14, chain_n = chain_last - chain_first + 1;
         if (chain_mode && L.feature == chain_first && !any_unsafe16(chain_first, chain_last) && (stop_feature < 0 || stop_feature >= chain_last) && li + 3 * chain_n <= nl &&
             n.max_hidden >= 2048 + 2 * (size_t)64 * 96 + 16 * 160 + 64 * 64) {

@@ -229,7 +229,9 @@ def test_calibration_on_real_crops_decides_what_the_interval_estimate_cannot(pac
     cd = torch.from_numpy(crops).cuda()
     before = per_face_err(model.forward_crops_u8(cd).cpu().numpy(), want)
     print('before calibration', before.max())
-    assert before.max() > 10 * TOL, before.max()                  # the accepted schedule IS wrong on this checkpoint
+    # the accepted schedule IS wrong on this checkpoint (2.2e-4 on the x16 register-resident kernels every batch size runs since the
+    # small-batch chain of round 4; 1.7e-3 on the tiled kernels at input scale 1 that batches below 32 faces ran before)
+    assert before.max() > 1.5 * TOL, before.max()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         n = model.calibrate(cd[:8])

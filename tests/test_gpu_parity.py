@@ -215,6 +215,37 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
     assert torch.equal(got, ref[idx.cuda()])
 
 
+@pytest.mark.parametrize('B', [1, 3, 31, 32, 127, 128, 255, 256, 257])
+def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd, B):
+    """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, four waves per
+    face, the partial sums of the four streams added in LDS (fused_chain_lb_small_kernel) -- instead of 14 hidden-sliced + reduce
+    launches (or the tiled kernels below 32 faces).  Same arithmetic in another summation order: equal to the block-by-block schedule
+    (SYNERGY_HIP_EARLY_RM without bit 10) to fp32 rounding on distinct faces, bitwise independent of the position in the batch, and
+    every face within the tolerance of the oracle."""
+    import torch
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    crops = synth.make_crops(B, seed=3100 + B)
+    cd = torch.from_numpy(crops).cuda()
+    m_new = SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    os.environ['SYNERGY_HIP_EARLY_RM'] = '1023'
+    try:
+        m_old = SynergyNet(device='cuda:0', pack=pack, backbone_state=backbone_sd)
+    finally:
+        os.environ.pop('SYNERGY_HIP_EARLY_RM', None)
+    got, ref = m_new.forward_crops_u8(cd), m_old.forward_crops_u8(cd)
+    assert rel_max(got.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    if B >= 3:                                        # the same face at another position of another batch: the same bits
+        perm = torch.roll(torch.arange(B), 1).cuda()
+        assert torch.equal(m_new.forward_crops_u8(cd[perm].contiguous()), got[perm])
+        if B < 32:                                    # (from 32 faces on features.15-17 run hidden-sliced: another summation order, 1e-6)
+            assert torch.equal(m_new.forward_crops_u8(cd[:2].contiguous()), got[:2])
+    pick = np.unique(np.r_[0, B // 2, B - 1])
+    want, _ = backbone_torch.mobilenet_v2_forward(backbone_sd, synth.normalize_crops(crops[pick]))
+    assert rel_max(got[torch.from_numpy(pick).cuda()].cpu().numpy(), want.numpy()) < 1e-4
+
+
 @pytest.mark.parametrize('B', [33, 128, 200, 224, 352, 353, 383, 385, 480, 511, 513, 575, 577, 640, 768, 769, 1030, 2307])
 def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_early, backbone_sd, B):
     """The early blocks switch kernels with the batch size (tiled below a few hundred faces, row-marching with 1, 2 or 4 units
