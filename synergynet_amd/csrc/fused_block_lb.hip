@@ -126,6 +126,9 @@ struct LbCfg {
     static constexpr int NW = FPW * NS, NT = NW * 64;
     static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
     static constexpr int KT = (MT + NS - 1) / NS;        // output tiles a wave keeps (mt % NS == its stream)
+    // four-stream schedule: one wave per SIMD and nobody to cover an L2 round trip, but 512 registers -- ALL project fragments of a group
+    // (or four of them) are requested half way through its depthwise phase, not during its last quarter
+    static constexpr bool EARLYP = NS == 4 && !S2_;
     static constexpr int RED_DW = (NS == 2 ? 1 : NS) * MT * NB * 256;   // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]; NS > 2: [stream][MT][NB][lane][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
     static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
@@ -306,7 +309,12 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 #pragma unroll
         for (int th = 0; th < 4; ++th) {
             const int t = th >> 1, hf = th & 1;
-            if (th == 3) fetch_p(0);                    // first project fragments: in flight behind the last depthwise pass
+            if (th == 3 && !C::EARLYP) fetch_p(0);      // first project fragments: in flight behind the last depthwise pass
+            if (th == 2 && C::EARLYP) {
+#pragma unroll
+                for (int i = 0; i < C::PPF; ++i)
+                    if (i < MT) fetch_p(i);
+            }
             const int c0 = 16 * t + 2 * hf;             // + 4 g per lane group
             f32x2 w[9];
 #pragma unroll
@@ -372,7 +380,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         const bool more = G + C::NS < gend;
 #pragma unroll
         for (int i = 1; i < C::PPF; ++i)
-            if (i < MT) fetch_p(i);
+            if (i < MT && !C::EARLYP) fetch_p(i);
         if (more) {
             if (!C::TLATE) fetch_t(G + C::NS);
             if (C::EPF != KE) {                                  // (one k32 step of them: the other slot is still being read -- see above for EPF == KE)
@@ -824,9 +832,9 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
 // waves, so those batches ran the blocks one launch each, hidden-sliced over workgroups (PARTIAL) with a reduce launch behind every
 // block: 14 launches, 135 us at B = 128.  Four streams per face halve a face's critical path, the partial sums of the four streams
 // meet in LDS (no global round trip, no reduce kernel), and the block output stays on chip as the next stage's fragments.
-using L8s = LbCfg<     64, 384,  64, true,  2, SYN_L8_PPF, 1, false, 4>;
-using L11s = LbCfg<    64, 384,  96, false, 2, SYN_L11_PPF, 1, false, 4>;
-using L12s = LbCfg<    96, 576,  96, true,  1, 3, 1, false, 4>;
+using L8s = LbCfg<     64, 384,  64, true,  2, 4, 1, false, 4>;
+using L11s = LbCfg<    64, 384,  96, false, 2, 4, 1, false, 4>;
+using L12s = LbCfg<    96, 576,  96, true,  1, 4, 1, false, 4>;
 using L14s = LbCfg<    96, 576, 160, false, 1, 2, 1, true, 4>;
 constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
 constexpr int kChainFaceDwS = cmax4(L8s::FACE_DW, L11s::FACE_DW, L12s::FACE_DW, L14s::FACE_DW);
