@@ -345,10 +345,12 @@ __global__ __launch_bounds__(64) void recon_prep_f16_kernel(const float *__restr
 // PK (round 4, the reference's PACKED [B,3,n_vert] layout, synergy3DMM.py:131-147): rows are n_vert floats apart, so row r starts
 // 4 r n_vert bytes into the tensor and a fixed 128-vertex run shares its first and last 128-byte line with the neighbouring
 // workgroups' runs -- partial lines written at different times, which HBM takes as read-modify-writes (same bytes through L2 as the
-// pitched layout by the counters, 3.0-3.5 TB/s against 4.4-5.4).  Here a workgroup still COMPUTES 128 vertices, [96 g, 96 g + 128),
-// but STORES per row the 96 of them that start on a line boundary of THAT row: [96 g + s_r, 96 g + 96 + s_r), s_r = -r n_vert mod 32
-// (96 = three whole lines, so every group shares the shift of its row and the windows tile the row; group 0 also writes the s_r
-// vertices in front of its window).  +33 % arithmetic for whole-line stores: the kernel is bound by the stores, not by the pipes.
+// pitched layout by the counters, 3.0-3.5 TB/s against 4.4-5.4).  Here a workgroup COMPUTES WPG tiles, [W g, W g + 32 WPG) with
+// W = 32 (WPG - 1), but STORES per row the W of them that start on a line boundary of THAT row: [W g + s_r, W g + W + s_r),
+// s_r = -r n_vert mod 32 (W = whole lines, so every group shares the shift of its row and the windows tile the row; group 0 also
+// writes the s_r vertices in front of its window).  The kernel is bound by its per-tile latency chain as much as by the stores, so the
+// recomputed tile costs its share of iterations: WPG = 4 (+33 %) 0.166-0.180 ms, WPG = 8 (+14 %, eight waves, one workgroup per CU,
+// 832 workgroups) 0.153 ms = 4.28 TB/s at B = 1024 -- within 5 % of the pitched layout (0.146).
 template <int WPG, bool FAST, bool PROF = false, bool PK = false>
 __global__ __launch_bounds__(WPG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restrict__ basis3, float *__restrict__ out, int B,
@@ -365,8 +367,9 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
     if ((int)(blockIdx.x >> 3) >= per_xcd || unit >= n_units) return;
     const int tg = unit / n_split, split = unit - tg * n_split;
     constexpr int RUN = WPG * 32;                                             // vertices per row and workgroup
-    static_assert(!PK || (!FAST && WPG == 4), "the packed-row schedule stores 96 of 128 vertices per workgroup through the guarded path");
-    int T = tg * (PK ? 3 : WPG) + wave;
+    static_assert(!PK || !FAST, "the packed-row schedule has its own store path");
+    constexpr int PKW = (WPG - 1) * 32;                                       // PK: vertices a workgroup stores per row (WPG - 1 whole lines)
+    int T = tg * (PK ? WPG - 1 : WPG) + wave;
     T = T < n_tiles ? T : n_tiles - 1;
     const int j = lane & 31, h = lane >> 5;
 
@@ -384,7 +387,7 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
     const int ft0 = ft_lo + split * ftiles_per_split;
     int ft1 = ft0 + ftiles_per_split;
     ft1 = ft1 < ft_hi ? ft1 : ft_hi;
-    const int v_base = tg * (PK ? 96 : RUN);
+    const int v_base = tg * (PK ? PKW : RUN);
     if (ft0 >= ft1) return;                          // (workgroup-uniform)
 
     u32x4 pf[NPF];                                   // this thread's quads of the next operand tile
@@ -470,33 +473,34 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
                 // code, so park()'s wait is a counted vmcnt and the stores stay in flight into the next tile (with branches around them
                 // every tile waited for the acknowledgement of its stores: 0.180 ms).  What is left -- the vertices in front of the
                 // first window (group 0) and a row's ragged last float4 (last group) -- follows park() under a workgroup-uniform branch.
+                constexpr int LPRK = PKW / 4, RPIK = WPG * 64 / LPRK, NIT = (96 + RPIK - 1) / RPIK;     // lanes per row, rows per instruction, instructions
                 int tid_ = threadIdx.x;
                 asm volatile("" : "+v"(tid_));
-                const int seg = tid_ % 24, rsub = tid_ / 24;
+                const int seg = tid_ % LPRK, rsub = tid_ / LPRK;
                 const int nv32 = n_vert & 31;
                 const long long r0 = 3ll * f0;
                 long long tile_rows = 3ll * B - r0;
                 tile_rows = tile_rows < 96 ? tile_rows : 96;
                 const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)r0 * n_vert, 0, (int)(tile_rows * n_vert * 4), 0x00027000);
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    const int rr = 10 * k + rsub;                                  // row of the face tile: face f0 + rr / 3, coordinate rr % 3
+                for (int k = 0; k < NIT; ++k) {
+                    const int rr = RPIK * k + rsub;                                // row of the face tile: face f0 + rr / 3, coordinate rr % 3
                     const int sh = (32 - (int)(((r0 + rr) * nv32) & 31)) & 31;     // the row's line boundaries lie at vertices = sh mod 32
                     const int vq = v_base + sh + 4 * seg;
                     const float *sp = &stage[(rr < 96 ? rr : 95) * SS + sh + 4 * seg];     // (4-byte aligned: sh is any number)
                     const f32x4 vv = {sp[0], sp[1], sp[2], sp[3]};
-                    const bool ok = rsub < 10 && rr < 96 && vq + 3 < n_vert;       // (rows past the batch are past the resource)
+                    const bool ok = rsub < RPIK && rr < 96 && vq + 3 < n_vert;     // (rows past the batch are past the resource)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rs_o, ok ? (unsigned)(rr * n_vert + vq) * 4u : 0x80000000u, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 park(buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (tg == 0 || v_base + 96 + 31 + 3 >= n_vert) {                    // (workgroup-uniform) first / last group of the rows
+                if (tg == 0 || v_base + PKW + 31 + 3 >= n_vert) {                   // (workgroup-uniform) first / last group of the rows
 #pragma unroll 1
-                    for (int k = 0; k < 10; ++k) {
-                        const int rr = 10 * k + rsub;
+                    for (int k = 0; k < NIT; ++k) {
+                        const int rr = RPIK * k + rsub;
                         const long long r = r0 + rr;
-                        if (rsub >= 10 || rr >= 96 || r >= 3ll * B) continue;
+                        if (rsub >= RPIK || rr >= 96 || r >= 3ll * B) continue;
                         const int sh = (32 - (int)((r * nv32) & 31)) & 31;
                         const int vq = v_base + sh + 4 * seg;
                         if (vq < n_vert && vq + 3 >= n_vert) {                      // the ragged last float4 of the row
@@ -563,14 +567,18 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     // the reference's packed rows (pitch == n_vert, dense mesh, a line-aligned tensor): the whole-line schedule PK of the kernel
     const bool pk = pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !getenv("SYN_RECON_NO_PK");
-    const int n_groups = pk ? (n_vert + 95) / 96 : (n_tiles + WPG - 1) / WPG;           // a workgroup = WPG consecutive vertex tiles (PK: a stride of three)
+    static const int pk_wpg = getenv("SYN_RECON_PK_WPG") ? atoi(getenv("SYN_RECON_PK_WPG")) : 8;       // tiles a PK workgroup computes: 8 (stores 7 lines per row) | 4 (stores 3)
+    const int pkw = (pk_wpg == 8 ? 7 : 3) * 32;
+    const int n_groups = pk ? (n_vert + pkw - 1) / pkw : (n_tiles + WPG - 1) / WPG;       // a workgroup = WPG consecutive vertex tiles (PK: a stride of WPG - 1)
     static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 1664;   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
     static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
     // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
     auto run = [&](int lo, int hi, bool fast) {
         const int nft = hi - lo;
         if (nft <= 0) return;
-        int n_split = (wg_target + n_groups - 1) / n_groups;
+        // (eight-wave PK workgroups, one per CU: half the target -- 832: 0.153 ms, 1664: 0.167, 512: 0.156 at B = 1024)
+        const int target = (pk && pk_wpg == 8 && !getenv("SYN_RECON_WGS")) ? wg_target / 2 : wg_target;
+        int n_split = (target + n_groups - 1) / n_groups;
         n_split = n_split < 1 ? 1 : n_split;
         n_split = n_split > nft ? nft : n_split;
         const int per = (nft + n_split - 1) / n_split;
@@ -590,6 +598,8 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
             fprintf(stderr, "recon prof workgroups %llu\n", hst[7]);
         } else if (fast)
             recon_f16_kernel<WPG, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
+        else if (pk && pk_wpg == 8)
+            recon_f16_kernel<8, false, false, true><<<grid, 8 * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
         else if (pk)
             recon_f16_kernel<WPG, false, false, true><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
         else
