@@ -393,8 +393,8 @@ bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
 bool launch_fused_block_lb4(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Glb || a.prof) return false;
     if (B < lb4_min_batch()) {
-        constexpr int sl_min = 32;      // below: the tiled kernel's own sliced schedule
-        if (B < sl_min) return false;
+        // (round 4: hidden-sliced from ONE face on -- thirty one-group workgroups per face quad and a reduce launch take ~15 us per block
+        // where the tiled kernel's own sliced schedule, the choice below 32 faces until then, took 43-45: B = 1 0.333 -> ms)
         switch (feature) {
             case 15: case 16: return launch_lb4_sliced<Q15>(a, B, s);
             case 17: return launch_lb4_sliced<Q17>(a, B, s);
