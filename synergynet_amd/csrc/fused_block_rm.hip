@@ -70,7 +70,7 @@ __device__ __forceinline__ float from_right(float v) {
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false, int WREG_ = 0>
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false, int WREG_ = 0, int NBD_ = 1>
 struct RmCfg {
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
@@ -87,6 +87,13 @@ struct RmCfg {
     static constexpr int NQ = COUT / 8;                  // valid register quads of the 32-row project tile
     static constexpr int NB = S == 1 ? 1 : 2;            // column blocks per input row
     static constexpr int HO = S == 2 ? H / 2 : H;
+    // NBD > 1 (small batches): a unit is a BAND of HB output rows of its face(s), so that B faces give NBD x B / NF units to spread over the
+    // chip.  A band marches the input rows its outputs touch -- stride 1: r0 - 1 .. r0 + HB (HB + 2 steps, padded to the row ring's multiple
+    // of 3), stride 2: the row pairs r0 - 1 .. r0 + HB - 1 (2 HB + 2 steps) -- rows outside the image expand to zeros (ReLU6 ceiling 0, as the
+    // padding columns do); every band runs the same number of steps (the units of a workgroup share its barriers).
+    static constexpr int NBD = NBD_, HB = HO / NBD;
+    static constexpr int BSTEPS = S == 1 ? cdivr(HB + 2, 3) * 3 : 2 * (HB + 1);
+    static_assert(HO % NBD == 0 && (NBD == 1 || !LEAN_), "bands: equal heights; not implemented for the one-slot (LEAN) sums");
     // A workgroup carries U independent units (a unit = NF faces marching together) on one barrier: NG compute waves each
     // (wave ids 0 .. U*NG-1) and one service wave each (ids U*NG ..).  One big workgroup, not several small ones: the hardware
     // reserves ceil(waves / 4) wave slots on EVERY SIMD per workgroup, so two 5-wave workgroups never share a CU at 3 waves
@@ -174,7 +181,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
         // =====================================================================================================================
         for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
             const int unit = ub + uw;
-            const int f_in = unit * C::NF + ia, f_out = unit * C::NF + oa;
+            const int fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;     // face unit, first output row of the band
+            const int f_in = fu * C::NF + ia, f_out = fu * C::NF + oa;
             const bool out_ok = (unsigned)ocol < (unsigned)HO && f_out < B;
             f32x4 xr[C::FR][2];
             // fragment b*KS + s = channels 16s + 8h .. +7 of the pixels of block b
@@ -183,7 +191,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 for (int fr = 0; fr < C::FR; ++fr) {
                     const int b = fr / C::KS, sk = fr % C::KS, c0 = 16 * sk + 8 * h;
                     xr[fr][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; xr[fr][1] = xr[fr][0];
-                    if (c0 + 8 <= C::CIN && (unsigned)icol[b] < (unsigned)H && f_in < B) {
+                    if (c0 + 8 <= C::CIN && (unsigned)icol[b] < (unsigned)H && f_in < B && (C::NBD == 1 || (unsigned)y < (unsigned)H)) {
                         const float *src = X + ((size_t)(f_in * H + y) * H + icol[b]) * C::CIN + c0;
                         xr[fr][0] = *(const f32x4 *)src; xr[fr][1] = *(const f32x4 *)(src + 4);
                     }
@@ -230,6 +238,29 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     if (out_ok) *(f32x4 *)(Y + ((size_t)(f_out * HO + yo) * HO + ocol) * C::COUT + 8 * q + 4 * h) = v;
                 }
             };
+            if (C::NBD > 1) {
+                // band: local step k marches input row gy0 + k; the sums finalized in step k are reduced in step k + 1
+                constexpr int NS = C::BSTEPS, HB = C::HB;
+                const int gy0 = C::S == 1 ? r0 - 1 : 2 * (r0 - 1);
+                load_row(gy0);
+                store_row(0);
+                load_row(gy0 + 1);
+                SYNR_BARRIER();                              // (P)
+                for (int k = 0; k < NS; ++k) {
+                    if (C::S == 1) {
+                        if (k >= 3 && k < HB + 3) reduce_row(r0 + k - 3, (k - 1) & 1);       // output row r0 + k - 3 was finalized in step k - 1
+                        if (k >= 2) load_res(r0 + k - 2);
+                    } else {
+                        if (!(k & 1) && k >= 4) reduce_row(r0 + (k >> 1) - 2, ((k >> 1) - 1) & 1);      // pair k/2 - 1 finalized output row r0 - 1 + (k/2 - 1)
+                    }
+                    if (k + 1 < NS) store_row((k + 1) & 1);
+                    if (k + 2 < NS) load_row(gy0 + k + 2);
+                    SYNR_BARRIER();
+                }
+                if (C::S == 2) reduce_row(r0 + HB - 1, HB & 1);
+                else if (NS == HB + 2) reduce_row(r0 + HB - 1, (NS - 1) & 1);
+                continue;
+            }
             load_row(0);
             store_row(0);
             load_row(1);                                      // in flight across the barrier
@@ -290,10 +321,16 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     // stores nothing (its faces are >= B)
     for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
         const int unit = ub + uw;
-        const int f_in = unit * C::NF + ia;
+        const int fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;
+        const int f_in = fu * C::NF + ia;
         float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
+        float ehs[C::NB];                         // ... of the row being expanded (bands: 0 for the rows above / below the image)
 #pragma unroll
-        for (int b = 0; b < C::NB; ++b) ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? c6e : 0.0f;
+        for (int b = 0; b < C::NB; ++b) ehs[b] = ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? c6e : 0.0f;
+        auto row_ceiling = [&](int gy) {
+#pragma unroll
+            for (int b = 0; b < C::NB; ++b) ehs[b] = (unsigned)gy < (unsigned)H ? ehi[b] : 0.0f;
+        };
 
         // ---- expand one block of the row in slot `slot`: 16 hidden channels per lane, BN shift, ReLU6 (0 on padding lanes) ----
         auto expand = [&](int slot, int b, f32x16 &e, int cbo) {
@@ -312,7 +349,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 e = mac3r(ae[s], xb, e);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehi[b]);
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehs[b]);
         };
         // ---- finished depthwise row -> ReLU6 -> fp16 x2 pieces (in place: register 8s+e = K slot e of step s) -> project
         //      partial over this wave's 32 hidden channels -> LDS ----
@@ -405,11 +442,12 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 }
             }
             // input row y -> kernel row 2 of output row y-1 (dm), row 1 of y (dc), row 0 of y+1 (dn)
-            auto step = [&](int y, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
+            // (xslot: fragment slot of the row; fin / pslot: finalize dm into that partial-sum slot)
+            auto step = [&](int xslot, bool fin, int pslot, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
                 SYNR_LAP(5);
                 const int cbo = opaque_cb();
                 f32x16 e;
-                expand(y & 1, 0, e, cbo);
+                expand(xslot, 0, e, cbo);
                 SYNR_LAP(1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -431,20 +469,34 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 }
                 SYNR_LAP(3);
                 if (C::LEAN) SYNR_BARRIER();                   // the service wave has read the previous row's sums
-                if (y >= 1) finalize(dm, (y - 1) & (C::PSLOTS - 1));
+                if (fin) finalize(dm, pslot);
                 SYNR_LAP(4);
                 SYNR_BARRIER();
                 nsteps += 1;
             };
-            for (int y = 0; y < H; y += 3) {
-                step(y, d2, d0, d1);
-                step(y + 1, d0, d1, d2);
-                step(y + 2, d1, d2, d0);
+            if (C::NBD > 1) {
+                // band: step k marches input row r0 - 1 + k and completes output row r0 + k - 2 (the accumulators of rows r0 - 2, r0 - 1 are
+                // never finalized; padded steps k >= HB + 2 complete nothing)
+                auto bstep = [&](int k, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
+                    row_ceiling(r0 - 1 + k);
+                    step(k & 1, k >= 2 && k < C::HB + 2, k & 1, dm, dc, dn);
+                };
+                for (int k = 0; k < C::BSTEPS; k += 3) {
+                    bstep(k, d2, d0, d1);
+                    bstep(k + 1, d0, d1, d2);
+                    bstep(k + 2, d1, d2, d0);
+                }
+            } else {
+                for (int y = 0; y < H; y += 3) {
+                    step(y & 1, y >= 1, (y - 1) & (C::PSLOTS - 1), d2, d0, d1);
+                    step((y + 1) & 1, true, y & (C::PSLOTS - 1), d0, d1, d2);
+                    step((y + 2) & 1, true, (y + 1) & (C::PSLOTS - 1), d1, d2, d0);
+                }
+                // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
+                if (C::LEAN) SYNR_BARRIER();
+                finalize(d2, (H - 1) & (C::PSLOTS - 1));
+                SYNR_BARRIER();
             }
-            // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
-            if (C::LEAN) SYNR_BARRIER();
-            finalize(d2, (H - 1) & (C::PSLOTS - 1));
-            SYNR_BARRIER();
         } else {
             f32x16 dcur, dnext;
             {
@@ -456,14 +508,17 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     for (int t = 0; t < 4; ++t) { dcur[4 * q + t] = sh[t]; dnext[4 * q + t] = 0.f; }
                 }
             }
-            for (int y = 0; y < H; y += 2) {
-                const int yo = y >> 1;
+            // pairs of input rows (2 yo, 2 yo + 1); bands: yo = r0 - 1 .. r0 + HB - 1, the first pair only starts output row r0
+            const int np = C::NBD > 1 ? C::HB + 1 : HO, p0 = C::NBD > 1 ? r0 - 1 : 0;
+            for (int lp = 0; lp < np; ++lp) {
+                const int yo = p0 + lp;                      // (even rows travel in fragment slot 0, odd rows in slot 1)
                 // ---- even input row 2yo: kernel row 1 of output row yo ----
                 {
+                    if (C::NBD > 1) row_ceiling(2 * yo);
                     SYNR_LAP(5);
                     const int cbo = opaque_cb();
                     f32x16 e;
-                    expand(y & 1, 0, e, cbo);                                // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
+                    expand(0, 0, e, cbo);                                    // U: columns 2x-1 (tap 3) and, from the right lane, 2x+1 (tap 5)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (q >= nq_live) break;
@@ -473,7 +528,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                         taps2(dcur, q, Filt + cbo + 8 * q, 3, 5, c4, r4, false);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    expand(y & 1, 1, e, cbo);                                // V: column 2x (tap 4)
+                    expand(0, 1, e, cbo);                                    // V: column 2x (tap 4)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (q >= nq_live) break;
@@ -486,10 +541,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 }
                 // ---- odd input row 2yo+1: kernel row 2 of output row yo, kernel row 0 of output row yo+1 ----
                 {
+                    if (C::NBD > 1) row_ceiling(2 * yo + 1);
                     SYNR_LAP(5);
                     const int cbo = opaque_cb();
                     f32x16 e;
-                    expand((y + 1) & 1, 0, e, cbo);
+                    expand(1, 0, e, cbo);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (q >= nq_live) break;
@@ -500,7 +556,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                         taps2(dnext, q, Filt + cbo + 8 * q, 0, 2, c4, r4, true);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    expand((y + 1) & 1, 1, e, cbo);
+                    expand(1, 1, e, cbo);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (q >= nq_live) break;
@@ -509,7 +565,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     SYNR_LAP(3);
-                    finalize(dcur, yo & 1);
+                    if (C::NBD == 1 || lp >= 1) finalize(dcur, lp & 1);
                     SYNR_LAP(4);
                     dcur = dnext;
                     SYNR_BARRIER();
@@ -526,9 +582,14 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     }
 }
 
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 template <class C>
 static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
-    const int n_units = (B + C::NF - 1) / C::NF;
+    const int n_units = (B + C::NF - 1) / C::NF * C::NBD;
     const int cap = 256 * wgs_per_cu, wgs = (n_units + C::U - 1) / C::U;  // persistent: as many workgroups as the CUs hold at once
     const int grid = wgs < cap ? wgs : cap;
     if (a.prof)
@@ -549,20 +610,32 @@ template <int U> using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, (U == 4 ? 4 : 
 template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG>;                   // features.3   30            U x (5 + 1) waves
 template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
 template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true>;             // features.5/6 15            U x (6 + 1) waves, two faces per unit, 4 per SIMD
+// small batches: NBD row bands per face (RmCfg::NBD).  A band march has a floor of its own -- its steps are a dependent chain of ~1.3-2 us
+// each whatever the batch (features.2: 12 steps + prologue = 16-18 us at B = 1, features.3: 25) -- against 12 us for the tiled kernels, so the
+// bands pay in a window: features.2 from ~40 faces (B = 64 / 128 / 256: 20 / 24 / 38 us against 24 / 36 / 57 tiled; six bands of five output
+// rows, one unit per workgroup, three workgroups per CU), features.3 from ~96 (B = 128: 28 against 34; three bands of ten rows, two units per
+// workgroup).  features.4 (two faces per unit: 21 against 23 us at B = 128, 34 against 32 at 256) and the other band counts / unit counts
+// tried (features.2: 3 or 5 bands 30 / 26 us, two units 29; features.3: 2 bands 29, 5 bands 38) are not instantiated.  tools/band_ab.sh.
+template <int U, int NBD> using R2b = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, U, false, 0, NBD>;
+template <int U, int NBD> using R3b = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG, NBD>;
+constexpr int kBand2Min = 40, kBand3Min = 96;
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p) return false;
     // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N).  The kernels are
     // persistent over 256 workgroups: 513 faces is where the smaller configuration needs a second round of workgroups (B = 640, us: features.2
     // 123 -> 91, features.4 74 -> 52, features.5/6 51 / 49 -> 43 / 42 with the larger one; at B = 512 the smaller one wins: 66 / 42 / 36 vs 88 / 50 / 41)
+    static const bool bands2 = env_int("SYN_RM_BAND2", 1) != 0, bands3 = env_int("SYN_RM_BAND3", 1) != 0;     // (0: the tiled kernels below the thresholds, as before round 4)
     switch (feature) {
         case 2:
             if (B >= 513) { launch_rm<R2<4>>(a, B, s, 1); return true; }
             if (B >= 352) { launch_rm<R2<2>>(a, B, s, 1); return true; }
+            if (bands2 && B >= kBand2Min) { launch_rm<R2b<1, 6>>(a, B, s, 3); return true; }
             return false;
         case 3:
             if (B >= 448) { launch_rm<R3<2>>(a, B, s, 1); return true; }
             if (B >= 200) { launch_rm<R3<1>>(a, B, s, 1); return true; }
+            if (bands3 && B >= kBand3Min) { launch_rm<R3b<2, 3>>(a, B, s, 1); return true; }
             return false;
         case 4:
             if (B >= 513) { launch_rm<R4<2>>(a, B, s, 1); return true; }
