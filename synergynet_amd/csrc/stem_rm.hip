@@ -19,7 +19,8 @@
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
 //   * ONE service wave per workgroup keeps the image rows of all units flowing: buffer loads one stage ahead (counted vmcnt, no
 //     branches) -> fp16 -> LDS row ring (8 slots per unit), one barrier per output row.
-// fp32 crops (forward_test): the F32 instantiation below (round 4); the tiled kernel of stem_block1.hip serves small batches.
+// fp32 crops (forward_test): the F32 instantiation below (round 4).  Small batches: row bands of a face from 112 faces on (StemRmCfg::NBD),
+// the tiled kernel of stem_block1.hip below that (and for fp32 crops below 480).
 #include "syn_internal.h"
 
 #include <cstdlib>
@@ -70,10 +71,19 @@ constexpr unsigned kPadF16 = 0x57F8u;     // 127.5 as fp16: the raw value of a z
 // ring holds two planes per image row, high pieces | low pieces, in the same (R, G, B, -) pixel layout; the filter is the plain BN-folded
 // one (nothing to fold the normalisation into) and the padding value is 0.  Domain: |x| < 6e4 (the reference's own normalisation gives
 // [-1, 1]); replaces the spatially tiled bf16 x3 kernel of stem_block1.hip for batches that fill the chip.
-template <int U_, int WPE_, bool F32_ = false>
+// NBD > 1 (small batches, uint8 crops): a workgroup round is ONE BAND of HB output rows of its U faces, so that B faces give NBD x B / U
+// rounds to spread over the chip (fused_block_rm.hip RmCfg::NBD is the same idea).  A band marches the stem rows r0 - 1 .. r0 + HB (HB + 2
+// steps, padded to the accumulator ring's multiple of 3); stem rows above / below the map contribute zeros (the ReLU6 multiplier of the
+// step is 0, as on the padding columns).  Step l reads image rows 2 (r0 - 1 + l) - 1 .. + 1 = local stages l and l + 1 (stage j = image rows
+// 2 (r0 - 2 + j), + 1), so the service wave runs TWO stages ahead of the compute waves: BSTG = BSTEPS + 2 stages and barriers per round on
+// both sides.
+template <int U_, int WPE_, bool F32_ = false, int NBD_ = 1>
 struct StemRmCfg {
     static constexpr int U = U_, WPE = WPE_;                                  // faces (units) per workgroup
     static constexpr bool F32 = F32_;
+    static constexpr int NBD = NBD_, HB = 60 / NBD;
+    static constexpr int BSTEPS = (HB + 2 + 2) / 3 * 3, BSTG = BSTEPS + 2;
+    static_assert(60 % NBD == 0 && (NBD == 1 || (!F32_ && BSTG % 2 == 0)), "bands: equal heights, uint8 crops, stages in pairs");
     static constexpr int NSV = F32 ? 2 : 1;                        // service waves (F32: splitting 2 x 360 floats per face and step is two waves' work)
     static constexpr int NCW = 2 * U, NT = (NCW + NSV) * 64;       // compute waves (face, half) + the service wave(s)
     static constexpr int SLOT_DW = (F32 ? 2 : 1) * kRowDw;         // one image row: plane of high pieces | (F32) plane of low pieces
@@ -221,6 +231,48 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
             }
         };
         Px8 va[ITER], vb[ITER];
+        if constexpr (C::NBD > 1) {
+            const int n_rounds = (B + C::U - 1) / C::U * C::NBD;
+            int iw = blockIdx.x, ij = 0;                       // round / stage `issue_b` requests next
+            auto issue_b = [&](Px8 (&v)[ITER]) {
+                const int fg = iw / C::NBD, band = iw - fg * C::NBD, fb0 = fg * C::U;
+                const int kk = band * C::HB - 2 + ij;          // global stage = image rows 2 kk, 2 kk + 1 (outside the image: nothing is read, zeros arrive)
+                const int kp = kk < 0 ? 0 : kk;
+                long long left = ((long long)B - fb0) * (long long)FACE_B;
+                if (left > (long long)(C::U * FACE_B)) left = C::U * FACE_B;
+                left -= (long long)kp * ROW2_B;
+                const int nrec = (left > 0 && kk >= 0 && iw < n_rounds) ? (int)left : 0;
+                const size_t base = iw < n_rounds ? (size_t)fb0 * FACE_B + (size_t)kp * ROW2_B : 0;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img) + base, 0, nrec, 0x00027000);
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    v[it].lo = __builtin_amdgcn_raw_buffer_load_b32(rs, gofs[it], 0, 0);
+                    v[it].hi = __builtin_amdgcn_raw_buffer_load_b32(rs, gofs[it] + 4, 0, 0);
+                }
+                if (++ij == C::BSTG) { ij = 0; iw += gridDim.x; }
+            };
+            auto consume_b = [&](const Px8 (&v)[ITER], int slot) {
+                unsigned *ringb = smem + slot * C::SLOT_DW;
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const unsigned T = __builtin_amdgcn_alignbyte(v[it].hi, v[it].lo, sft);
+                    const unsigned rg = __builtin_amdgcn_perm(0x64646464u, T, 0x04010400u);
+                    const unsigned bx = __builtin_amdgcn_perm(0x64646464u, T, 0x040c0402u);
+                    const f16x2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f};
+                    u32x2 o;
+                    o[0] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, rg) - k1024);
+                    o[1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(f16x2, bx) - k1024);
+                    if (live[it]) *reinterpret_cast<u32x2 *>(ringb + lofs[it]) = o;
+                }
+            };
+            issue_b(va);
+            for (int w = blockIdx.x; w < n_rounds; w += gridDim.x)
+                for (int j = 0; j < C::BSTG; j += 2) {         // local stage j -> ring slots (2 j) & 7, + 1
+                    issue_b(vb); __builtin_amdgcn_sched_barrier(0); consume_b(va, (2 * j) & 7); __syncthreads();
+                    issue_b(va); __builtin_amdgcn_sched_barrier(0); consume_b(vb, (2 * j + 2) & 7); __syncthreads();
+                }
+            return;
+        }
         issue(va);
         for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
             for (int k = 0; k < kHid; k += 4) {            // barrier (P), then the barriers that end compute steps 0 .. 58
@@ -257,9 +309,13 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
     const int cb = 4 * h;
     auto opaque_cb = [&]() { int v = cb; asm volatile("" : "+v"(v)); return v; };
 
-    for (int fb = blockIdx.x * C::U; fb < B; fb += gridDim.x * C::U) {
+    const int n_rounds = C::NBD > 1 ? (B + C::U - 1) / C::U * C::NBD : 0;
+    for (int fbw = C::NBD > 1 ? blockIdx.x : blockIdx.x * C::U; fbw < (C::NBD > 1 ? n_rounds : B); fbw += C::NBD > 1 ? gridDim.x : gridDim.x * C::U) {
+        const int fb = C::NBD > 1 ? (fbw / C::NBD) * C::U : fbw;                        // first face of the round
+        const int band_r0 = C::NBD > 1 ? (fbw - (fbw / C::NBD) * C::NBD) * C::HB : 0;   // first output row of the band
         const int f = fb + uw;
-        const float emul = (col_ok && f < B) ? inv_c6s : 0.0f;        // 0 on the out-of-image lanes: the depthwise zero padding
+        const float emul_f = (col_ok && f < B) ? inv_c6s : 0.0f;      // 0 on the out-of-image lanes: the depthwise zero padding
+        float emul = emul_f;                                          // ... of the row being computed (bands: 0 above / below the map)
         const bool st_ok = out_lane && f < B;
         const int yofs = (30 * c + j - 1) * 16 + 4 * h;             // (column, channel quad) inside an output row; < 2^31 elements per face
 
@@ -318,15 +374,17 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
                 for (int t = 0; t < 4; ++t) { d0[4 * q + t] = sh[t]; d1[4 * q + t] = 0.f; d2[4 * q + t] = 0.f; }
             }
         }
+        if (C::NBD > 1) __syncthreads();                       // (bands: the service wave is two stages ahead)
         __syncthreads();                                       // (P)
 
-        // stem row hy -> kernel row 2 of output row hy-1 (dm), row 1 of hy (dc), row 0 of hy+1 (dn)
-        auto step = [&](int hy, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
+        // stem row hy -> kernel row 2 of output row hy-1 (dm), row 1 of hy (dc), row 0 of hy+1 (dn);  sl0: ring slot of image row 2hy-1
+        // (2hy, 2hy+1 follow it); fin: output row hy-1 is complete and wanted
+        auto step = [&](int hy, int sl0, bool fin, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
             const int cbo = opaque_cb();
             // ---- im2col B operand: image rows 2hy-1 (kernel row 0), 2hy, 2hy+1 from the ring; row -1 = the padding row ----
-            const unsigned *r0 = ring + (hy == 0 ? kSlots : ((2 * hy - 1) & (kSlots - 1))) * C::SLOT_DW + run0;
-            const unsigned *r1 = ring + ((2 * hy) & (kSlots - 1)) * C::SLOT_DW + run0;
-            const unsigned *r2 = ring + ((2 * hy + 1) & (kSlots - 1)) * C::SLOT_DW + run0;
+            const unsigned *r0 = ring + (hy == 0 ? kSlots : (sl0 & (kSlots - 1))) * C::SLOT_DW + run0;
+            const unsigned *r1 = ring + ((sl0 + 1) & (kSlots - 1)) * C::SLOT_DW + run0;
+            const unsigned *r2 = ring + ((sl0 + 2) & (kSlots - 1)) * C::SLOT_DW + run0;
             // lane half 0: kernel row 0 (three pixels) + pixels 0, 1 of kernel row 1; half 1: kernel row 2 + pixel 2 of row 1 (and one
             // pixel past the window under zero weights).  K slots: step 0 = pixels 0, 1 of pa, step 1 = pixel 2 of pa | first pixel of
             // pb, step 2 = second pixel of pb | (zero weights)
@@ -366,22 +424,37 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
                 taps3(dm, q, wq, 2, l4, c4, r4, false, true);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (hy >= 1) finalize(dm, hy - 1);
+            if (fin) finalize(dm, hy - 1);
             __syncthreads();
         };
-        for (int hy = 0; hy < kHid; hy += 3) {
-            step(hy, d2, d0, d1);
-            step(hy + 1, d0, d1, d2);
-            step(hy + 2, d1, d2, d0);
+        if (C::NBD > 1) {
+            // band: step l computes stem row r0 - 1 + l from local stages l (its odd image row) and l + 1 and completes output row r0 + l - 2;
+            // the map's last row is completed (and clamped) by the all-zero stem row 60
+            auto bstep = [&](int l, f32x16 &dm, f32x16 &dc, f32x16 &dn) {
+                const int hy = band_r0 - 1 + l;
+                emul = (unsigned)hy < (unsigned)kHid ? emul_f : 0.0f;
+                step(hy, 2 * l + 1, l >= 2 && l < C::HB + 2, dm, dc, dn);
+            };
+            for (int l = 0; l < C::BSTEPS; l += 3) {
+                bstep(l, d2, d0, d1);
+                bstep(l + 1, d0, d1, d2);
+                bstep(l + 2, d1, d2, d0);
+            }
+        } else {
+            for (int hy = 0; hy < kHid; hy += 3) {
+                step(hy, 2 * hy - 1, hy >= 1, d2, d0, d1);
+                step(hy + 1, 2 * hy + 1, true, d0, d1, d2);
+                step(hy + 2, 2 * hy + 3, true, d1, d2, d0);
+            }
+            finalize(d2, kHid - 1, false);       // (60 - 1) % 3 == 2
         }
-        finalize(d2, kHid - 1, false);       // (60 - 1) % 3 == 2
     }
 }
 
 template <class C>
 static void launch_stem_cfg(const void *img, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                             const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
-    const int wgs = (B + C::U - 1) / C::U;
+    const int wgs = (B + C::U - 1) / C::U * C::NBD;
     const int grid = wgs < 256 ? wgs : 256;
     stem_rm_kernel<C><<<grid, C::NT, 0, s>>>(static_cast<const uint8_t *>(img), As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B);
 }
@@ -390,6 +463,7 @@ static void launch_stem_cfg(const void *img, const unsigned *As3, const float *s
 // threshold, the spatially tiled kernel (stem_block1.hip)
 constexpr int kStemMin4 = 513;      // (two faces per workgroup need a second round of workgroups from here on: B = 640 163 -> 122 us)
 constexpr int kStemMin2 = 480;
+constexpr int kStemBandMin = 112;   // row bands of a face below kStemMin2 (StemRmCfg::NBD)
 
 bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shift, const float *Wd, const float *d_shift,
                     const unsigned *Ap3, const float *p_shift, const float *scl_p, float *Y, int B, hipStream_t s) {
@@ -397,6 +471,10 @@ bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shi
     if (reinterpret_cast<uintptr_t>(img8) & 7) return false;       // the service wave fetches eight-byte pieces of the image rows
     if (B >= kStemMin4) { launch_stem_cfg<StemRmCfg<4, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     if (B >= kStemMin2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
+    // six bands of ten output rows, four faces per workgroup (12 steps + 2 lead stages per round; step time of configs[1] - tiled stem, us:
+    // B = 64 +6, 96 -1, 128 -6, 256 -12, 400 -20; four bands, or two faces per workgroup: +3 ... -3 at B = 128; tools/band_ab.sh)
+    static const bool bands = !getenv("SYN_STEM_BAND") || atoi(getenv("SYN_STEM_BAND")) != 0;
+    if (bands && B >= kStemBandMin) { launch_stem_cfg<StemRmCfg<4, 2, false, 6>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     return false;
 }
 

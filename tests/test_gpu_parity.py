@@ -246,12 +246,13 @@ def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd,
     assert rel_max(got[torch.from_numpy(pick).cuda()].cpu().numpy(), want.numpy()) < 1e-4
 
 
-@pytest.mark.parametrize('B', [33, 39, 40, 95, 97, 128, 161, 200, 224, 351, 352, 353, 383, 385, 480, 511, 513, 575, 577, 640, 768, 769, 1030, 2307])
+@pytest.mark.parametrize('B', [33, 39, 40, 95, 97, 111, 112, 113, 128, 161, 200, 224, 351, 352, 353, 383, 385, 480, 511, 513, 575, 577, 640, 768, 769, 1030, 2307])
 def test_row_marching_kernels_across_their_batch_thresholds(model, model_tiled_early, backbone_sd, B):
     """The early blocks switch kernels with the batch size (tiled below a few hundred faces, row-marching with 1, 2 or 4 units
     per workgroup above: fused_block_rm.hip / stem_rm.hip launchers; B = 2307: more units than persistent workgroups, i.e. several
     rounds per workgroup; features.2 from 40 and features.3 from 96 faces march ROW BANDS of a face -- six / three units per face, rows above
-    and below the image expanded to zeros -- up to where whole faces fill the chip (B = 351: 2106 bands on 768 resident workgroups); B = 33 ... 511 also run features.15-17 in the hidden-sliced schedule of fused_block_lb4.hip: partial sums of
+    and below the image expanded to zeros -- up to where whole faces fill the chip (B = 351: 2106 bands on 768 resident workgroups);
+    the stem does the same from 112 faces (six bands, four faces per workgroup: B = 113 leaves three empty face slots in the last group); B = 33 ... 511 also run features.15-17 in the hidden-sliced schedule of fused_block_lb4.hip: partial sums of
     six / three / two slices of the hidden groups, added by a second kernel).  On DISTINCT faces, at batch sizes on both sides of every
     threshold (incl. odd sizes: features.4 marches two faces per unit, the last unit of an odd batch is half empty): every face
     equals the all-tiled schedule to fp32 rounding, and a spot check of faces against the oracle."""

@@ -1,13 +1,13 @@
 #!/bin/bash
-# GPU box: row-band variants of the row-marching kernels at small batches (fused_block_rm.hip RmCfg::NBD).  Each argument is
-# "<SYN_RM_BAND2>,<SYN_RM_BAND3>,<SYN_RM_BAND4>[,<batch>]" (10 U + NBD, 0 = tiled kernels); prints the per-launch microseconds (tools/perlaunch.py), interleaved twice.
-# TEST=1: also run the batch-threshold parity test (small batches) under each setting.
+# GPU box: row-band variants at small batches.  Each argument is "<SYN_STEM_BAND>,<batch>[,<SYN_RM_BAND2>,<SYN_RM_BAND3>]" (stem: 10 U + NBD
+# or 0 = the tiled stem; features.2 / 3 bands: 1 / 0); prints the per-launch microseconds (tools/perlaunch.py), interleaved twice.
+# TEST=1: also run the batch-threshold parity tests under each setting.
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/band_ab.txt; : > $out
 for rep in 1 2; do for c in "$@"; do
-  IFS=, read b2 b3 b4 bs <<< "$c"; bs=${bs:-128}
-  export SYN_RM_BAND2=$b2 SYN_RM_BAND3=$b3 SYN_RM_BAND4=$b4
+  IFS=, read st bs b2 b3 <<< "$c"; bs=${bs:-128}
+  export SYN_STEM_BAND=$st SYN_RM_BAND2=${b2:-1} SYN_RM_BAND3=${b3:-1}
   if [ "$TEST" = 1 ] && [ $rep = 1 ]; then
-    echo "== $c test: $(cd $R && timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k 'across_their_batch_thresholds or ragged_batches_match or every_feature' < /dev/null 2>&1 | tail -1)" >> $out
+    echo "== $c test: $(cd $R && timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k 'across_their_batch_thresholds or ragged_batches_match or every_feature or u8_ingest' < /dev/null 2>&1 | tail -1)" >> $out
   fi
   echo "== $c B=$bs: $(timeout 120 python $R/tools/perlaunch.py --lmk-only --batch $bs --steps 200 --warmup 20 --overlap 0 < /dev/null 2>&1 | tail -1)" >> $out
 done; done
