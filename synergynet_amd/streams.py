@@ -37,6 +37,8 @@ class OverlappedPipeline:
         self.s_rec = reconstruction_stream(self.dev, rec_priority) if overlap else self.s_main
         self._inflight = [None, None]              # per parity: (tensors kept alive, event "second stage done")
         self._n = 0
+        self._tail_stream = None
+        self.last_done = None
 
     def submit(self, crops_u8, rois, lmk_out=None, mesh_out=None, dense=True):
         """Enqueue one batch: uint8 crops [B,120,120,3] and rois [B,5] (device tensors).  Returns (param, lmk, mesh, (angles,
@@ -50,13 +52,19 @@ class OverlappedPipeline:
             param = m.forward_crops_u8(crops_u8)
             ready = torch.cuda.Event()
             ready.record(self.s_main)
-        with torch.cuda.stream(self.s_rec):
-            self.s_rec.wait_event(ready)
+        # landmarks + pose only (three kernels of ~5 us): nothing to overlap, and the hop to the second stream costs as much as they take
+        # (configs[1], B = 128: 0.335 -> 0.331 ms) -- they stay behind the backbone on its stream
+        s_tail = self.s_rec if dense else self.s_main
+        with torch.cuda.stream(s_tail):
+            s_tail.wait_event(ready)
+            if self._tail_stream is not s_tail and self.last_done is not None:
+                s_tail.wait_event(self.last_done)      # (a dense batch's tail may still use the handle's reconstruction records on the other stream)
+            self._tail_stream = s_tail
             lmk = m.reconstruct(param, roi=rois, dense=False, out=lmk_out)
             mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out) if dense else None
             pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
-            done.record(self.s_rec)
+            done.record(s_tail)
         self._inflight[k] = ((param, lmk, mesh, pose, crops_u8, rois), done)
         self.last_done = done
         return param, lmk, mesh, pose
