@@ -125,19 +125,20 @@ struct LbCfg {
                                                          // one face per workgroup, four streams, all partial sums through LDS (below)
     static constexpr int NW = FPW * NS, NT = NW * 64;
     static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
-    static constexpr int KT = (MT + NS - 1) / NS;        // output tiles a wave keeps (mt % NS == its stream)
+    static constexpr int NSX = NS == 8 ? 4 : NS;         // streams that keep output tiles (eight streams: 4 .. 7 first add theirs into 0 .. 3)
+    static constexpr int KT = (MT + NSX - 1) / NSX;      // output tiles a keeper wave keeps (mt % NSX == its stream)
     // four-stream schedule: one wave per SIMD and nobody to cover an L2 round trip, but 512 registers -- ALL project fragments of a group
     // (or four of them) are requested half way through its depthwise phase, not during its last quarter
     static constexpr bool EARLYP = NS == 4 && !S2_;
-    static constexpr int RED_DW = (NS == 2 ? 1 : NS) * MT * NB * 256;   // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]; NS > 2: [stream][MT][NB][lane][4]
+    static constexpr int RED_DW = (NS == 2 ? 1 : NSX) * MT * NB * 256;  // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]; NS > 2: [stream 4][MT][NB][lane][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
     static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
     static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
-    static_assert(NS == 2 || (NS == 4 && FPW == 1 && (HID / 32) >= NS), "four streams: the one-face-per-workgroup schedule of small batches");
+    static_assert(NS == 2 || ((NS == 4 || NS == 8) && FPW == 1 && (HID / 32) >= NS), "four / eight streams: the one-face-per-workgroup schedule of small batches");
     static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
     static_assert(!RES || (CIN == COUT && !S2), "residual only on same-width stride-1 blocks");
-    static_assert((FPW == 4 || NS == 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
+    static_assert((FPW == 4 || NS >= 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
 // compiler fence between the phases of a hidden group: without it every load of a group is hoisted to the top of the loop body
@@ -193,7 +194,34 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     };
 
     // ---- stage: block input of this face -> pre-split B fragments (this wave: blocks 2 st, 2 st + 1) ----
-    if (FIRST) {
+    if constexpr (FIRST && C::NS == 8) {
+        // eight streams: the KE x 4 (k32 step, block) pieces of the block input dealt over the waves
+        constexpr int NIT = (KE * 4 + 7) / 8;
+        f32x4 xv[NIT][2];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = st + 8 * i, itc = it < KE * 4 ? it : 0;
+            const float *src = X + ((size_t)fc * 64 + pix_in(itc & 3, n)) * CIN + 32 * (itc >> 2) + 8 * g;
+            xv[i][0] = *(const f32x4 *)src;
+            xv[i][1] = *(const f32x4 *)(src + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int it = st + 8 * i;
+            f32x4 a = xv[i][0], b = xv[i][1];
+            if (!real) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a; }
+            a *= 16.0f; b *= 16.0f;
+            u32x4 pc[2];
+            split2v(a[0], a[1], pc, 0);
+            split2v(a[2], a[3], pc, 1);
+            split2v(b[0], b[1], pc, 2);
+            split2v(b[2], b[3], pc, 3);
+            if (it < KE * 4) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[(it * 2 + p) * 256 + lane * 4] = pc[p];      // it = kc * 4 + block
+            }
+        }
+    } else if (FIRST) {
         f32x4 xv[KE][BPW][2];
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc)
@@ -425,11 +453,11 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     // stands between the second barrier and the stores).  Inside a chain the residual is what this wave stored one stage ago, into
     // a buffer this CU read two stages ago: the load goes past the vector cache (sc0: miss in the CU's cache, served by the XCD's L2, where the store landed).
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, 0x7fffffff, 0x00027000);
-    constexpr int KT = C::KT, NSW = C::NS;
+    constexpr int KT = C::KT, NSW = C::NSX;              // (eight streams: four keepers, see below)
     f32x4 rs[KT][NB], psh[KT];
 #pragma unroll
     for (int i = 0; i < KT; ++i) {
-        const int mtk = NSW * i + st;                    // the i-th output tile this wave keeps (may not exist when MT % NS != 0)
+        const int mtk = NSW * i + (st & (NSW - 1));      // the i-th output tile this wave keeps (may not exist when MT % NS != 0)
         const int nch = 16 * (mtk < MT ? mtk : MT - 1) + 4 * ge;
         psh[i] = *(const f32x4 *)&p_shift[nch];
 #pragma unroll
@@ -439,7 +467,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     __syncthreads();                                     // every wave is done reading the fragments
     constexpr bool HANDOFF = !__is_same(CN, void);
     f32x4 vout[KT][NB];
-    if constexpr (NSW == 2) {
+    if constexpr (C::NS == 2) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if ((mt & 1) == st) continue;
@@ -469,9 +497,26 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         // four streams: every wave publishes the tiles it does not keep, then adds the other three streams' copies of its own tiles in
         // stream order 0 + 1 + 2 + 3 (fixed: results do not depend on the position in the batch)
         static_assert(!PARTIAL, "the four-stream schedule reduces inside the workgroup");
+        if constexpr (C::NS == 8) {
+            // eight streams: streams 4 .. 7 hand ALL their sums to streams 0 .. 3 first (s + (s + 4), fixed order), which then meet as above
+            if (st >= 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) *(f32x4 *)&Red[((((st - 4) * MT + mt) * NB + r) * 64 + lane) * 4] = acc[mt][r];
+            }
+            __syncthreads();
+            if (st < 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) acc[mt][r] += *(const f32x4 *)&Red[(((st * MT + mt) * NB + r) * 64 + lane) * 4];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (mt % NSW == st) continue;
+            if (mt % NSW == st || st >= NSW) continue;
 #pragma unroll
             for (int r = 0; r < NB; ++r) *(f32x4 *)&Red[(((st * MT + mt) * NB + r) * 64 + lane) * 4] = acc[mt][r];
         }
@@ -499,11 +544,11 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         __syncthreads();                                 // everybody has read the exchange buffer (it aliases the fragments)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (mt % C::NS != st) continue;
+            if (mt % NSW != st) continue;
             const int kc = mt >> 1, lg = (2 * (mt & 1) + (ge >> 1)) * 16, dw = 2 * (ge & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4 v = real ? vout[mt / C::NS][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = real ? vout[mt / NSW][r] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
                 unsigned a0, b0, a1, b1;
                 split2h(v[0], v[1], a0, b0);
                 split2h(v[2], v[3], a1, b1);
@@ -854,6 +899,32 @@ void fused_chain_lb_small_kernel(LbChainArgs ca, int B) {
     lb_stage<L14s, void, false, false, kChainFaceDwS>(smem, ca.s[7], B, pt_, tk);
 }
 
+// EIGHT waves per face (two per SIMD, 256 registers): the four-stream kernel has one wave per SIMD, and a lone wave stalls on every dependent
+// step of a hidden group (~3.4 us per group against ~2.4 per SIMD in the two-waves-per-SIMD chain of large batches); with eight streams a
+// SIMD's two waves cover each other's round trips, a wave walks 1-3 groups per block instead of 3-5, and the partial sums meet in two
+// levels (streams 4 .. 7 into 0 .. 3, then as above).  Landmarks-only step, four -> eight streams (ms, interleaved on one box): B = 1 0.244 -> 0.225,
+// 8 0.265 -> 0.245, 64 0.300 -> 0.281, 128 0.330 -> 0.310, 256 0.429 -> 0.409.  The default; SYN_SMALL_NS=4 selects the kernel above.
+using L8e = LbCfg<     64, 384,  64, true,  2, SYN_L8_PPF, 1, false, 8>;
+using L11e = LbCfg<    64, 384,  96, false, 2, SYN_L11_PPF, 1, false, 8>;
+using L12e = LbCfg<    96, 576,  96, true,  1, 3, 1, false, 8>;
+using L14e = LbCfg<    96, 576, 160, false, 1, 2, 1, true, 8>;
+constexpr int kChainFaceDwE = cmax4(L8e::FACE_DW, L11e::FACE_DW, L12e::FACE_DW, L14e::FACE_DW);
+constexpr int kChainLdsDwE = L8e::FPW * kChainFaceDwE + L8e::NW * L8e::TB_DW;
+static_assert(kChainLdsDwE * 4 <= 160 * 1024, "one workgroup per CU");
+
+__global__ __launch_bounds__(L8e::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_chain_lb_small8_kernel(LbChainArgs ca, int B) {
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDwE];
+    lb_stage<L8e, L8e, true, false, kChainFaceDwE>(smem, ca.s[1], B, pt_, tk);
+    lb_stage<L8e, L8e, false, false, kChainFaceDwE>(smem, ca.s[2], B, pt_, tk);
+    lb_stage<L8e, L11e, false, false, kChainFaceDwE>(smem, ca.s[3], B, pt_, tk);
+    lb_stage<L11e, L12e, false, false, kChainFaceDwE>(smem, ca.s[4], B, pt_, tk);
+    lb_stage<L12e, L12e, false, false, kChainFaceDwE>(smem, ca.s[5], B, pt_, tk);
+    lb_stage<L12e, L14e, false, false, kChainFaceDwE, false>(smem, ca.s[6], B, pt_, tk);
+    lb_stage<L14e, void, false, false, kChainFaceDwE>(smem, ca.s[7], B, pt_, tk);
+}
+
 // y = (slice 0 + slice 1 + ... in this order) / (16 Sp) + BN shift (+ x): one thread per four channels of a pixel
 template <class C>
 __global__ __launch_bounds__(256) void lb_reduce_kernel(const float *__restrict__ part, int S, const float *__restrict__ Tlb,
@@ -918,7 +989,9 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int
     if (last == 13) ca.s[7] = ca.s[6];
     if (B < kChainMin) {
         if (first != 8 || last != 14) return false;
-        fused_chain_lb_small_kernel<<<B, L8s::NT, 0, s>>>(ca, B);
+        static const int small_ns = getenv("SYN_SMALL_NS") ? atoi(getenv("SYN_SMALL_NS")) : 8;      // (4: the four-stream kernel, for A/B: tools/small_ns_ab.sh)
+        if (small_ns == 8) fused_chain_lb_small8_kernel<<<B, L8e::NT, 0, s>>>(ca, B);
+        else fused_chain_lb_small_kernel<<<B, L8s::NT, 0, s>>>(ca, B);
         return true;
     }
     const int grid = (B + L8::FPW - 1) / L8::FPW;

@@ -217,9 +217,9 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
 
 @pytest.mark.parametrize('B', [1, 3, 31, 32, 127, 128, 255, 256, 257])
 def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd, B):
-    """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, four waves per
-    face, the partial sums of the four streams added in LDS (fused_chain_lb_small_kernel) -- instead of 14 hidden-sliced + reduce
-    launches (or the tiled kernels below 32 faces).  Same arithmetic in another summation order: equal to the block-by-block schedule
+    """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, eight waves per
+    face, the partial sums of the eight streams added in LDS in a fixed order (fused_chain_lb_small8_kernel; SYN_SMALL_NS=4: the four-stream
+    kernel it replaced) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Same arithmetic in another summation order: equal to the block-by-block schedule
     (SYNERGY_HIP_EARLY_RM without bit 10) to fp32 rounding on distinct faces, bitwise independent of the position in the batch, and
     every face within the tolerance of the oracle."""
     import torch
