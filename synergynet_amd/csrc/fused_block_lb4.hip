@@ -361,6 +361,8 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.scratch) return false;
     const int wg = (B + 3) / 4;
     static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
+    // the fewest slices that give 192 workgroups (more slices lose: 320 / 480 workgroups cost the landmarks-only step +21 / +18 us at B = 128,
+    // +25 / +30 at B = 256 -- every slice streams its own partial tensor through the reduce launch)
     int S = 30;
     for (int d : divs) if (wg * d >= 192) { S = d; break; }
     if ((size_t)S * B * 16 * C::COUT > a.scratch_floats) return false;
