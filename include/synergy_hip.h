@@ -88,7 +88,11 @@ int syn_set_schedule(syn_handle *h, int fusion);
  * tensor's maximum; 2e-5 is the natural choice, the schedules agree to ~1e-6) runs the exact kernel from then on, in this handle and
  * in every replica that imports its constants.  Closes the one assumption of the load-time analysis that is not a proof: that the
  * interval bound of a tensor is within 2^8 of its true activations (underflow side).  Returns the number of blocks switched
- * (0 for ResNet-50, which is guarded at run time).  Synchronises; not for use while forwards of this handle are in flight. */
+ * (0 for ResNet-50, which is guarded at run time).  Synchronises; not for use while forwards of this handle are in flight.
+ * Scope of the check: the comparison runs block by block at B <= 256, i.e. on the kernels THAT batch size selects (tiled /
+ * band-marching early blocks, features.8-13 one block per launch).  The whole-face row-marching kernels of B >= 352 ... 513 and the
+ * chain launches use the same operand pieces, scales and range proofs but another summation order; the verdict is taken as valid for
+ * them because what it measures -- operand underflow of a block's input and weights -- does not depend on the order of the sum. */
 int syn_backbone_calibrate(syn_handle *h, const uint8_t *crops_u8, int B, float tol, void *stream);
 
 /* ResNet-50 (ReLU, no static activation bound): the fp16 convolutions are guarded at RUN time.  Every tensor they split reports
@@ -134,8 +138,14 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
  * rank calls it with its own handle, on the device the communicator was created for) -- rank `root` exports, ncclBroadcast ships the
  * size and then the blob, every other rank imports; returns after the stream has drained.  The library does not link RCCL: it
  * calls the instance the process already holds (the caller's, or torch's librccl.so.1), so the communicator and the code that
- * uses it always belong together.  SYN_ERR_INVALID for a NULL communicator, SYN_ERR_NOT_LOADED when the process holds no RCCL
- * (or the root handle no constants). */
+ * uses it always belong together (a process that holds more than one RCCL names the owner of the communicator with the environment
+ * variable SYNERGY_HIP_RCCL_LIB = path of that librccl).  SYN_ERR_INVALID for a NULL communicator, SYN_ERR_NOT_LOADED when the process
+ * holds no RCCL.
+ * A COLLECTIVE THAT FAILS, FAILS ON EVERY RANK (csrc/bcast_protocol.h): a root handle without constants, or one that cannot stage its
+ * blob, reports that inside the first broadcast (size word 0 + its code) and EVERY rank returns that code (SYN_ERR_NOT_LOADED /
+ * SYN_ERR_HIP); a rank that cannot stage or import the blob reports it in an ncclAllReduce(max) of the status and every rank returns
+ * it -- no rank is left waiting in a collective another rank never enters, and the communicator stays usable.  (The one local exit:
+ * a rank that cannot allocate the 256-byte word buffer has no device memory to join a collective with.) */
 int syn_bcast_constants(syn_handle *h, void *nccl_comm, int root, void *stream);
 /* The 256-byte header syn_export_constants would write for this handle NOW (what it holds: arch, backbone / basis present, vertex and
  * landmark counts, total bytes), into HOST memory, no device call -- how a host mirror learns what a syn_bcast_constants import gave it. */

@@ -177,33 +177,64 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
         else if (HANDOFF) lb4_fetch<NPWN>(pf, GlbNext + l4, wave);          // the next block's first group
         const unsigned *We = smem + ((G - gb) & 1) * GRPL, *Wp = We + C::WE_DW;
         const float *Tb = reinterpret_cast<const float *>(Wp + C::WP_DW);
-        // fragments of this wave: its hidden tile's expand fragments and its output tiles' project fragments, read up front
+#ifndef SYN_LB4_V1
+        __builtin_amdgcn_sched_barrier(0);               // the next group's fetch stays in front of this group's LDS reads
+#endif
+        // fragments of this wave.  Round 5: the eight waves read 22 KB each here, the LDS delivers 128 bytes per cycle, and the expand chain
+        // used to wait for ALL of it (the project fragments were pinned in front of it): ~1400 cycles per group in which nothing else ran.
+        // Now only the expand fragments and the group's constants stand in front of the expand chain; the project fragments are requested
+        // behind it and land during the depthwise arithmetic, which leaves the LDS idle.  (SYN_LB4_V1: the old order, for A/B runs.)
         u32x4 Ae[KE][2], Ap[MTW][2];
+        // (the LDS returns in order: the accumulator's start value first, then the fragments in the order the chain consumes them, then the filter)
+        f32x4 D = *(const f32x4 *)&Tb[10 * 32 + 16 * t + g4];
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) Ae[kc][p] = *(const u32x4 *)&We[((t * KE + kc) * 2 + p) * 256 + l4];
+            for (int p = 1; p >= 0; --p) Ae[kc][p] = *(const u32x4 *)&We[((t * KE + kc) * 2 + p) * 256 + l4];
         constexpr int MTW0 = MTW > 5 ? MTW / 2 : MTW;    // (320 output channels: the second half of the project fragments after the exchange)
+#ifdef SYN_LB4_V1
 #pragma unroll
         for (int i = 0; i < MTW0; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p) Ap[i][p] = *(const u32x4 *)&Wp[((t * MTW + i) * 2 + p) * 256 + l4];
+#else
+        // depthwise filter, its BN shift: two channels x two halves per lane group, requested with the expand fragments
+        f32x2 wt[2][9], dsht[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wt[hf][k] = *(const f32x2 *)&Tb[k * 32 + 16 * t + 2 * hf + g4];
+            dsht[hf] = *(const f32x2 *)&Tb[9 * 32 + 16 * t + 2 * hf + g4];
+        }
+#endif
         // ---- expand 1x1 + BN shift: D = channels 32 G + 16 t + 4 g + i of pixel n (three partial products, smallest first) ----
-        f32x4 D = *(const f32x4 *)&Tb[10 * 32 + 16 * t + g4];
+#ifndef SYN_LB4_V1
+        __builtin_amdgcn_sched_barrier(0);               // every read above is issued before the first matrix instruction (the LDS returns in order: counted waits)
+#endif
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc) {
             D = mfmaq(Ae[kc][1], Xr[kc][0], D);
             D = mfmaq(Ae[kc][0], Xr[kc][1], D);
             D = mfmaq(Ae[kc][0], Xr[kc][0], D);
         }
+#ifdef SYN_LB4_V1
 #pragma unroll
         for (int i = 0; i < MTW0; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(Ap[i][p]));      // (keeps these reads up here instead of next to their MFMAs)
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MTW0; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Ap[i][p] = *(const u32x4 *)&Wp[((t * MTW + i) * 2 + p) * 256 + l4];
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- ReLU6, depthwise 3x3 + BN shift + ReLU6 on the registers, split into this wave's half of the project operand ----
         u32x4 own;                                      // {piece 0 dwords hf 0, 1 | piece 1 dwords hf 0, 1}
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
+#ifdef SYN_LB4_V1
             const int c0 = 16 * t + 2 * hf;             // + 4 g per lane group
             f32x2 w[9];
 #pragma unroll
@@ -211,13 +242,22 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
             const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
+#else
+            const f32x2 (&w)[9] = wt[hf];
+            const f32x2 dsh = dsht[hf];
+#endif
             f32x2 E;
             // ReLU6 as clamp modifiers (fused_block_lb.hip): E = relu6 / 6 = clamp(D / (96 Se)); the last add of the output clamps too
             E[0] = __builtin_amdgcn_fmed3f(D[2 * hf] * c6e, 0.0f, 1.0f);
             E[1] = __builtin_amdgcn_fmed3f(D[2 * hf + 1] * c6e, 0.0f, 1.0f);
             // horizontal first (two lane shifts), then the three row sums shifted vertically (two more): 8 DPP moves per channel pair
             // instead of 16.  (Summation order differs from the other kernels': dx inside dy inside the vertical sum.)
+#ifdef SYN_LB4_V1
             const f32x2 l = dppq2<kShr1>(E), rt = dppq2<kShl1>(E);
+#else
+            // the image border in x: the shifted VALUE is zeroed (two multiplies) instead of six filter entries -- the same products, bit for bit
+            const f32x2 l = dppq2<kShr1>(E) * mL, rt = dppq2<kShl1>(E) * mR;
+#endif
             f32x2 H[3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {

@@ -154,9 +154,19 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 
     // power-of-two operand scales of the fp16 pieces (synergy_abi.hip): the expand accumulators start at Se x shift, ReLU6 clamps at
     // 6 Se and the depthwise filter carries 1 / Se; the project sums are rescaled by 1 / Sp where the service wave reduces them
-    const float Se = scl_e[0], inv_se = scl_e[1], c6e = scl_e[2], inv_sp = scl_p[1];
-    for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] * inv_se : 0.f; }
-    for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] : 0.f; Esh[i] = i < C::HID ? e_shift[i] * Se : 0.f; }
+    //
+    // ReLU6 without instructions of its own (round 5; the register-resident blocks and the stem since round 4): both activations are carried as
+    // relu6(x) / 6 in [0, 1] = what the `clamp` output modifier leaves -- on the multiply that rescales the expand accumulator (1 / (6 Se), 0 on
+    // padding lanes) and on the LAST fused multiply-add a depthwise output receives.  The 6 rides on the constants: plain depthwise filter,
+    // depthwise shift / 6, output rescale 6 / Sp.  Per row step and wave 32 v_med3 (4 issue cycles each) become 16 multiplies (2.7); SYN_RM_MED3=1: the old form.
+#ifndef SYN_RM_MED3
+#define SYN_RM_MED3 0
+#endif
+    constexpr bool CLAMP = !SYN_RM_MED3;
+    const float Se = scl_e[0], inv_se = scl_e[1], c6e = CLAMP ? scl_e[1] * (1.0f / 6.0f) : scl_e[2], inv_sp = CLAMP ? scl_p[1] * 6.0f : scl_p[1];
+    const float f_scale = CLAMP ? 1.0f : inv_se, d_scale = CLAMP ? 1.0f / 6.0f : 1.0f;
+    for (int i = tid; i < 9 * C::HIDP; i += NT) { const int c = i % C::HIDP; Filt[i] = c < C::HID ? Wd[(i / C::HIDP) * C::HID + c] * f_scale : 0.f; }
+    for (int i = tid; i < C::HIDP; i += NT) { Filt[DSH + i] = i < C::HID ? d_shift[i] * d_scale : 0.f; Esh[i] = i < C::HID ? e_shift[i] * Se : 0.f; }
     if (tid < 32) Psh[tid] = tid < C::COUT ? p_shift[tid] : 0.f;
     if (C::LEAN)
         for (int i = tid; i < C::APL_DW / 4; i += NT) *(u32x4 *)&ApL[4 * i] = *(const u32x4 *)&Ap3[4 * i];
@@ -323,7 +333,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
         const int unit = ub + uw;
         const int fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;
         const int f_in = fu * C::NF + ia;
-        float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes
+        float ehi[C::NB];                         // ReLU6 ceiling of the expanded pixel: 6 inside the image, 0 on padding lanes (clamp form: the multiplier 1 / (6 Se) | 0)
         float ehs[C::NB];                         // ... of the row being expanded (bands: 0 for the rows above / below the image)
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) ehs[b] = ehi[b] = ((unsigned)icol[b] < (unsigned)H && f_in < B) ? c6e : 0.0f;
@@ -348,12 +358,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 for (int p = 0; p < 2; ++p) xb[p] = *(const u32x4 *)(src + p * 256);
                 e = mac3r(ae[s], xb, e);
             }
+            // (compiler-made clamp: a vector instruction that reads a matrix result needs wait states only the compiler inserts)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], 0.0f, ehs[b]);
+            for (int r = 0; r < 16; ++r) e[r] = CLAMP ? __builtin_amdgcn_fmed3f(e[r] * ehs[b], 0.0f, 1.0f) : __builtin_amdgcn_fmed3f(e[r], 0.0f, ehs[b]);
         };
         // ---- finished depthwise row -> ReLU6 -> fp16 x2 pieces (in place: register 8s+e = K slot e of step s) -> project
         //      partial over this wave's 32 hidden channels -> LDS ----
-        auto finalize = [&](f32x16 &d, int pslot) {
+        auto finalize = [&](f32x16 &d, int pslot, bool raw = false) {        // raw: an output row whose last kernel row does not exist (clamp form: not clamped yet)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -363,7 +374,9 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 u32x4 db[2];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float v0 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t], 0.0f, 6.0f), v1 = __builtin_amdgcn_fmed3f(d[8 * s + 2 * t + 1], 0.0f, 6.0f);
+                    float v0 = d[8 * s + 2 * t], v1 = d[8 * s + 2 * t + 1];
+                    if (!CLAMP) { v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 6.0f); v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 6.0f); }
+                    else if (raw) { v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 1.0f); v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 1.0f); }
                     unsigned ha, hb;
                     split2r(v0, v1, ha, hb);
                     db[0][t] = ha; db[1][t] = hb;
@@ -382,7 +395,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             for (int q = 0; q < C::NQ; ++q) *(f32x4 *)(dst + q * 256) = (f32x4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         };
         // three taps of one kernel row into one accumulator quad; `init`: the accumulator starts at the BN shift (Filt row 9)
-        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+        // `last` (clamp form): this kernel row completes the output row -- its last multiply-add clamps to [0, 1]
+        auto taps3 = [&](f32x16 &d, int q, const float *wq, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init, bool last = false) {
             const f32x4 w0 = *(const f32x4 *)(wq + (3 * ky + 0) * C::HIDP), w1 = *(const f32x4 *)(wq + (3 * ky + 1) * C::HIDP),
                         w2 = *(const f32x4 *)(wq + (3 * ky + 2) * C::HIDP);
             f32x4 base;
@@ -390,7 +404,8 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float b0 = init ? base[t] : d[4 * q + t];
-                d[4 * q + t] = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0)));
+                const float v = __builtin_fmaf(r4[t], w2[t], __builtin_fmaf(c4[t], w1[t], __builtin_fmaf(l4[t], w0[t], b0)));
+                d[4 * q + t] = CLAMP && last ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : v;
             }
             // pin the update here: otherwise the compiler sinks these FMAs to where the accumulator is next read (the following
             // row's step) and keeps their operands + filter quads alive across the barrier instead
@@ -398,11 +413,12 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
         };
         // the same with the filter quads in registers (wr[3 * ky + kx])
-        auto taps3r = [&](f32x16 &d, int q, const f32x4 *wr, const f32x4 &base, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init) {
+        auto taps3r = [&](f32x16 &d, int q, const f32x4 *wr, const f32x4 &base, int ky, const f32x4 &l4, const f32x4 &c4, const f32x4 &r4, bool init, bool last = false) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float b0 = init ? base[t] : d[4 * q + t];
-                d[4 * q + t] = __builtin_fmaf(r4[t], wr[3 * ky + 2][t], __builtin_fmaf(c4[t], wr[3 * ky + 1][t], __builtin_fmaf(l4[t], wr[3 * ky][t], b0)));
+                const float v = __builtin_fmaf(r4[t], wr[3 * ky + 2][t], __builtin_fmaf(c4[t], wr[3 * ky + 1][t], __builtin_fmaf(l4[t], wr[3 * ky][t], b0)));
+                d[4 * q + t] = CLAMP && last ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : v;
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
@@ -417,10 +433,13 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
         };
-        auto taps1 = [&](f32x16 &d, int q, const float *wq, int ta, const f32x16 &e) {
+        auto taps1 = [&](f32x16 &d, int q, const float *wq, int ta, const f32x16 &e, bool last = false) {
             const f32x4 wa = *(const f32x4 *)(wq + ta * C::HIDP);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d[4 * q + t] = __builtin_fmaf(e[4 * q + t], wa[t], d[4 * q + t]);
+            for (int t = 0; t < 4; ++t) {
+                const float v = __builtin_fmaf(e[4 * q + t], wa[t], d[4 * q + t]);
+                d[4 * q + t] = CLAMP && last ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : v;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(d[4 * q + t]));
         };
@@ -459,11 +478,11 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                     if (q < C::WREG) {
                         taps3r(dn, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 0, l4, c4, r4, true);
                         taps3r(dc, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 1, l4, c4, r4, false);
-                        taps3r(dm, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 2, l4, c4, r4, false);
+                        taps3r(dm, q, wreg[q < C::WREG ? q : 0], wbase[q < C::WREG ? q : 0], 2, l4, c4, r4, false, true);
                     } else {
                         taps3(dn, q, wq, 0, l4, c4, r4, true);
                         taps3(dc, q, wq, 1, l4, c4, r4, false);
-                        taps3(dm, q, wq, 2, l4, c4, r4, false);
+                        taps3(dm, q, wq, 2, l4, c4, r4, false, true);
                     }
                     __builtin_amdgcn_sched_barrier(0);          // one register quad at a time
                 }
@@ -494,7 +513,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 }
                 // the last output row has no input row below it: complete as it is ((H-1) % 3 == 2 -> d2)
                 if (C::LEAN) SYNR_BARRIER();
-                finalize(d2, (H - 1) & (C::PSLOTS - 1));
+                finalize(d2, (H - 1) & (C::PSLOTS - 1), true);
                 SYNR_BARRIER();
             }
         } else {
@@ -560,7 +579,7 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (q >= nq_live) break;
-                        taps1(dcur, q, Filt + cbo + 8 * q, 7, e);
+                        taps1(dcur, q, Filt + cbo + 8 * q, 7, e, true);
                         taps1(dnext, q, Filt + cbo + 8 * q, 1, e);
                         __builtin_amdgcn_sched_barrier(0);
                     }

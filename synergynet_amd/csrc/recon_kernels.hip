@@ -566,10 +566,14 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
     const int n_tiles = nvp / 32;
     constexpr int WPG = 4;                                    // 8 (1 KiB runs, one workgroup per CU) measured slower
     // the reference's packed rows (pitch == n_vert, dense mesh, a line-aligned tensor): the whole-line schedule PK of the kernel
-    const bool pk = pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !getenv("SYN_RECON_NO_PK");
+    // (the straight-line FAST path counts groups of WPG x 32 = 128 vertices, PK counts groups of 224 | 96 -- two counts, kept apart: a
+    // caller with pitch == n_vert AND pad_writable used to reach the FAST kernel with PK's group count and leave vertices >= 128 x that unwritten)
+    const int fast_groups = (n_tiles + WPG - 1) / WPG;
+    const bool fast_ok = pad_writable && pitch >= fast_groups * WPG * 32;
+    const bool pk = !fast_ok && pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !getenv("SYN_RECON_NO_PK");
     static const int pk_wpg = getenv("SYN_RECON_PK_WPG") ? atoi(getenv("SYN_RECON_PK_WPG")) : 8;       // tiles a PK workgroup computes: 8 (stores 7 lines per row) | 4 (stores 3)
     const int pkw = (pk_wpg == 8 ? 7 : 3) * 32;
-    const int n_groups = pk ? (n_vert + pkw - 1) / pkw : (n_tiles + WPG - 1) / WPG;       // a workgroup = WPG consecutive vertex tiles (PK: a stride of WPG - 1)
+    const int n_groups = pk ? (n_vert + pkw - 1) / pkw : fast_groups;       // a workgroup = WPG consecutive vertex tiles (PK: a stride of WPG - 1)
     static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 1664;   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
     static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
     // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
@@ -605,7 +609,7 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
         else
             recon_f16_kernel<WPG, false><<<grid, WPG * 64, 0, s>>>(rec3, basis3, out, B, n_vert, pitch, n_tiles, n_split, per, lo, hi, n_units);
     };
-    if (pad_writable && pitch >= n_groups * WPG * 32) {   // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
+    if (fast_ok) {                        // pitched output with room for whole 128-vertex runs: whole face tiles on the straight-line
                                           // store path (columns [n_vert, pitch) receive padding values), the ragged last one guarded
         run(0, B / 32, true);
         run(B / 32, n_ftiles, false);

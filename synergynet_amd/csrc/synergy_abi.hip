@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "syn_internal.h"
+#include "bcast_protocol.h"
 
 namespace {
 
@@ -1748,59 +1749,87 @@ int syn_check_constants_host(const void *host_blob, size_t bytes) {
 namespace {
 struct RcclApi {
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclBroadcast
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclAllReduce (optional: the agreement steps)
     int (*CommUserRank)(void *, int *) = nullptr;                                                 // ncclCommUserRank
     const char *(*GetErrorString)(int) = nullptr;                                                 // ncclGetErrorString
     bool ok = false;
 };
+// SYNERGY_HIP_RCCL_LIB: the path of the RCCL instance that owns the caller's communicator, for a process that holds more than one
+// (ADVICE r4); default: what the process already holds -- global scope, librccl.so.1 as loaded by the caller or by torch
+// (RTLD_NOLOAD finds a library whatever scope it was loaded into) -- and only then the ROCm installation.
 const RcclApi &rccl_api() {
     static const RcclApi api = [] {
         RcclApi a;
-        void *cands[4] = {RTLD_DEFAULT, dlopen("librccl.so.1", RTLD_LAZY | RTLD_NOLOAD), dlopen("librccl.so", RTLD_LAZY | RTLD_NOLOAD), nullptr};
-        for (int i = 0; i < 4 && !a.ok; ++i) {
-            void *lib = i < 3 ? cands[i] : dlopen("librccl.so.1", RTLD_LAZY | RTLD_GLOBAL);
-            if (i > 0 && !lib) continue;
+        const char *own = getenv("SYNERGY_HIP_RCCL_LIB");
+        void *cands[5] = {own && *own ? dlopen(own, RTLD_LAZY | RTLD_GLOBAL) : nullptr, RTLD_DEFAULT, dlopen("librccl.so.1", RTLD_LAZY | RTLD_NOLOAD),
+                          dlopen("librccl.so", RTLD_LAZY | RTLD_NOLOAD), nullptr};
+        for (int i = (own && *own) ? 0 : 1; i < 5 && !a.ok; ++i) {
+            void *lib = i < 4 ? cands[i] : dlopen("librccl.so.1", RTLD_LAZY | RTLD_GLOBAL);
+            if (i != 1 && !lib) continue;
             a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(lib, "ncclBroadcast"));
+            a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
             a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
             a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
             a.ok = a.Broadcast && a.CommUserRank && a.GetErrorString;
+            if (own && *own && i == 0) break;            // an explicit instance is not silently replaced by another one
         }
         return a;
     }();
     return api;
 }
+
+// the pieces bcast_constants_protocol (bcast_protocol.h) is made of, on HIP memory and the caller's RCCL communicator
+struct RcclBcastOps {
+    syn_handle *h; void *comm; hipStream_t s; const RcclApi &R; int my_rank;
+    unsigned long long *word_dev = nullptr;              // 256 bytes: the size word and the agreement word travel through device memory
+    const char *transport_error = nullptr;
+    int rank() const { return my_rank; }
+    bool loaded() const { return h->d_backbone || h->d_basis; }
+    uint64_t bytes() const { return (uint64_t)syn_constants_bytes(h); }
+    void *alloc(uint64_t n) { void *p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
+    void release(void *p) { (void)hipFree(p); }
+    int export_to(void *p, uint64_t n) { return syn_export_constants(h, p, n, s); }
+    int import_from(void *p, uint64_t n) { return syn_import_constants(h, p, n, s); }
+    int broadcast(void *buf, uint64_t n, int root) {
+        const bool small = n <= 64;                      // the size word lives on the host: staged through word_dev
+        void *dev = small ? (void *)word_dev : buf;
+        if (small && (hipMemcpyAsync(dev, buf, n, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) { transport_error = "staging a word"; return 1; }
+        if (int e = R.Broadcast(dev, dev, n, 1 /*ncclUint8*/, root, comm, s)) { transport_error = R.GetErrorString(e); return 1; }
+        if (small && (hipMemcpyAsync(buf, dev, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) { transport_error = "reading a word back"; return 1; }
+        return 0;
+    }
+    int agree(int code) {                                // the most severe (most negative) code of all ranks; codes are <= 0
+        if (!R.AllReduce) return code;                   // (an RCCL without ncclAllReduce does not exist; a stub in a test may leave it out)
+        int v = -code;
+        if (hipMemcpyAsync(word_dev + 8, &v, sizeof v, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return code ? code : SYN_ERR_HIP;
+        if (int e = R.AllReduce(word_dev + 8, word_dev + 8, 1, 2 /*ncclInt32*/, 2 /*ncclMax*/, comm, s)) { transport_error = R.GetErrorString(e); return code ? code : SYN_ERR_HIP; }
+        if (hipMemcpyAsync(&v, word_dev + 8, sizeof v, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return code ? code : SYN_ERR_HIP;
+        return -v;
+    }
+};
 }  // namespace
 
+// A collective fails collectively (bcast_protocol.h): a root that has loaded nothing, or cannot stage its blob, says so IN the first
+// broadcast and every rank returns that error together; a rank that cannot stage or import says so in an agreement step (all-reduce of the
+// status) and every rank returns it.  The one failure that stays local is a rank that cannot allocate the 256-byte word buffer: it has no
+// device memory to join a collective with.
 int syn_bcast_constants(syn_handle *h, void *nccl_comm, int root, void *stream) {
     if (!h) return fail(SYN_ERR_INVALID, "syn_bcast_constants: NULL handle");
     if (!nccl_comm) return fail(SYN_ERR_INVALID, "syn_bcast_constants: NULL communicator");
     if (root < 0) return fail(SYN_ERR_INVALID, "syn_bcast_constants: root %d", root);
     const RcclApi &R = rccl_api();
-    if (!R.ok) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: no RCCL in this process (ncclBroadcast / ncclCommUserRank not found, librccl.so.1 not loadable)");
+    if (!R.ok) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: no RCCL in this process (ncclBroadcast / ncclCommUserRank not found, librccl.so.1 not loadable; SYNERGY_HIP_RCCL_LIB names an instance explicitly)");
     DeviceGuard g(h->device);
-    hipStream_t s = (hipStream_t)stream;
     int rank = -1;
     if (int e = R.CommUserRank(nccl_comm, &rank)) return fail(SYN_ERR_HIP, "syn_bcast_constants: ncclCommUserRank: %s", R.GetErrorString(e));
-    // two collectives, both on device memory: the blob's size (a replica that has loaded nothing cannot know it), then the blob
-    unsigned long long n_host = rank == root ? (unsigned long long)syn_constants_bytes(h) : 0ull, *n_dev = nullptr;
-    if (rank == root && !h->d_backbone && !h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: the root handle has loaded nothing");
-    HIP_TRY(hipMalloc((void **)&n_dev, 256));
-    char *blob = nullptr;
-    int rc = SYN_OK;
-    auto finish = [&](int code) { if (n_dev) (void)hipFree(n_dev); if (blob) (void)hipFree(blob); return code; };
-    if (hipMemcpyAsync(n_dev, &n_host, sizeof n_host, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: staging the size failed"));
-    if (int e = R.Broadcast(n_dev, n_dev, sizeof n_host, 1 /*ncclUint8*/, root, nccl_comm, s))
-        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: ncclBroadcast(size): %s", R.GetErrorString(e)));
-    if (hipMemcpyAsync(&n_host, n_dev, sizeof n_host, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: reading the size back failed"));
-    if (n_host < sizeof(ConstHeader) || n_host > (1ull << 34)) return finish(fail(SYN_ERR_INVALID, "syn_bcast_constants: implausible blob size %llu", n_host));
-    if (hipMalloc((void **)&blob, n_host) != hipSuccess) return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: %llu bytes of staging", n_host));
-    if (rank == root && (rc = syn_export_constants(h, blob, n_host, stream))) return finish(rc);
-    if (int e = R.Broadcast(blob, blob, n_host, 1 /*ncclUint8*/, root, nccl_comm, s))
-        return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: ncclBroadcast(%llu bytes): %s", n_host, R.GetErrorString(e)));
-    if (rank != root && (rc = syn_import_constants(h, blob, n_host, stream))) return finish(rc);
-    if (hipStreamSynchronize(s) != hipSuccess) return finish(fail(SYN_ERR_HIP, "syn_bcast_constants: stream synchronisation failed"));
-    return finish(SYN_OK);
+    RcclBcastOps ops{h, nccl_comm, (hipStream_t)stream, R, rank};
+    HIP_TRY(hipMalloc((void **)&ops.word_dev, 256));
+    const char *where = "";
+    const int rc = syn::bcast_constants_protocol(ops, root, SYN_ERR_NOT_LOADED, SYN_ERR_HIP, SYN_ERR_HIP, SYN_ERR_INVALID, &where);
+    (void)hipFree(ops.word_dev);
+    if (rc) return fail(rc, "syn_bcast_constants (rank %d, root %d): %s%s%s", rank, root, where, ops.transport_error ? ": " : "", ops.transport_error ? ops.transport_error : "");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(SYN_ERR_HIP, "syn_bcast_constants: stream synchronisation failed");
+    return SYN_OK;
 }
 
 size_t syn_constants_bytes(syn_handle *h) {

@@ -384,6 +384,7 @@ class SynergyNet(nn.Module):
             self.arch = ('mobilenet_v2', 'resnet50')[hdr['arch']]
             self._have_backbone = True
             self._range_checked = False
+            self._range_events = 0          # the C side starts counting from 0 again on an import (a stale count here hid the next warning)
             self._warn_numerics()
         if hdr['has_basis']:
             self._n_vert, self._n_lmk = hdr['n_vert'], hdr['n_lmk']
@@ -613,6 +614,10 @@ class SynergyNet(nn.Module):
         # by a pixel for float32 detections)
         kinds = {type(x) for r in flat for x in r[:4]}
         if kinds <= {np.float32}:
+            if int(np.__version__.split('.')[0]) < 2:
+                # NumPy 1.x promotes `np.float32 scalar * 1.2` to float64 but keeps a float32 ARRAY float32: the array form would no longer
+                # be the scalar statement's arithmetic -- take the scalar statement itself there
+                return SynergyNet._face_tables_scalar(flat, n)
             dt = np.float32
         elif kinds <= {float, int, np.float64}:
             dt = np.float64

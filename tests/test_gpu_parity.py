@@ -399,6 +399,30 @@ def test_pitched_and_packed_outputs_are_identical(model, B):
         model.reconstruct(p, roi=roi, dense=True, out=torch.empty((B, n, 3), device='cuda').permute(0, 2, 1))
 
 
+@pytest.mark.parametrize('B', [32, 100])
+def test_packed_rows_with_pad_writable_set_through_the_c_abi(model, B):
+    """ADVICE r4 (recon_kernels.hip): a C caller may pass row_pitch == n together with pad_writable != 0 (there are no pad columns to own).
+    The launcher used to take the straight-line FAST kernel with the packed-row schedule's group count and left vertices >= 128 x that count of
+    every whole face tile unwritten.  Straight through syn_reconstruct_pitched: a 128-byte-aligned packed tensor, pad_writable = 1, every
+    vertex of every face equal to the default pitched output, nothing written outside the tensor."""
+    import torch
+    from synergynet_amd import abi, synth
+    p = torch.from_numpy(synth.make_params(B, seed=91)).cuda()
+    roi = torch.from_numpy(synth.make_rois(B, seed=92)).cuda()
+    n = model._n_vert
+    want = model.reconstruct(p, roi=roi, dense=True)
+    guard = torch.full((B * 3 * n + 64,), 7.0, device='cuda')
+    assert guard.data_ptr() % 128 == 0
+    out = guard[32:32 + B * 3 * n]
+    assert out.data_ptr() % 128 == 0
+    for pad_writable in (1, 0):
+        out.fill_(-3.0)
+        abi.check(abi.lib().syn_reconstruct_pitched(model._h, p.data_ptr(), B, 62, 1, 1, roi.data_ptr(), out.data_ptr(), n, pad_writable, model._stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(B, 3, n), want), f'pad_writable={pad_writable}'
+        assert torch.all(guard[:32] == 7.0) and torch.all(guard[-32:] == 7.0)
+
+
 @pytest.mark.parametrize('B', [1, 5, 37, 300])
 def test_results_do_not_depend_on_workspace_contents(model, B):
     """Scratch buffers are reused across calls and never cleared: fill them with NaN bytes (test hook) and with zeros, the
@@ -495,6 +519,14 @@ def test_bcast_constants_through_the_c_abi_on_a_single_rank_communicator(model):
             lib = abi.lib()
             assert lib.syn_bcast_constants(model._h, None, 0, None) == -1 and b'NULL communicator' in lib.syn_last_error()
             assert lib.syn_bcast_constants(model._h, comm, -1, None) == -1
+            # a root that has loaded nothing says so IN the first collective (size word 0) and returns SYN_ERR_NOT_LOADED = what every other rank
+            # would return with it (csrc/bcast_protocol.h; the N > 1 control flow: tests/test_bcast_protocol_cpu.py) -- and the communicator
+            # is still usable afterwards
+            from synergynet_amd.synergy3DMM import SynergyNet
+            empty = SynergyNet(device='cuda:0', load_constants=False)
+            assert lib.syn_bcast_constants(empty._h, comm, 0, None) == -3 and b'loaded nothing' in lib.syn_last_error()
+            dist.broadcast_constants_rccl(model, comm.value, root=0)
+            assert torch.equal(model.forward_crops_u8(np.zeros((3, 120, 120, 3), np.uint8) + 7), before)
         finally:
             rccl.ncclCommDestroy.argtypes = [C.c_void_p]
             rccl.ncclCommDestroy(comm)
