@@ -273,6 +273,15 @@ int syn_nme(syn_handle *h, const float *fit, const float *gt, const float *roi, 
 int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double *angles,
              float *t3d, void *stream);
 
+/* Landmarks AND pose of a batch in one launch: lmk [B,3,n_lmk] (packed rows) = syn_reconstruct(dense = 0, roi) and angles / t3d =
+ * syn_pose(roi) -- what the reference's get_all_outputs computes per face besides the mesh (synergy3DMM.py:194-201: predict_sparseVert
+ * + predict_pose; utils/inference.py:127-157).  The two calls above remain the boundary; this one exists because as separate calls
+ * the three dependent launches (prologue, contraction, pose) are ~19 us of a 128-face landmarks-only step, one launch is ~6.  The
+ * contraction runs as plain fp32 multiply-adds on the exact fp32 landmark basis (no fp16 pieces): equal to syn_reconstruct's landmarks
+ * to fp32 rounding (~1e-6 of the largest coordinate), pose bit-identical to syn_pose.  SYN_ERR_PARAM_LEN for param_len != 62. */
+int syn_landmarks_pose(syn_handle *h, const float *param, int B, int param_len, int transform, const float *roi /*nullable [B,5]*/,
+                       float *lmk, double *angles /*[B,3] degrees*/, float *t3d /*[B,3]*/, void *stream);
+
 /* predict_pose(..., ret_mat=True) (utils/inference.py:146-157): parse_pose's P = [R | t3d] "without scale" (:86-92),
  * pmat [B,3,4] fp32 row-major; R = normalised rows 0,1 of the de-whitened camera matrix and their cross product, column 3 =
  * the de-whitened translation WITHOUT the ROI affine (the reference concatenates P before predict_pose rescales t3d). */

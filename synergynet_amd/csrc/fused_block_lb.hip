@@ -167,7 +167,10 @@ struct LbStageArgs {
 
 // PARTIAL (small batches, single block per launch): the workgroup (blockIdx.x = two faces, blockIdx.y = slice) walks only the hidden groups
 // of its slice and stores the raw sums of its two streams; lb_reduce_kernel adds the slices in fixed order, rescales, adds BN shift and residual.
-template <class C, class CN, bool FIRST, bool PROF, int FACE_DW, bool STORE = true, bool PARTIAL = false>
+// RED_OFF > 0 (round 5, the eight-wave small-batch chain): the exchange buffer lives RED_OFF dwords behind the fragments instead of aliasing them,
+// which makes the barrier in front of the exchange and the one in front of the hand-over unnecessary (two of a stage's six barriers;
+// B = 128 landmarks-only step 0.308 -> 0.304 ms, with features.7 in the chain 0.300 -> 0.296: gpurun_out/r5c1/b128ab.txt)
+template <class C, class CN, bool FIRST, bool PROF, int FACE_DW, bool STORE = true, bool PARTIAL = false, int RED_OFF = 0>
 __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, int B, unsigned long long (&pt_)[5], unsigned long long &tk) {
     unsigned long long tn = 0;
     const float *__restrict__ X = sa.X;
@@ -445,7 +448,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
     }
 
     // ---- exchange: wave `st` keeps the output tiles mt with (mt & 1) == st and hands the others to its partner ----
-    float *Red = reinterpret_cast<float *>(Xf);
+    float *Red = reinterpret_cast<float *>(Xf + RED_OFF);
     int le = lane;
     asm volatile("" : "+v"(le));                         // (output addresses are computed here, not carried through the loop)
     const int ne = le & 15, ge = le >> 4, pixe = C::S2 ? ne : 32 * (ne >> 3) + (ne & 7);      // output pixel of (block 0, lane column ne); block r adds 8 r
@@ -464,7 +467,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         for (int r = 0; r < NB; ++r)
             if (C::RES && !PARTIAL) rs[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (unsigned)(((fc * 64 + pixe + 8 * r) * COUT + nch) * 4), 0, FIRST ? 0 : 1));
     }
-    __syncthreads();                                     // every wave is done reading the fragments
+    if (RED_OFF == 0) __syncthreads();                   // every wave is done reading the fragments (which the exchange buffer aliases)
     constexpr bool HANDOFF = !__is_same(CN, void);
     f32x4 vout[KT][NB];
     if constexpr (C::NS == 2) {
@@ -541,7 +544,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         // ---- hand the block output to the next stage: x 16, split, into the fragment layout of ITS expand GEMM.  This lane holds
         //      channels 16 mt + 4 ge .. + 3 of pixel (r, ne): k32 step mt >> 1, lane group 2 (mt & 1) + (ge >> 1), dwords 2 (ge & 1), + 1 ----
         static_assert(CN::CIN == COUT && !C::S2, "the next block of the chain takes this block's output (8x8)");
-        __syncthreads();                                 // everybody has read the exchange buffer (it aliases the fragments)
+        if (RED_OFF == 0) __syncthreads();               // everybody has read the exchange buffer (it aliases the fragments)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (mt % NSW != st) continue;
@@ -805,6 +808,225 @@ __device__ __forceinline__ void lb7_stage(unsigned *smem, const LbStageArgs &sa,
     SYNL_LAP(4);
 }
 
+// features.7 as the FIRST stage of the eight-wave small-batch chain (one face per workgroup; round 5: B = 128 0.308 -> 0.300 ms, B = 1 0.226 -> 0.220,
+// same tests as the chain without it: test_small_batch_chain_equals_the_block_by_block_schedule, the ragged-batch and threshold tests).
+// lb7_stage gives a face two waves that split the OUTPUT rows and walk all six hidden groups -- one wave per SIMD and a critical path of
+// six groups of 8-10 block expansions.  Here wave w = (hidden stream hs = w >> 2, output block q = w & 3): a wave owns ONE 16-pixel output
+// block (output rows 2 q, 2 q + 1) and every second hidden group (hs, hs + 2, hs + 4).  Per group it expands its own block of the four parity
+// classes and, for q >= 1, block q - 1 of the two odd-row classes (the class row above its first output row, lanes 8-15 of that block):
+// 4 + 2 block expansions instead of 8-10, three groups instead of six.  The two hidden streams of an output block meet through LDS
+// (stream 1 publishes, stream 0 adds -- a fixed order), stream 0 stores and hands the block to features.8's fragment layout.
+template <class CN, int FACE_DW>
+__device__ __forceinline__ void lb7_stage8(unsigned *smem, const LbStageArgs &sa, int B) {
+    const float *__restrict__ X = sa.X;
+    const float *__restrict__ Tlb = sa.Tlb, *__restrict__ p_shift = sa.p_shift;
+    float *__restrict__ Y = sa.Y;
+    constexpr int MT = L7::MT, CIN = L7::CIN, COUT = L7::COUT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wave & 3, hs = wave >> 2;
+    const int f = blockIdx.x;
+    const bool real = f < B;
+    const int fc = real ? f : B - 1;
+    const int n = lane & 15, g = lane >> 4;
+    const unsigned l4 = lane * 4, g4 = g * 4;
+    unsigned *Xf = smem;
+
+    // ---- stage: the 16 class blocks of the face as pre-split B fragments (x 16); wave w converts class w & 3, blocks 2 (w >> 2), + 1 ----
+    {
+        const int c = wave & 3, py = c >> 1, px = c & 1, b0 = 2 * (wave >> 2);
+        f32x4 xv[2][2];
+        bool ok[2];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int b = b0 + bb;
+            const int y = 2 * (2 * b + (n >> 3)) + py, x = 2 * (n & 7) + px;
+            ok[bb] = real && y < L7::H && x < L7::H;
+            const float *src = X + ((size_t)fc * (L7::H * L7::H) + (ok[bb] ? y * L7::H + x : 0)) * CIN + 8 * g;
+            xv[bb][0] = *(const f32x4 *)src;
+            xv[bb][1] = *(const f32x4 *)(src + 4);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            f32x4 a = xv[bb][0], d = xv[bb][1];
+            if (!ok[bb]) { a = (f32x4){0.f, 0.f, 0.f, 0.f}; d = a; }
+            a *= 16.0f; d *= 16.0f;
+            u32x4 pc[2];
+            split2v(a[0], a[1], pc, 0);
+            split2v(a[2], a[3], pc, 1);
+            split2v(d[0], d[1], pc, 2);
+            split2v(d[2], d[3], pc, 3);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *(u32x4 *)&Xf[(((c * 4 + b0 + bb) * 2) + p) * 256 + lane * 4] = pc[p];
+        }
+    }
+    const float mL = (n & 7) != 0 ? 1.f : 0.f;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float *Tb = reinterpret_cast<float *>(smem + FACE_DW + wave * L7::TB_DW);
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(sa.Weh), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(sa.Wlb), 0, 0x7fffffff, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Tlb), 0, 0x7fffffff, 0x00027000);
+    const unsigned l16 = lane * 16;
+    f32x4 tv[2];
+    auto fetch_t = [&](int G) __attribute__((always_inline)) {
+        tv[0] = bload4f(rs_t, l16, G * (L7::TB_DW * 4));
+        tv[1] = bload4f(rs_t, l16 & 511, G * (L7::TB_DW * 4) + 1024);
+    };
+    auto park_t = [&]() __attribute__((always_inline)) {
+        *(f32x4 *)&Tb[l4] = tv[0];
+        *(f32x4 *)&Tb[256 + (l4 & 127)] = tv[1];
+    };
+    const float c6e = Tlb[11 * 32], inv_p = Tlb[11 * 32 + 1];
+    // ReLU6 ceilings: 0 on the padding lanes (column 15 = odd-column classes, j = 7; row 15 = odd-row classes, block 3, i = 7)
+    const float cJ = (n & 7) != 7 ? c6e : 0.f;
+    const float cR0 = (q == 3 && n >= 8) ? 0.f : c6e, cR1 = (q == 3 && n >= 8) ? 0.f : cJ;
+    u32x4 Ae[2][2];
+    auto fetch_e = [&](int G) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Ae[t][p] = bload4(rs_e, l16, G * 4096 + (t * 2 + p) * 1024);
+    };
+    fetch_t(hs);
+    fetch_e(hs);
+    park_t();
+    __syncthreads();
+
+    for (int G = hs; G < L7::NG; G += 2) {
+        // ---- expand: D[t][class] = own block q; Dh[t][class - 2] = block q - 1 of the odd-row classes (q >= 1) ----
+        f32x4 D[2][4], Dh[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 es = *(const f32x4 *)&Tb[10 * 32 + 16 * t + g4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) D[t][c] = es;
+            Dh[t][0] = es; Dh[t][1] = es;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            u32x4 Bx[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) Bx[k][p] = *(const u32x4 *)&Xf[((((c + k) * 4 + q) * 2) + p) * 256 + lane * 4];
+            mac3x4(Ae[0], Bx[0], D[0][c], Ae[1], Bx[0], D[1][c], Ae[0], Bx[1], D[0][c + 1], Ae[1], Bx[1], D[1][c + 1]);
+            SYNL_FENCE();
+        }
+        if (q >= 1) {
+            u32x4 Bx[2][2];
+#pragma unroll
+            for (int c = 2; c < 4; ++c)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) Bx[c - 2][p] = *(const u32x4 *)&Xf[(((c * 4 + q - 1) * 2) + p) * 256 + lane * 4];
+            mac3x4(Ae[0], Bx[0], Dh[0][0], Ae[1], Bx[0], Dh[1][0], Ae[0], Bx[1], Dh[0][1], Ae[1], Bx[1], Dh[1][1]);
+            SYNL_FENCE();
+        }
+        // ---- depthwise 3x3 stride 2 + BN shift + ReLU6, split in place into the B operand of the project step ----
+        u32x4 Ap[3][2];
+        auto fetch_p = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Ap[mt % 3][p] = bload4(rs_p, l16, G * (MT * 2048) + (mt * 2 + p) * 1024);
+        };
+        u32x4 Bd[2];
+#pragma unroll
+        for (int th = 0; th < 4; ++th) {
+            const int t = th >> 1, hf = th & 1;
+            if (th == 3) fetch_p(0);
+            const int c0 = 16 * t + 2 * hf;
+            f32x2 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *(const f32x2 *)&Tb[k * 32 + c0 + g4];
+            const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) w[3 * dy] *= mL;
+            auto relu = [&](const f32x4 &d, float ceil) __attribute__((always_inline)) {
+                f32x2 e;
+                e[0] = relu01(d[2 * hf], ceil);
+                e[1] = relu01(d[2 * hf + 1], ceil);
+                return e;
+            };
+            f32x2 up2, up3;                              // the odd-row classes' row above this block's first row: lanes 8-15 of block q - 1 -> lanes 0-7
+            if (q >= 1) {
+                up2 = dpp2<kRowShl8>(relu(Dh[t][0], c6e));
+                up3 = dpp2<kRowShl8>(relu(Dh[t][1], cJ));
+            } else {
+                up2 = (f32x2){0.f, 0.f}; up3 = up2;      // (row -1: the image border)
+            }
+            const f32x2 E0 = relu(D[t][0], c6e), E1 = relu(D[t][1], cJ);
+            const f32x2 E2 = relu(D[t][2], cR0), E3 = relu(D[t][3], cR1);
+            const f32x2 U2 = dpp2<kRowShr8>(E2) + up2, U3 = dpp2<kRowShr8>(E3) + up3;
+            f32x2 O = dsh;
+            O += dpp2<kRowShr1>(U3) * w[0];
+            O += U2 * w[1];
+            O += U3 * w[2];
+            asm volatile("" : "+v"(O));
+            O += dpp2<kRowShr1>(E1) * w[3];
+            O += E0 * w[4];
+            O += E1 * w[5];
+            asm volatile("" : "+v"(O));
+            O += dpp2<kRowShr1>(E3) * w[6];
+            O += E2 * w[7];
+            O = pk_fma_clamp01(E3, w[8], O);
+            split2v(O[0], O[1], Bd, th);
+            SYNL_FENCE();
+        }
+        // ---- project 1x1, K = this group ----
+        const bool more = G + 2 < L7::NG;
+        fetch_p(1);
+        if (more) { fetch_t(G + 2); fetch_e(G + 2); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt + 2 < MT) fetch_p(mt + 2);
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[mt] = mfmal(Ap[mt % 3][PA[j]], Bd[PB[j]], acc[mt]);
+            SYNL_FENCE();
+        }
+        if (more) park_t();
+    }
+
+    // ---- the two hidden streams of an output block meet (stream 0 + stream 1), then rescale, BN shift, NHWC store and hand-over ----
+    float *Ex = reinterpret_cast<float *>(Xf);
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int ne = le & 15, ge = le >> 4, ox = ne & 7, oy = 2 * q + (ne >> 3);
+    __syncthreads();                                     // every wave is done reading the class fragments
+    if (hs == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *(f32x4 *)&Ex[((q * MT + mt) * 64 + lane) * 4] = acc[mt];
+    }
+    __syncthreads();
+    f32x4 v[MT];
+    if (hs == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int nch = 16 * mt + 4 * ge;
+            v[mt] = (acc[mt] + *(const f32x4 *)&Ex[((q * MT + mt) * 64 + lane) * 4]) * inv_p + *(const f32x4 *)&p_shift[nch];
+            if (real) *(f32x4 *)&Y[((size_t)f * 64 + oy * 8 + ox) * COUT + nch] = v[mt];     // (the next block's residual reads it)
+        }
+    }
+    static_assert(CN::CIN == COUT && !CN::S2, "features.8 takes this block's output");
+    __syncthreads();                                     // the exchange buffer has been read (the hand-over overwrites it)
+    if (hs == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            // pixel (oy, ox) in the next stage's layout: block oy & 3, lane column 8 (oy >> 2) + ox
+            const int kc = mt >> 1, lg = (2 * (mt & 1) + (ge >> 1)) * 16, dw = 2 * (ge & 1);
+            const int r = oy & 3, nn = 8 * (oy >> 2) + ox;
+            const f32x4 vs = real ? v[mt] * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+            unsigned a0, b0, a1, b1;
+            split2h(vs[0], vs[1], a0, b0);
+            split2h(vs[2], vs[3], a1, b1);
+            *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 0) * 256 + (lg + nn) * 4 + dw] = (u32x2){a0, a1};
+            *(u32x2 *)&Xf[((kc * 4 + r) * 2 + 1) * 256 + (lg + nn) * 4 + dw] = (u32x2){b0, b1};
+        }
+    }
+    // (the barrier after the next stage's prologue publishes the fragments)
+}
+
 template <bool PROF = false>
 __global__ __launch_bounds__(L7::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_block_lb7_kernel(LbStageArgs sa, int B, unsigned long long *prof = nullptr) {
@@ -912,17 +1134,32 @@ constexpr int kChainFaceDwE = cmax4(L8e::FACE_DW, L11e::FACE_DW, L12e::FACE_DW, 
 constexpr int kChainLdsDwE = L8e::FPW * kChainFaceDwE + L8e::NW * L8e::TB_DW;
 static_assert(kChainLdsDwE * 4 <= 160 * 1024, "one workgroup per CU");
 
+static_assert(L7::XF_DW <= kChainFaceDwE, "features.7's class fragments fit the chain's face buffer");
+#ifndef SYN_SMALL8_SPLIT
+#define SYN_SMALL8_SPLIT 1             // fragments | exchange buffer side by side, four barriers per stage instead of six (0: the aliased buffer of round 4, for A/B runs)
+#endif
+constexpr int kChainXfDwE = cmax4(L7::XF_DW, L8e::XF_DW, L12e::XF_DW, L14e::XF_DW);
+constexpr int kChainRedDwE = cmax4(L8e::RED_DW, L11e::RED_DW, L12e::RED_DW, L14e::RED_DW);
+constexpr int kRedOffE = SYN_SMALL8_SPLIT ? kChainXfDwE : 0;
+constexpr int kFaceDwE = SYN_SMALL8_SPLIT ? kChainXfDwE + kChainRedDwE : kChainFaceDwE;
+constexpr int kLdsDwE = kFaceDwE + L8e::NW * L8e::TB_DW;
+static_assert(kLdsDwE * 4 <= 160 * 1024, "one workgroup per CU");
+template <bool WITH7 = false>
 __global__ __launch_bounds__(L8e::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb_small8_kernel(LbChainArgs ca, int B) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
-    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDwE];
-    lb_stage<L8e, L8e, true, false, kChainFaceDwE>(smem, ca.s[1], B, pt_, tk);
-    lb_stage<L8e, L8e, false, false, kChainFaceDwE>(smem, ca.s[2], B, pt_, tk);
-    lb_stage<L8e, L11e, false, false, kChainFaceDwE>(smem, ca.s[3], B, pt_, tk);
-    lb_stage<L11e, L12e, false, false, kChainFaceDwE>(smem, ca.s[4], B, pt_, tk);
-    lb_stage<L12e, L12e, false, false, kChainFaceDwE>(smem, ca.s[5], B, pt_, tk);
-    lb_stage<L12e, L14e, false, false, kChainFaceDwE, false>(smem, ca.s[6], B, pt_, tk);
-    lb_stage<L14e, void, false, false, kChainFaceDwE>(smem, ca.s[7], B, pt_, tk);
+    __shared__ __attribute__((aligned(16))) unsigned smem[kLdsDwE];
+    if constexpr (WITH7) {
+        lb7_stage8<L8e, kFaceDwE>(smem, ca.s[0], B);
+        lb_stage<L8e, L8e, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[1], B, pt_, tk);
+    } else
+    lb_stage<L8e, L8e, true, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[1], B, pt_, tk);
+    lb_stage<L8e, L8e, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[2], B, pt_, tk);
+    lb_stage<L8e, L11e, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[3], B, pt_, tk);
+    lb_stage<L11e, L12e, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[4], B, pt_, tk);
+    lb_stage<L12e, L12e, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[5], B, pt_, tk);
+    lb_stage<L12e, L14e, false, false, kFaceDwE, false, false, kRedOffE>(smem, ca.s[6], B, pt_, tk);
+    lb_stage<L14e, void, false, false, kFaceDwE, true, false, kRedOffE>(smem, ca.s[7], B, pt_, tk);
 }
 
 // y = (slice 0 + slice 1 + ... in this order) / (16 Sp) + BN shift (+ x): one thread per four channels of a pixel
@@ -970,10 +1207,14 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 // The chain launch: mode 0 = off (one launch per block), 1 = features.8-13, 2 = features.8-14, 3 = features.7-14 (SYN_LB_CHAIN; default 3)
 constexpr int kChainMin = 384;          // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
 constexpr int kSmallChainMax = 256;     // the one-face-per-workgroup chain: one round of workgroups
+static bool small_f7() {      // features.7 as the first stage of the eight-wave small-batch chain (SYN_SMALL_F7=0: its own launch, as in round 4)
+    static const bool on = !(getenv("SYN_SMALL_F7") && atoi(getenv("SYN_SMALL_F7")) == 0) && !(getenv("SYN_SMALL_NS") && atoi(getenv("SYN_SMALL_NS")) != 8);
+    return on;
+}
 int lb_chain_mode(int B, bool small) {
     static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
     if (chain <= 0) return 0;
-    if (B < kChainMin) return (small && B <= kSmallChainMax) ? 2 : 0;      // (2 = features.8 .. 14: launch_fused_chain_lb picks the small-batch kernel)
+    if (B < kChainMin) return (small && B <= kSmallChainMax) ? (small_f7() ? 3 : 2) : 0;      // (2 = features.8 .. 14: launch_fused_chain_lb picks the small-batch kernel)
     return chain > 3 ? 3 : chain;
 }
 // a[i] = the arguments of features.(first + i), first = 7 | 8, first + n_blocks - 1 = 13 | 14; false: not applicable
@@ -988,9 +1229,10 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int
     if (first == 8) ca.s[0] = ca.s[1];
     if (last == 13) ca.s[7] = ca.s[6];
     if (B < kChainMin) {
-        if (first != 8 || last != 14) return false;
+        if (last != 14 || (first == 7 && !small_f7())) return false;
+        if (first == 7) { fused_chain_lb_small8_kernel<true><<<B, L8e::NT, 0, s>>>(ca, B); return true; }
         static const int small_ns = getenv("SYN_SMALL_NS") ? atoi(getenv("SYN_SMALL_NS")) : 8;      // (4: the four-stream kernel, for A/B: tools/small_ns_ab.sh)
-        if (small_ns == 8) fused_chain_lb_small8_kernel<<<B, L8e::NT, 0, s>>>(ca, B);
+        if (small_ns == 8) fused_chain_lb_small8_kernel<false><<<B, L8e::NT, 0, s>>>(ca, B);
         else fused_chain_lb_small_kernel<<<B, L8s::NT, 0, s>>>(ca, B);
         return true;
     }

@@ -98,13 +98,26 @@ struct Lb4StageArgs {
     int g0 = 0, g1 = 0;      // hidden groups [g0, g1) of this workgroup's slice (g1 = 0: all); slice = blockIdx.y
 };
 
+// SYN_LB4_ABL: TIMING-ONLY ablations (wrong results; tools/build_variant.sh): 1 no weight fetch from L2 | 2 no park into LDS | 4 no exchange
+// barrier | 8 no project-fragment LDS reads | 16 no depthwise arithmetic | 32 no group barrier
+#ifndef SYN_LB4_ABL
+#define SYN_LB4_ABL 0
+#endif
 template <int N>
 __device__ __forceinline__ void lb4_fetch(u32x4 *pf, const unsigned *src /* + 4 lane */, int wave) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) pf[i] = *(const u32x4 *)(src + (wave + 8 * i) * 256);
+    for (int i = 0; i < N; ++i) {
+        if (SYN_LB4_ABL & 1) { pf[i] = (u32x4){(unsigned)wave, 1u, 2u, 3u}; asm volatile("" : "+v"(pf[i])); }
+        else pf[i] = *(const u32x4 *)(src + (wave + 8 * i) * 256);
+    }
 }
 template <int N>
 __device__ __forceinline__ void lb4_park(const u32x4 *pf, unsigned *dst /* + 4 lane */, int wave) {
+    if (SYN_LB4_ABL & 2) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("" :: "v"(pf[i]));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) *(u32x4 *)&dst[(wave + 8 * i) * 256] = pf[i];
 }
@@ -172,7 +185,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
         c6e = t0[11 * 32]; inv_p = t0[11 * 32 + 1];
     }
     for (int G = gb; G < ge; ++G) {
-        __syncthreads();                                 // every wave has written its pieces of group G and is done with group G-1
+        if (!(SYN_LB4_ABL & 32)) __syncthreads();        // every wave has written its pieces of group G and is done with group G-1
         if (G + 1 < ge) lb4_fetch<NPW>(pf, Glb + (size_t)(G + 1) * C::GRP_DW + l4, wave);
         else if (HANDOFF) lb4_fetch<NPWN>(pf, GlbNext + l4, wave);          // the next block's first group
         const unsigned *We = smem + ((G - gb) & 1) * GRPL, *Wp = We + C::WE_DW;
@@ -227,11 +240,16 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
 #pragma unroll
         for (int i = 0; i < MTW0; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) Ap[i][p] = *(const u32x4 *)&Wp[((t * MTW + i) * 2 + p) * 256 + l4];
+            for (int p = 0; p < 2; ++p) {
+                if (SYN_LB4_ABL & 8) Ap[i][p] = Ae[i % KE][p];
+                else Ap[i][p] = *(const u32x4 *)&Wp[((t * MTW + i) * 2 + p) * 256 + l4];
+            }
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- ReLU6, depthwise 3x3 + BN shift + ReLU6 on the registers, split into this wave's half of the project operand ----
         u32x4 own;                                      // {piece 0 dwords hf 0, 1 | piece 1 dwords hf 0, 1}
+        if (SYN_LB4_ABL & 16) own = __builtin_bit_cast(u32x4, D);
+        else
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
 #ifdef SYN_LB4_V1
@@ -277,7 +295,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
         }
         // ---- the partner's half: K slots 0-3 of a lane group are tile 0's channels, 4-7 tile 1's ----
         *(u32x4 *)&Xch[((fl * 2 + t) * 64 + lane) * 4] = own;
-        __syncthreads();
+        if (!(SYN_LB4_ABL & 4)) __syncthreads();
         const u32x4 oth = *(const u32x4 *)&Xch[((fl * 2 + (1 - t)) * 64 + lane) * 4];
 #pragma unroll
         for (int i = MTW0; i < MTW; ++i)

@@ -70,8 +70,13 @@ __device__ __forceinline__ float from_right(float v) {
 }
 }  // namespace
 
-template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false, int WREG_ = 0, int NBD_ = 1>
+template <int CIN_, int HID_, int COUT_, int H_, int S_, int NF_, bool RES_, int WPE_, int U_, bool LEAN_ = false, int WREG_ = 0, int NBD_ = 1, bool SVC2_ = false>
 struct RmCfg {
+    // SVC2 (round 5, features.5/6): TWO service waves per unit -- one stages the block-input rows, the other reduces the partial sums and stores --
+    // so that the 2 x 6 compute + 4 service waves of a workgroup fill the four SIMDs evenly (3 + 1 each).  With one service wave per unit the
+    // two of them sat on SIMD 0 and 1 beside three compute waves each, and every row step ended when THOSE SIMDs were done.
+    static constexpr bool SVC2 = SVC2_;
+    static constexpr int NSVW = SVC2_ ? 2 * U_ : U_;           // service waves of a workgroup
     static constexpr int CIN = CIN_, HID = HID_, COUT = COUT_, H = H_, S = S_, NF = NF_, WPE = WPE_, U = U_;
     static constexpr bool RES = RES_;
     // LEAN (features.5/6: six hidden groups, two units = 14 waves want 4 waves per SIMD, i.e. <= 128 registers, and 160 KB of LDS):
@@ -94,11 +99,12 @@ struct RmCfg {
     static constexpr int NBD = NBD_, HB = HO / NBD;
     static constexpr int BSTEPS = S == 1 ? cdivr(HB + 2, 3) * 3 : 2 * (HB + 1);
     static_assert(HO % NBD == 0 && (NBD == 1 || !LEAN_), "bands: equal heights; not implemented for the one-slot (LEAN) sums");
+    static_assert(!SVC2_ || NBD_ == 1, "two service waves per unit: implemented for the whole-face march");
     // A workgroup carries U independent units (a unit = NF faces marching together) on one barrier: NG compute waves each
     // (wave ids 0 .. U*NG-1) and one service wave each (ids U*NG ..).  One big workgroup, not several small ones: the hardware
     // reserves ceil(waves / 4) wave slots on EVERY SIMD per workgroup, so two 5-wave workgroups never share a CU at 3 waves
     // per SIMD.
-    static constexpr int NW = NG, NCW = U * NG, NT = (NCW + U) * 64;
+    static constexpr int NW = NG, NCW = U * NG, NT = (NCW + NSVW) * 64;
     static constexpr int FR = NB * KS;                   // block-input fragments per input row
     static constexpr int XP_DW = FR * 2 * 256, PART_DW = NW * NQ * 256;
     static constexpr int PSLOTS = LEAN ? 1 : 2;
@@ -137,7 +143,9 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool service = wave_wg >= C::NCW;
-    const int uw = service ? wave_wg - C::NCW : wave_wg / NW;                 // unit inside the workgroup
+    const int uw = service ? (wave_wg - C::NCW) % C::U : wave_wg / NW;        // unit inside the workgroup
+    // service roles (SVC2: wave NCW + u stages the rows of unit u, wave NCW + U + u reduces its sums; otherwise one wave does both)
+    const bool svc_in = !C::SVC2 || wave_wg - C::NCW < C::U, svc_out = !C::SVC2 || wave_wg - C::NCW >= C::U;
     const int wave = service ? 0 : wave_wg % NW;                              // hidden group inside the unit (compute waves)
     unsigned *Xp = smem + uw * C::UNIT_DW;                                    // per unit: [2][FR][2][64][4]
     float *Part = reinterpret_cast<float *>(Xp + 2 * C::XP_DW);               // per unit: [2][NW][NQ][64][4]
@@ -271,34 +279,32 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                 else if (NS == HB + 2) reduce_row(r0 + HB - 1, (NS - 1) & 1);
                 continue;
             }
-            load_row(0);
-            store_row(0);
-            load_row(1);                                      // in flight across the barrier
+            if (svc_in) { load_row(0); store_row(0); load_row(1); }     // (row 1 in flight across the barrier)
             SYNR_BARRIER();                                  // (P) row 0 is in slot 0
             if (C::S == 1) {
-                load_res(0);
+                if (svc_out) load_res(0);
                 constexpr int PM = C::PSLOTS - 1;             // partial-sum slot of output row r: r & PM
                 for (int y = 0; y < H; ++y) {
-                    if (y >= 2) reduce_row(y - 2, y & PM);    // completed by the barrier that ended step y-1; the slot is rewritten in step y+1 (LEAN: y, after the barrier below)
+                    if (svc_out && y >= 2) reduce_row(y - 2, y & PM);    // completed by the barrier that ended step y-1; the slot is rewritten in step y+1 (LEAN: y, after the barrier below)
                     if (C::LEAN) SYNR_BARRIER();              // the compute waves write this step's sums only after it
-                    load_res(y - 1);                          // for the next step's reduction
-                    if (y + 1 < H) store_row((y + 1) & 1);    // row y+1 (requested a step ago); slot (y+1)&1 was last read in step y-1
-                    if (y + 2 < H) load_row(y + 2);
+                    if (svc_out) load_res(y - 1);             // for the next step's reduction
+                    if (svc_in && y + 1 < H) store_row((y + 1) & 1);    // row y+1 (requested a step ago); slot (y+1)&1 was last read in step y-1
+                    if (svc_in && y + 2 < H) load_row(y + 2);
                     SYNR_BARRIER();
                 }
-                reduce_row(H - 2, (H - 2) & PM);
+                if (svc_out) reduce_row(H - 2, (H - 2) & PM);
                 if (C::LEAN) SYNR_BARRIER();
-                load_res(H - 1);
+                if (svc_out) load_res(H - 1);
                 SYNR_BARRIER();                              // the compute waves finalized the last row
-                reduce_row(H - 1, (H - 1) & PM);
+                if (svc_out) reduce_row(H - 1, (H - 1) & PM);
             } else {
                 for (int y = 0; y < H; ++y) {
-                    if (!(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
-                    if (y + 1 < H) store_row((y + 1) & 1);
-                    if (y + 2 < H) load_row(y + 2);
+                    if (svc_out && !(y & 1) && y >= 2) reduce_row((y >> 1) - 1, ((y >> 1) - 1) & 1);     // completed by the barrier that ended odd step y-1
+                    if (svc_in && y + 1 < H) store_row((y + 1) & 1);
+                    if (svc_in && y + 2 < H) load_row(y + 2);
                     SYNR_BARRIER();
                 }
-                reduce_row(HO - 1, (HO - 1) & 1);
+                if (svc_out) reduce_row(HO - 1, (HO - 1) & 1);
             }
         }
         if (PROF && lane == 0) atomicAdd(&prof[8 + wave_wg], busy_);
@@ -628,7 +634,10 @@ template <int U> using R2 = RmCfg< 16,  96,  24, 60, 2, 1, false, (U == 4 ? 4 : 
 #endif
 template <int U> using R3 = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG>;                   // features.3   30            U x (5 + 1) waves
 template <int U> using R4 = RmCfg< 24, 144,  32, 30, 2, 2, false, 3, U>;                   // features.4   30 -> 15      U x (5 + 1) waves, two faces per unit
-template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true>;             // features.5/6 15            U x (6 + 1) waves, two faces per unit, 4 per SIMD
+#ifndef SYN_R5_SVC2
+#define SYN_R5_SVC2 1
+#endif
+template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true, 0, 1, SYN_R5_SVC2 != 0>;    // features.5/6 15     U x (6 + 2) waves, two faces per unit, 4 per SIMD
 // small batches: NBD row bands per face (RmCfg::NBD).  A band march has a floor of its own -- its steps are a dependent chain of ~1.3-2 us
 // each whatever the batch (features.2: 12 steps + prologue = 16-18 us at B = 1, features.3: 25) -- against 12 us for the tiled kernels, so the
 // bands pay in a window: features.2 from ~40 faces (B = 64 / 128 / 256: 20 / 24 / 38 us against 24 / 36 / 57 tiled; six bands of five output

@@ -622,15 +622,10 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
 // predict_pose: one lane per face.  fp32 for the de-whitening / normalisation / cross product
 // (numpy float32 in the reference), double for asin/atan2/cos (python math on the float32 values).
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ param, const float *__restrict__ mean,
-                                                  const float *__restrict__ stdv, const float *__restrict__ roi,
-                                                  double *__restrict__ angles, float *__restrict__ t3d,
-                                                  float *__restrict__ pmat /*nullable [B,3,4]*/, int B) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    float p[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) p[i] = param[(size_t)b * kParam + i] * stdv[i] + mean[i];
+// the pose arithmetic of one face (shared by pose_kernel and lmk_pose_kernel so that both produce the same bits): p = the face's 12
+// de-whitened pose parameters
+__device__ __forceinline__ void pose_of_face(const float (&p)[12], const float *__restrict__ roi5 /*nullable*/, double *__restrict__ angles3 /*nullable*/,
+                                             float *__restrict__ t3d3, float *__restrict__ pmat12 /*nullable*/) {
     const float n1 = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);      // P2sRt (:33-43)
     const float n2 = sqrtf(p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
     const float r1[3] = {p[0] / n1, p[1] / n1, p[2] / n1};
@@ -649,30 +644,116 @@ __global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ para
         if (r3[0] == -1.0f) { x = PI / 2; y = z + atan2((double)r1[1], (double)r1[2]); }
         else                { x = -PI / 2; y = -z + atan2(-(double)r1[1], -(double)r1[2]); }
     }
-    if (pmat) {           // parse_pose's P = [R | t3d] "without scale" (:90), built BEFORE predict_pose's ROI affine touches t3d
-        float *m = pmat + (size_t)b * 12;
+    if (pmat12) {           // parse_pose's P = [R | t3d] "without scale" (:90), built BEFORE predict_pose's ROI affine touches t3d
+        float *m = pmat12;
         m[0] = r1[0]; m[1] = r1[1]; m[2] = r1[2]; m[3] = p[3];
         m[4] = r2[0]; m[5] = r2[1]; m[6] = r2[2]; m[7] = p[7];
         m[8] = r3[0]; m[9] = r3[1]; m[10] = r3[2]; m[11] = p[11];
     }
-    if (!angles) return;
-    angles[(size_t)b * 3 + 0] = x * 180.0 / PI;
-    angles[(size_t)b * 3 + 1] = y * 180.0 / PI;
-    angles[(size_t)b * 3 + 2] = z * 180.0 / PI;
+    if (!angles3) return;
+    angles3[0] = x * 180.0 / PI;
+    angles3[1] = y * 180.0 / PI;
+    angles3[2] = z * 180.0 / PI;
     float tx = p[3], ty = p[7], tz = p[11];
-    if (roi) {                                                              // predict_pose (:149-154)
-        const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
+    if (roi5) {                                                             // predict_pose (:149-154)
+        const float sx = roi5[0], sy = roi5[1], ex = roi5[2], ey = roi5[3];
         tx = tx * ((ex - sx) / 120.0f) + sx;
         ty = ty * ((ey - sy) / 120.0f) + sy;
     }
-    t3d[(size_t)b * 3 + 0] = tx;
-    t3d[(size_t)b * 3 + 1] = ty;
-    t3d[(size_t)b * 3 + 2] = tz;
+    t3d3[0] = tx;
+    t3d3[1] = ty;
+    t3d3[2] = tz;
+}
+
+__global__ __launch_bounds__(64) void pose_kernel(const float *__restrict__ param, const float *__restrict__ mean,
+                                                  const float *__restrict__ stdv, const float *__restrict__ roi,
+                                                  double *__restrict__ angles, float *__restrict__ t3d,
+                                                  float *__restrict__ pmat /*nullable [B,3,4]*/, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float p[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = param[(size_t)b * kParam + i] * stdv[i] + mean[i];
+    pose_of_face(p, roi ? roi + (size_t)b * 5 : nullptr, angles ? angles + (size_t)b * 3 : nullptr, t3d + (size_t)b * 3, pmat ? pmat + (size_t)b * 12 : nullptr);
 }
 
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi, double *angles,
                  float *t3d, float *pmat, int B, hipStream_t s) {
     pose_kernel<<<(B + 63) / 64, 64, 0, s>>>(param, mean62, std62, roi, angles, t3d, pmat, B);
+}
+
+// -------------------------------------------------------------------------------------
+// Landmarks + pose of a batch in ONE launch (round 5): what get_all_outputs computes per face besides the mesh
+// (synergy3DMM.py:194-201: predict_sparseVert + predict_pose).  As separate calls it is three dependent launches of 4-8 us each
+// (prologue, contraction, pose) for 10.6 k multiply-adds per face -- 19 of the 300 us of a BASELINE configs[1] step.  One workgroup per
+// face: de-whitening, the [204 x 52] landmark contraction as plain fp32 fused multiply-adds over k = 0 .. 51 in order (the exact-fp32
+// landmark tiles of the handle, layout of recon_kernel above: no operand split, nothing to range-check), the pose / flip / ROI affine
+// of recon_prep_kernel, and pose_of_face on lane 0.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lmk_pose_kernel(const float *__restrict__ param, const float *__restrict__ mean, const float *__restrict__ stdv,
+                                                       const float *__restrict__ basis /*fp32 landmark tiles*/, int n_lmk, int nlp,
+                                                       const float *__restrict__ roi, int transform, float *__restrict__ lmk /*[B,3,n_lmk]*/,
+                                                       double *__restrict__ angles, float *__restrict__ t3d, int B) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    __shared__ float p[64], aff[12];
+    extern __shared__ float S[];                     // [3][nlp]
+    if (l < kParam) p[l] = param[(size_t)b * kParam + l] * stdv[l] + mean[l];
+    __syncthreads();
+    if (l < 3) {                                     // out = Mx * S + T of recon_prep_kernel (same expressions)
+        const int c = l;
+        float sc = 1.0f, of = 0.0f;
+        if (roi) {
+            const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
+            const float scx = (ex - sx) / 120.0f, scy = (ey - sy) / 120.0f;
+            if (c == 0) { sc = scx; of = sx; }
+            else if (c == 1) { sc = scy; of = sy; }
+            else { sc = (scx + scy) * 0.5f; }
+        }
+        float m0 = p[4 * c + 0], m1 = p[4 * c + 1], m2 = p[4 * c + 2], t = p[4 * c + 3];
+        if (transform && c == 1) { m0 = -m0; m1 = -m1; m2 = -m2; t = (float)(kImg + 1) - t; }
+        aff[3 * c + 0] = m0 * sc;
+        aff[3 * c + 1] = m1 * sc;
+        aff[3 * c + 2] = m2 * sc;
+        aff[9 + c] = t * sc + of;
+    }
+    if (l == 0 && angles) {
+        float pp[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pp[i] = p[i];
+        pose_of_face(pp, roi ? roi + (size_t)b * 5 : nullptr, angles + (size_t)b * 3, t3d + (size_t)b * 3, nullptr);
+    }
+    // S[c][v] = sum_k basis[v][c][k] alpha[k]: element k = 8 t + 4 h + s of (tile T, coord c, column j) sits at
+    // T * 3 * 52 * 32 + c * 52 * 32 + t * 256 + (32 h + j) * 4 + s; the tail k = 48 + 2 h + s at ... + 6 * 256 + (32 h + j) * 2 + s (k = 50: the mean
+    // shape, coefficient 1; k = 51: zero pad)
+    for (int i = l; i < 3 * nlp; i += 256) {
+        const int c = i / nlp, v = i - c * nlp, T = v >> 5, j = v & 31;
+        const float *bc = basis + ((size_t)T * 3 + c) * (kBasisK * 32);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 w = *(const f32x4 *)(bc + t * 256 + (32 * h + j) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_fmaf(w[s], p[12 + 8 * t + 4 * h + s], acc);
+            }
+        const f32x2 w0 = *(const f32x2 *)(bc + 6 * 256 + j * 2), w1 = *(const f32x2 *)(bc + 6 * 256 + (32 + j) * 2);
+        acc = __builtin_fmaf(w0[0], p[12 + 48], acc);
+        acc = __builtin_fmaf(w0[1], p[12 + 49], acc);
+        acc += w1[0];                                // the mean shape
+        S[i] = acc;
+    }
+    __syncthreads();
+    for (int i = l; i < 3 * n_lmk; i += 256) {
+        const int c = i / n_lmk, v = i - c * n_lmk;
+        const float sx = S[v], sy = S[nlp + v], sz = S[2 * nlp + v];
+        lmk[((size_t)b * 3 + c) * n_lmk + v] = aff[3 * c + 0] * sx + aff[3 * c + 1] * sy + aff[3 * c + 2] * sz + aff[9 + c];
+    }
+}
+
+void launch_lmk_pose(const float *param, const float *mean62, const float *std62, const float *basis_lmk, int n_lmk, int nlp, const float *roi,
+                     int transform, float *lmk, double *angles, float *t3d, int B, hipStream_t s) {
+    lmk_pose_kernel<<<B, 256, 3 * nlp * sizeof(float), s>>>(param, mean62, std62, basis_lmk, n_lmk, nlp, roi, transform, lmk, angles, t3d, B);
 }
 
 }  // namespace syn

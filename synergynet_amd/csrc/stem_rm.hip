@@ -17,8 +17,9 @@
 //   * depthwise 3x3 scattered into three row accumulators, neighbours through wave_shr / wave_shl, filter from LDS
 //     (broadcast reads); ReLU6 -> in-place fp16 x2 split = B operand of the 32->16 projection (rows 16..31 of its A tile are
 //     zero), BN shift, NHWC store straight from the compute wave -- one hidden group, so there is no partial-sum exchange;
-//   * ONE service wave per workgroup keeps the image rows of all units flowing: buffer loads one stage ahead (counted vmcnt, no
-//     branches) -> fp16 -> LDS row ring (8 slots per unit), one barrier per output row.
+//   * service waves keep the image rows of all units flowing: buffer loads one stage ahead (counted vmcnt, no branches) -> fp16 -> LDS
+//     row ring (8 slots per unit), one barrier per output row.  Four of them since round 5, one per SIMD, a quarter of a stage each
+//     (StemRmCfg::NSV: a single one made SIMD 0 the slowest SIMD of every step).
 // fp32 crops (forward_test): the F32 instantiation below (round 4).  Small batches: row bands of a face from 112 faces on (StemRmCfg::NBD),
 // the tiled kernel of stem_block1.hip below that (and for fp32 crops below 480).
 #include "syn_internal.h"
@@ -84,7 +85,13 @@ struct StemRmCfg {
     static constexpr int NBD = NBD_, HB = 60 / NBD;
     static constexpr int BSTEPS = (HB + 2 + 2) / 3 * 3, BSTG = BSTEPS + 2;
     static_assert(60 % NBD == 0 && (NBD == 1 || (!F32_ && BSTG % 2 == 0)), "bands: equal heights, uint8 crops, stages in pairs");
-    static constexpr int NSV = F32 ? 2 : 1;                        // service waves (F32: splitting 2 x 360 floats per face and step is two waves' work)
+    // service waves.  Round 5: FOUR, one per SIMD (wave ids NCW .. NCW + 3 follow the 2 U compute waves cyclically), each converting a quarter of a
+    // stage.  One service wave (two for F32) sat on SIMD 0 (and 1) beside that SIMD's two compute waves: ~600 of its ~3600 issue cycles per row
+    // step against ~3000 on the other SIMDs, and every step ends at a workgroup barrier -- the whole chip ran at SIMD 0's pace.
+#ifndef SYN_STEM_NSV
+#define SYN_STEM_NSV 4
+#endif
+    static constexpr int NSV = SYN_STEM_NSV > 0 ? SYN_STEM_NSV : (F32 ? 2 : 1);
     static constexpr int NCW = 2 * U, NT = (NCW + NSV) * 64;       // compute waves (face, half) + the service wave(s)
     static constexpr int SLOT_DW = (F32 ? 2 : 1) * kRowDw;         // one image row: plane of high pieces | (F32) plane of low pieces
     static constexpr int UNIT_DW = (kSlots + 1) * SLOT_DW;         // ring + one all-padding row (image row -1)
@@ -186,13 +193,14 @@ void stem_rm_kernel(const uint8_t *__restrict__ img /*uint8 [B,120,120,3] | F32:
         // (items of eight pixels, 64 bytes apart, put sixteen lanes on every bank: the service wave's stores alone kept the LDS busy a
         // fifth of a row step).  A pixel's three bytes start anywhere in a dword: the dword that holds the first byte and the next one
         // (two loads: the second one of the very last pixel of a batch is out of range and reads 0), v_alignbyte by the lane's own shift.
-        constexpr int TOTAL = C::U * 2 * kImgW, ITER = (TOTAL + 63) / 64;
+        constexpr int TOTAL = C::U * 2 * kImgW, ITER = (TOTAL + 64 * C::NSV - 1) / (64 * C::NSV);
         constexpr unsigned FACE_B = kImgW * kImgW * 3, ROW2_B = 2 * kImgW * 3;
+        const int sv = wave_wg - C::NCW;                                   // the service waves deal the items 64 at a time
         unsigned gofs[ITER], lofs[ITER];
         bool live[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int i = lane + 64 * it;
+            const int i = lane + 64 * (it * C::NSV + sv);
             const int u = i / (2 * kImgW), r = (i / kImgW) % 2, px = i % kImgW;
             live[it] = i < TOTAL;
             gofs[it] = live[it] ? (unsigned)(u * FACE_B + r * (kImgW * 3) + ((3 * px) & ~3)) : 0x80000000u;

@@ -226,5 +226,8 @@ int det_sort_capacity();
 
 void launch_pose(const float *param, const float *mean62, const float *std62, const float *roi,
                  double *angles /*nullable together with t3d*/, float *t3d, float *pmat /*nullable [B,3,4]*/, int B, hipStream_t s);
+// landmarks + pose in one launch (recon_kernels.hip lmk_pose_kernel): fp32 landmark tiles, plain fp32 multiply-adds
+void launch_lmk_pose(const float *param, const float *mean62, const float *std62, const float *basis_lmk, int n_lmk, int nlp, const float *roi,
+                     int transform, float *lmk, double *angles, float *t3d, int B, hipStream_t s);
 
 }  // namespace syn

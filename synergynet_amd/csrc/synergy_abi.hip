@@ -2454,6 +2454,18 @@ int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double 
     return SYN_OK;
 }
 
+int syn_landmarks_pose(syn_handle *h, const float *param, int B, int param_len, int transform, const float *roi, float *lmk, double *angles,
+                       float *t3d, void *stream) {
+    if (!h || !param || !lmk || !angles || !t3d) return fail(SYN_ERR_INVALID, "syn_landmarks_pose: NULL argument");
+    if (param_len != SYN_PARAM_DIM) return fail(SYN_ERR_PARAM_LEN, "length of params mismatch");
+    if (B <= 0) return fail(SYN_ERR_INVALID, "syn_landmarks_pose: B=%d", B);
+    if (!h->d_basis) return fail(SYN_ERR_NOT_LOADED, "syn_landmarks_pose: 3DMM basis not loaded");
+    DeviceGuard g(h->device);
+    syn::launch_lmk_pose(param, basis_mean(h), basis_std(h), basis_lmk(h), h->n_lmk, h->nlp, roi, transform, lmk, angles, t3d, B, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return SYN_OK;
+}
+
 int syn_pose_matrix(syn_handle *h, const float *param, int B, float *pmat, void *stream) {
     if (!h || !param || !pmat) return fail(SYN_ERR_INVALID, "syn_pose_matrix: NULL argument");
     if (B <= 0) return fail(SYN_ERR_INVALID, "syn_pose_matrix: B=%d", B);

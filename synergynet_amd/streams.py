@@ -60,9 +60,8 @@ class OverlappedPipeline:
             if self._tail_stream is not s_tail and self.last_done is not None:
                 s_tail.wait_event(self.last_done)      # (a dense batch's tail may still use the handle's reconstruction records on the other stream)
             self._tail_stream = s_tail
-            lmk = m.reconstruct(param, roi=rois, dense=False, out=lmk_out)
+            lmk, pose = m.landmarks_and_pose(param, roi=rois, out=lmk_out)        # one launch (round 5; was prologue + contraction + pose)
             mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out) if dense else None
-            pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
             done.record(s_tail)
         self._inflight[k] = ((param, lmk, mesh, pose, crops_u8, rois), done)
@@ -103,9 +102,8 @@ class ReplicaRing:
         st.wait_stream(torch.cuda.current_stream(m.device))          # the inputs were produced on the caller's stream
         with torch.cuda.stream(st):
             param = m.forward_crops_u8(crops_u8)
-            lmk = m.reconstruct(param, roi=rois, dense=False, out=lmk_out)
+            lmk, pose = m.landmarks_and_pose(param, roi=rois, out=lmk_out)
             mesh = m.reconstruct(param, roi=rois, dense=True, out=mesh_out) if dense else None
-            pose = m.predict_pose_batch(param, rois)
             done = torch.cuda.Event()
             done.record(st)
         for t in (crops_u8, rois):              # (numpy inputs / roi=None are staged by the calls above into tensors of their own)

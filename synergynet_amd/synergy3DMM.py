@@ -506,6 +506,30 @@ class SynergyNet(nn.Module):
                                          ang.data_ptr(), t3d.data_ptr(), self._stream()))
         return ang, t3d
 
+    def landmarks_and_pose(self, param, roi=None, transform=True, out=None):
+        """`reconstruct(param, roi, dense=False, transform)` and `predict_pose_batch(param, roi)` in ONE launch (syn_landmarks_pose): what
+        get_all_outputs needs per face besides the mesh (reference synergy3DMM.py:194-201).  Returns (lmk [B,3,68], (angles [B,3] float64, t3d
+        [B,3])); landmarks equal to `reconstruct`'s to fp32 rounding, pose the same bits as `predict_pose_batch`."""
+        p = self._dev_f32(param)
+        if p.dim() != 2:
+            raise RuntimeError('param must be [B,62]')
+        if p.shape[1] != 62:
+            raise RuntimeError('length of params mismatch')
+        B, n = p.shape[0], self._n_lmk
+        r = self._dev_f32(roi) if roi is not None else None
+        if r is not None and tuple(r.shape) != (B, 5):
+            raise RuntimeError('roi must be [B,5] (sx,sy,ex,ey,score)')
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((B, 3, n), dtype=torch.float32, device=self.device)
+            if tuple(out.shape) != (B, 3, n) or out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous():
+                raise RuntimeError(f'out must be a contiguous float32 [B,3,{n}] tensor on {self.device}')
+            ang = torch.empty((B, 3), dtype=torch.float64, device=self.device)
+            t3d = torch.empty((B, 3), dtype=torch.float32, device=self.device)
+            abi.check(self._lib.syn_landmarks_pose(self._h, p.data_ptr(), B, 62, int(transform), r.data_ptr() if r is not None else None,
+                                                   out.data_ptr(), ang.data_ptr(), t3d.data_ptr(), self._stream()))
+        return out, (ang, t3d)
+
     def pose_matrix_batch(self, param):
         """Batched predict_pose(..., ret_mat=True) (utils/inference.py:146-157): [B,3,4] fp32 = [R | t3d] of parse_pose
         (:86-92), the translation column WITHOUT the ROI affine (the reference builds P before rescaling t3d)."""
@@ -741,8 +765,7 @@ class SynergyNet(nn.Module):
                                                            box_d.data_ptr(), ofs_d[0].data_ptr(), coef_d[0].data_ptr(), ofs_d[1].data_ptr(),
                                                            coef_d[1].data_ptr(), crops.data_ptr(), m, self._stream()))
                 param = self.forward_crops_u8(crops)
-                lmk_d = self.reconstruct(param, roi=roi_d, dense=False, transform=True)
-                ang_d, t3d_d = self.predict_pose_batch(param, roi_d)
+                lmk_d, (ang_d, t3d_d) = self.landmarks_and_pose(param, roi=roi_d, transform=True)
                 mesh_d = None
                 if dense:
                     # packed rows on the device (the kernel's guarded store path; 0.04 us per face more than pitched rows), so that the

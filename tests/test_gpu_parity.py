@@ -149,6 +149,36 @@ def test_roi_vertices_and_pose_match_reference_golden(model, golden):
     assert np.allclose(a, golden['angles'][2], atol=1e-3)
 
 
+def test_landmarks_and_pose_in_one_launch_match_reference_golden_and_the_two_calls(model, golden, basis):
+    """syn_landmarks_pose (round 5): landmarks + pose of a batch in ONE launch -- plain fp32 multiply-adds on the exact landmark basis.
+    Against the REFERENCE's own outputs (golden: predict_sparseVert-shaped landmarks with the ROI affine, predict_pose), against the
+    oracle on ragged batches, and against the two boundary calls it stands for: landmarks to fp32 rounding, pose the same bits."""
+    import torch
+    from oracle import recon_numpy
+    from synergynet_amd import synth
+    lmk, (ang, t3d) = model.landmarks_and_pose(golden['params'], roi=golden['rois'])
+    assert rel_max(lmk.cpu().numpy(), golden['lmk_roi']) < TOL
+    assert np.allclose(ang.cpu().numpy(), golden['angles'], rtol=0, atol=1e-3)
+    assert rel_max(t3d.cpu().numpy(), golden['t3d']) < TOL
+    for tr, key in ((True, 'lmk_batched'), (False, 'lmk_batched_notransform')):
+        got, _ = model.landmarks_and_pose(golden['params'], roi=None, transform=tr)
+        assert rel_max(got.cpu().numpy(), golden[key]) < TOL
+    for B in (1, 5, 33, 300):
+        params = synth.make_params(B, seed=400 + B, scale=1.3)
+        rois = synth.make_rois(B, seed=500 + B)
+        want = recon_numpy.reconstruct_vertex_62(basis, params, dense=False)
+        got, _ = model.landmarks_and_pose(params, roi=None)
+        per_face = np.abs(got.cpu().numpy() - want).reshape(B, -1).max(axis=1) / np.abs(want).reshape(B, -1).max(axis=1)
+        assert per_face.max() < 3e-6                        # an fp32 chain of 52 products against the oracle's fp32 matmul
+        one, (a1, t1) = model.landmarks_and_pose(params, roi=rois)
+        two = model.reconstruct(params, roi=rois, dense=False)
+        a2, t2 = model.predict_pose_batch(params, rois)
+        assert rel_max(one.cpu().numpy(), two.cpu().numpy()) < 3e-6
+        assert torch.equal(a1, a2) and torch.equal(t1, t2)
+    with pytest.raises(RuntimeError, match='length of params mismatch'):
+        model.landmarks_and_pose(torch.zeros(2, 61))
+
+
 @pytest.mark.parametrize('B', [1, 31, 32, 33, 100])
 def test_dense_reconstruction_ragged_batches_match_oracle(model, basis, B):
     from oracle import recon_numpy
@@ -219,7 +249,10 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
 def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd, B):
     """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, eight waves per
     face, the partial sums of the eight streams added in LDS in a fixed order (fused_chain_lb_small8_kernel; SYN_SMALL_NS=4: the four-stream
-    kernel it replaced) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Same arithmetic in another summation order: equal to the block-by-block schedule
+    kernel it replaced) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Round 5: features.7 is the
+    first stage of that launch (lb7_stage8: a wave = hidden stream x output block; SYN_SMALL_F7=0 keeps it a launch of its own) and the
+    exchange buffer no longer aliases the fragments (two barriers per stage fewer) -- the reference schedule below (EARLY_RM without bit
+    10) still runs features.7 ... 14 block by block.  Same arithmetic in another summation order: equal to the block-by-block schedule
     (SYNERGY_HIP_EARLY_RM without bit 10) to fp32 rounding on distinct faces, bitwise independent of the position in the batch, and
     every face within the tolerance of the oracle."""
     import torch
