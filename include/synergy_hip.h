@@ -278,7 +278,7 @@ int syn_pose(syn_handle *h, const float *param, int B, const float *roi, double 
  * + predict_pose; utils/inference.py:127-157).  The two calls above remain the boundary; this one exists because as separate calls
  * the three dependent launches (prologue, contraction, pose) are ~19 us of a 128-face landmarks-only step, one launch is ~6.  The
  * contraction runs as plain fp32 multiply-adds on the exact fp32 landmark basis (no fp16 pieces): equal to syn_reconstruct's landmarks
- * to fp32 rounding (~1e-6 of the largest coordinate), pose bit-identical to syn_pose.  SYN_ERR_PARAM_LEN for param_len != 62. */
+ * to fp32 rounding (~1e-6 of the largest coordinate); translation bit-identical to syn_pose, angles within 1e-4 degree of it.  SYN_ERR_PARAM_LEN for param_len != 62. */
 int syn_landmarks_pose(syn_handle *h, const float *param, int B, int param_len, int transform, const float *roi /*nullable [B,5]*/,
                        float *lmk, double *angles /*[B,3] degrees*/, float *t3d /*[B,3]*/, void *stream);
 

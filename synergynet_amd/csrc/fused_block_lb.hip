@@ -1073,11 +1073,36 @@ static_assert(L8::FACE_DW <= kChainFaceDw && L11::FACE_DW <= kChainFaceDw && L12
 constexpr int kChainLdsDw = L8::FPW * kChainFaceDw + L8::NW * L8::TB_DW;
 static_assert(2 * kChainLdsDw * 4 <= 160 * 1024, "two workgroups per CU");
 
+#ifndef SYN_L2_TOUCH
+#define SYN_L2_TOUCH 1              // 0: no L2 warm-up of the weight fragments (A/B)
+#endif
+// one stage's expand fragments, project fragments and per-group tables (the layouts fetch_e / fetch_p / fetch_t walk)
+template <int NG, int KE, int MT>
+__device__ __forceinline__ void lb_touch_stage(const LbStageArgs &sa, unsigned gi, unsigned nth, unsigned &sink) {
+    l2_touch(sa.Weh, NG * KE * 4096u, gi, nth, sink);
+    l2_touch(sa.Wlb, NG * MT * 2048u, gi, nth, sink);
+    l2_touch(sa.Tlb, NG * 12u * 32u * 4u, gi, nth, sink);
+}
 template <bool WITH7, bool WITH14>
 __global__ __launch_bounds__(L8::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
     __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDw];
+    // every stage's weights (2.6 MB for features.7-14) into this XCD's L2 before the walk starts (syn_internal.h l2_touch): the waves fetch their
+    // fragments one group ahead, which covers an L2 hit but not the miss the first CU of an XCD takes on every group of a cold run
+    // (B = 1024, interleaved on one box: 267.0 against 271.6 us without, gpurun_out/r5c3)
+    unsigned sink = 0;
+    if (SYN_L2_TOUCH) {
+        const unsigned gi = (blockIdx.x >> 3) * (unsigned)L8::NT + threadIdx.x, nth = ((gridDim.x + 7) >> 3) * (unsigned)L8::NT;
+        if (WITH7) lb_touch_stage<L7::NG, 1, L7::MT>(ca.s[0], gi, nth, sink);
+        lb_touch_stage<L8::NG, L8::KE, L8::MT>(ca.s[1], gi, nth, sink);
+        lb_touch_stage<L8::NG, L8::KE, L8::MT>(ca.s[2], gi, nth, sink);
+        lb_touch_stage<L8::NG, L8::KE, L8::MT>(ca.s[3], gi, nth, sink);
+        lb_touch_stage<L11::NG, L11::KE, L11::MT>(ca.s[4], gi, nth, sink);
+        lb_touch_stage<L12::NG, L12::KE, L12::MT>(ca.s[5], gi, nth, sink);
+        lb_touch_stage<L12::NG, L12::KE, L12::MT>(ca.s[6], gi, nth, sink);
+        if (WITH14) lb_touch_stage<L14::NG, L14::KE, L14::MT>(ca.s[7], gi, nth, sink);
+    }
     if constexpr (WITH7) {
         lb7_stage<L8, false, kChainFaceDw>(smem, ca.s[0], B, pt_, tk);
         lb_stage<L8, L8, false, false, kChainFaceDw>(smem, ca.s[1], B, pt_, tk);
@@ -1092,6 +1117,7 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
         lb_stage<L14, void, false, false, kChainFaceDw>(smem, ca.s[7], B, pt_, tk);
     } else
         lb_stage<L12, void, false, false, kChainFaceDw>(smem, ca.s[6], B, pt_, tk);
+    if (SYN_L2_TOUCH) l2_touch_done(sink);
 }
 
 // Small batches (round 4; BASELINE configs[1] is 128 faces): features.8 .. 14 as ONE launch with ONE face per workgroup and FOUR waves

@@ -398,14 +398,30 @@ constexpr int kChain4LdsDw = 2 * kChain4Grp + Q15::XCH_DW;
 static_assert(kChain4LdsDw * 4 <= 160 * 1024 && 4 * 5 * 2 * 256 <= kChain4Grp, "LDS budget; the handed-over fragments of four faces fit one buffer half");
 struct Lb4ChainArgs { Lb4StageArgs s[3]; };
 
+// L2 warm-up of the three weight runs at kernel start (syn_internal.h l2_touch): measured SLOWER here -- 167.4 against 163.3 us, interleaved on one
+// box (gpurun_out/r5c3), while the same touch gains 4.5 us in the features.7-14 chain: this kernel's groups are paced by the LDS (224 KB through
+// it per group) and its two barriers, not by where the weight lines come from.  Off; SYN_LB4_L2_TOUCH=1 builds it for A/B runs.
+#ifndef SYN_LB4_L2_TOUCH
+#define SYN_LB4_L2_TOUCH 0
+#endif
+#define SYN_L2_TOUCH SYN_LB4_L2_TOUCH
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb4_kernel(Lb4ChainArgs ca, int B) {
     __shared__ __attribute__((aligned(16))) unsigned smem[kChain4LdsDw];
     u32x4 Xr[5][2];
     f32x4 vres[5];
+    // the three blocks' weight runs (1.2 + 1.2 + 1.8 MB) into this XCD's L2 before the first group is needed (syn_internal.h l2_touch)
+    unsigned sink = 0;
+    if (SYN_L2_TOUCH) {
+        const unsigned gi = (blockIdx.x >> 3) * 512u + threadIdx.x, nth = ((gridDim.x + 7) >> 3) * 512u;
+        l2_touch(ca.s[0].Glb, Q15::NG * Q15::GRP_DW * 4u, gi, nth, sink);
+        l2_touch(ca.s[1].Glb, Q15::NG * Q15::GRP_DW * 4u, gi, nth, sink);
+        l2_touch(ca.s[2].Glb, Q17::NG * Q17::GRP_DW * 4u, gi, nth, sink);
+    }
     lb4_stage<Q15, Q15, true, kChain4Grp>(smem, ca.s[0], ca.s[1].Glb, B, Xr, vres);
     lb4_stage<Q15, Q17, false, kChain4Grp>(smem, ca.s[1], ca.s[2].Glb, B, Xr, vres);
     lb4_stage<Q17, void, false, kChain4Grp>(smem, ca.s[2], nullptr, B, Xr, vres);
+    if (SYN_L2_TOUCH) l2_touch_done(sink);
 }
 
 template <class C>

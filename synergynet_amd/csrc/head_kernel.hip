@@ -236,6 +236,18 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
     const int nt0 = NS > 1 ? (int)blockIdx.y * NTS : 0, nt_end = nt0 + NTS;
 
     u32x4 ring[5][2];                                   // weight pieces of 5 k-chunks in flight
+    // the 1.6 MB of weight fragments (and the heads' rows) into this XCD's L2 before the walk (syn_internal.h l2_touch; large batches: NS == 1):
+    // measured 1 us SLOWER (50.9 against 49.8 us, gpurun_out/r5c3) -- the ring of five chunks in flight already covers the misses.  Off.
+#ifndef SYN_HEAD_L2_TOUCH
+#define SYN_HEAD_L2_TOUCH 0
+#endif
+#define SYN_L2_TOUCH SYN_HEAD_L2_TOUCH
+    unsigned sink = 0;
+    if (SYN_L2_TOUCH && NS == 1) {
+        const unsigned gi = (blockIdx.x >> 3) * (unsigned)NT + tid, nth = ((gridDim.x + 7) >> 3) * (unsigned)NT;
+        l2_touch(Wb3, 80u * 10u * 2u * 1024u, gi, nth, sink);
+        l2_touch(Wfc, 64u * 1280u * 4u, gi, nth, sink);
+    }
     auto lda = [&](int nt, int kc, u32x4(&dst)[2]) {
         const unsigned *w = Wb3 + ((size_t)(nt * KC32 + kc) * 2) * 256 + lane * 4;
 #pragma unroll
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
 #pragma unroll
         for (int i = 0; i < N / 256; ++i) xv[j][i] = *(const f32x4 *)&Ps[j * N + (i * 64 + lane) * 4];
     fc_rows<(kParam + NWV - 1) / NWV, NFK, NWV>(xv, Wfc, bfc, param, f0, B, 0, wave, lane);
+    if (SYN_L2_TOUCH && NS == 1) l2_touch_done(sink);
 }
 
 // second half of the sliced tail: blockIdx.y owns 4 of the 16 rounds of head rows

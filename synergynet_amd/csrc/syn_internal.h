@@ -7,6 +7,27 @@
 
 namespace syn {
 
+#ifdef __HIPCC__
+// L2 warm-up ("touch") of a weight run a kernel is going to stream later (round 5).  The kernels of features.7-17 and the head walk 1.6-4 MB of
+// weight fragments group by group, fetched ONE group (~1.5 us) ahead; every forward finds them cold (1.4 GB of activations went through
+// the 4 MB L2 of each XCD since the last one), so the first CU of an XCD to reach a group pays a miss into the Infinity Cache / HBM of
+// about that long, and the CUs of an XCD -- started together -- all wait for the same line fills: timing-only builds of the features.15-17
+// chain without its weight fetch ran 21 of 155 us faster (gpurun_out/r5c2).  Here every thread of the launch issues one dword load per
+// 128-byte line of its share of the run, long before the run is needed: the misses overlap each other instead of standing in 90 groups.
+//   gi / nth: this thread's index among, and the number of, the threads of the launch that run on ITS XCD (workgroup b runs on XCD b % 8).
+//   sink: ONE register that receives every touched dword (never read).  It must stay allocated until the loads have returned, which is
+//   what l2_touch_done() at the end of the kernel is for.  The loads are inline assembly on purpose: the compiler's wait-count
+//   bookkeeping does not know them, so no later s_waitcnt is computed FOR them; vector memory returns in order, hence every wait the
+//   compiler inserts for a younger load of its own still covers them (waits can only be longer than needed, never too short).
+__device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, unsigned gi, unsigned nth, unsigned &sink) {
+    for (unsigned ofs = gi * 128u; ofs < bytes; ofs += nth * 128u) {
+        const char *p = static_cast<const char *>(base) + ofs;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+    }
+}
+__device__ __forceinline__ void l2_touch_done(unsigned &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory"); }
+#endif
+
 constexpr int kImg = 120;           // utils/params.py:34
 constexpr int kParam = 62;
 constexpr int kPool = 1280;

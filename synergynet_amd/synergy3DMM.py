@@ -509,7 +509,7 @@ class SynergyNet(nn.Module):
     def landmarks_and_pose(self, param, roi=None, transform=True, out=None):
         """`reconstruct(param, roi, dense=False, transform)` and `predict_pose_batch(param, roi)` in ONE launch (syn_landmarks_pose): what
         get_all_outputs needs per face besides the mesh (reference synergy3DMM.py:194-201).  Returns (lmk [B,3,68], (angles [B,3] float64, t3d
-        [B,3])); landmarks equal to `reconstruct`'s to fp32 rounding, pose the same bits as `predict_pose_batch`."""
+        [B,3])); landmarks equal to `reconstruct`'s to fp32 rounding, pose as `predict_pose_batch` (translation the same bits, angles within 1e-4 degree)."""
         p = self._dev_f32(param)
         if p.dim() != 2:
             raise RuntimeError('param must be [B,62]')
