@@ -127,15 +127,12 @@ struct LbCfg {
     static constexpr int XF_DW = KE * 4 * 2 * 256;       // block input of one face as fragments [KE][block 4][piece 2][lane 64][4 dwords]
     static constexpr int NSX = NS == 8 ? 4 : NS;         // streams that keep output tiles (eight streams: 4 .. 7 first add theirs into 0 .. 3)
     static constexpr int KT = (MT + NSX - 1) / NSX;      // output tiles a keeper wave keeps (mt % NSX == its stream)
-    // four-stream schedule: one wave per SIMD and nobody to cover an L2 round trip, but 512 registers -- ALL project fragments of a group
-    // (or four of them) are requested half way through its depthwise phase, not during its last quarter
-    static constexpr bool EARLYP = NS == 4 && !S2_;
     static constexpr int RED_DW = (NS == 2 ? 1 : NSX) * MT * NB * 256;  // exchange buffer of one face: [stream 2][MT / 2][block NB][lane 64][4]; NS > 2: [stream 4][MT][NB][lane][4]
     static constexpr int TB_DW = 12 * 32;                // per wave: depthwise filter [9][32] | depthwise shift | expand shift | (pad) of its current group
     static constexpr int FACE_DW = XF_DW > RED_DW ? XF_DW : RED_DW;      // the exchange buffer reuses the fragments of its face
     static constexpr int LDS_DW = FPW * FACE_DW + NW * TB_DW;
     static_assert(CIN % 32 == 0 && HID % 64 == 0 && COUT % 32 == 0, "k32 steps, two streams, two halves of the output tiles");
-    static_assert(NS == 2 || ((NS == 4 || NS == 8) && FPW == 1 && (HID / 32) >= NS), "four / eight streams: the one-face-per-workgroup schedule of small batches");
+    static_assert(NS == 2 || (NS == 8 && FPW == 1 && (HID / 32) >= NS), "eight streams: the one-face-per-workgroup schedule of small batches (the four-stream form of round 4 is retired)");
     static_assert(EPF == 1 || EPF == KE, "expand prefetch depth");
     static_assert(!RES || (CIN == COUT && !S2), "residual only on same-width stride-1 blocks");
     static_assert((FPW == 4 || NS >= 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
@@ -340,12 +337,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 #pragma unroll
         for (int th = 0; th < 4; ++th) {
             const int t = th >> 1, hf = th & 1;
-            if (th == 3 && !C::EARLYP) fetch_p(0);      // first project fragments: in flight behind the last depthwise pass
-            if (th == 2 && C::EARLYP) {
-#pragma unroll
-                for (int i = 0; i < C::PPF; ++i)
-                    if (i < MT) fetch_p(i);
-            }
+            if (th == 3) fetch_p(0);                    // first project fragments: in flight behind the last depthwise pass
             const int c0 = 16 * t + 2 * hf;             // + 4 g per lane group
             f32x2 w[9];
 #pragma unroll
@@ -411,7 +403,7 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         const bool more = G + C::NS < gend;
 #pragma unroll
         for (int i = 1; i < C::PPF; ++i)
-            if (i < MT && !C::EARLYP) fetch_p(i);
+            if (i < MT) fetch_p(i);
         if (more) {
             if (!C::TLATE) fetch_t(G + C::NS);
             if (C::EPF != KE) {                                  // (one k32 step of them: the other slot is still being read -- see above for EPF == KE)
@@ -1120,38 +1112,18 @@ void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     if (SYN_L2_TOUCH) l2_touch_done(sink);
 }
 
-// Small batches (round 4; BASELINE configs[1] is 128 faces): features.8 .. 14 as ONE launch with ONE face per workgroup and FOUR waves
-// per face.  Below ~400 faces the chain above leaves most CUs empty and its workgroups walk 12-18 hidden groups per block with two
-// waves, so those batches ran the blocks one launch each, hidden-sliced over workgroups (PARTIAL) with a reduce launch behind every
-// block: 14 launches, 135 us at B = 128.  Four streams per face halve a face's critical path, the partial sums of the four streams
-// meet in LDS (no global round trip, no reduce kernel), and the block output stays on chip as the next stage's fragments.
-using L8s = LbCfg<     64, 384,  64, true,  2, 4, 1, false, 4>;
-using L11s = LbCfg<    64, 384,  96, false, 2, 4, 1, false, 4>;
-using L12s = LbCfg<    96, 576,  96, true,  1, 4, 1, false, 4>;
-using L14s = LbCfg<    96, 576, 160, false, 1, 2, 1, true, 4>;
+// Small batches (round 4; BASELINE configs[1] is 128 faces): features.8 .. 14 (round 5: 7 .. 14) as ONE launch with ONE face per workgroup.  Below
+// ~400 faces the chain above leaves most CUs empty and its workgroups walk 12-18 hidden groups per block with two waves, so those batches ran
+// the blocks one launch each, hidden-sliced over workgroups (PARTIAL) with a reduce launch behind every block: 14 launches, 135 us at B = 128.
+// Several streams per face shorten a face's critical path, their partial sums meet in LDS (no global round trip, no reduce kernel), and the
+// block output stays on chip as the next stage's fragments.  (The first form had FOUR waves per face, one per SIMD; retired in round 5.)
 constexpr int cmax4(int a, int b, int c, int d) { return (a > b ? a : b) > (c > d ? c : d) ? (a > b ? a : b) : (c > d ? c : d); }
-constexpr int kChainFaceDwS = cmax4(L8s::FACE_DW, L11s::FACE_DW, L12s::FACE_DW, L14s::FACE_DW);
-constexpr int kChainLdsDwS = L8s::FPW * kChainFaceDwS + L8s::NW * L8s::TB_DW;
-static_assert(kChainLdsDwS * 4 <= 160 * 1024, "one workgroup per CU");
-
-__global__ __launch_bounds__(L8s::NT) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void fused_chain_lb_small_kernel(LbChainArgs ca, int B) {
-    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
-    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDwS];
-    lb_stage<L8s, L8s, true, false, kChainFaceDwS>(smem, ca.s[1], B, pt_, tk);
-    lb_stage<L8s, L8s, false, false, kChainFaceDwS>(smem, ca.s[2], B, pt_, tk);
-    lb_stage<L8s, L11s, false, false, kChainFaceDwS>(smem, ca.s[3], B, pt_, tk);
-    lb_stage<L11s, L12s, false, false, kChainFaceDwS>(smem, ca.s[4], B, pt_, tk);
-    lb_stage<L12s, L12s, false, false, kChainFaceDwS>(smem, ca.s[5], B, pt_, tk);
-    lb_stage<L12s, L14s, false, false, kChainFaceDwS, false>(smem, ca.s[6], B, pt_, tk);
-    lb_stage<L14s, void, false, false, kChainFaceDwS>(smem, ca.s[7], B, pt_, tk);
-}
 
 // EIGHT waves per face (two per SIMD, 256 registers): the four-stream kernel has one wave per SIMD, and a lone wave stalls on every dependent
 // step of a hidden group (~3.4 us per group against ~2.4 per SIMD in the two-waves-per-SIMD chain of large batches); with eight streams a
 // SIMD's two waves cover each other's round trips, a wave walks 1-3 groups per block instead of 3-5, and the partial sums meet in two
 // levels (streams 4 .. 7 into 0 .. 3, then as above).  Landmarks-only step, four -> eight streams (ms, interleaved on one box): B = 1 0.244 -> 0.225,
-// 8 0.265 -> 0.245, 64 0.300 -> 0.281, 128 0.330 -> 0.310, 256 0.429 -> 0.409.  The default; SYN_SMALL_NS=4 selects the kernel above.
+// 8 0.265 -> 0.245, 64 0.300 -> 0.281, 128 0.330 -> 0.310, 256 0.429 -> 0.409.
 using L8e = LbCfg<     64, 384,  64, true,  2, SYN_L8_PPF, 1, false, 8>;
 using L11e = LbCfg<    64, 384,  96, false, 2, SYN_L11_PPF, 1, false, 8>;
 using L12e = LbCfg<    96, 576,  96, true,  1, 3, 1, false, 8>;
@@ -1234,7 +1206,7 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 constexpr int kChainMin = 384;          // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
 constexpr int kSmallChainMax = 256;     // the one-face-per-workgroup chain: one round of workgroups
 static bool small_f7() {      // features.7 as the first stage of the eight-wave small-batch chain (SYN_SMALL_F7=0: its own launch, as in round 4)
-    static const bool on = !(getenv("SYN_SMALL_F7") && atoi(getenv("SYN_SMALL_F7")) == 0) && !(getenv("SYN_SMALL_NS") && atoi(getenv("SYN_SMALL_NS")) != 8);
+    static const bool on = !(getenv("SYN_SMALL_F7") && atoi(getenv("SYN_SMALL_F7")) == 0);
     return on;
 }
 int lb_chain_mode(int B, bool small) {
@@ -1257,9 +1229,7 @@ bool launch_fused_chain_lb(const FusedBlockArgs *a, int first, int n_blocks, int
     if (B < kChainMin) {
         if (last != 14 || (first == 7 && !small_f7())) return false;
         if (first == 7) { fused_chain_lb_small8_kernel<true><<<B, L8e::NT, 0, s>>>(ca, B); return true; }
-        static const int small_ns = getenv("SYN_SMALL_NS") ? atoi(getenv("SYN_SMALL_NS")) : 8;      // (4: the four-stream kernel, for A/B: tools/small_ns_ab.sh)
-        if (small_ns == 8) fused_chain_lb_small8_kernel<false><<<B, L8e::NT, 0, s>>>(ca, B);
-        else fused_chain_lb_small_kernel<<<B, L8s::NT, 0, s>>>(ca, B);
+        fused_chain_lb_small8_kernel<false><<<B, L8e::NT, 0, s>>>(ca, B);
         return true;
     }
     const int grid = (B + L8::FPW - 1) / L8::FPW;

@@ -125,20 +125,19 @@ struct RmCfg {
 // PROF: barrier that also books the time since the previous barrier as this wave's busy time
 #define SYNR_BARRIER() do { if (PROF) { const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); busy_ += tb_ - tw_; __syncthreads(); tw_ = __builtin_amdgcn_s_memtime(); } else __syncthreads(); } while (0)
 
-template <class C, bool PROF = false>
-__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
-void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][2][64][4]*/,
+// one block (the whole kernel body; `smem` = the workgroup's C::LDS_DW dwords).  Service waves return from here at the end of their loop.
+template <class C, bool PROF>
+__device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][2][64][4]*/,
                            const unsigned *__restrict__ Ap3 /*[NG][2][2][64][4]*/, const float *__restrict__ e_shift,
                            const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
                            const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units,
                            const float *__restrict__ scl_e /*{S, 1/S, 6 S} of the expand weights*/, const float *__restrict__ scl_p,
-                           unsigned long long *prof = nullptr) {
+                           unsigned long long *prof) {
     // PROF: s_memtime sums of compute wave 0 per phase {(unused), expand, (unused), depthwise, finalize, barrier wait,
     // whole workgroup lifetime} and the number of row steps (syn_debug_profile_block)
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0, nsteps = 0;
     const unsigned long long t_begin = tk;
     unsigned long long busy_ = 0, tw_ = tk;
-    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
     constexpr int H = C::H, HO = C::HO, NW = C::NW, NT = C::NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_wg = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,6 +606,35 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
     }
 }
 
+template <class C, bool PROF = false>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
+void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restrict__ Ae3, const unsigned *__restrict__ Ap3, const float *__restrict__ e_shift,
+                           const float *__restrict__ Wd, const float *__restrict__ d_shift, const float *__restrict__ p_shift, float *__restrict__ Y, int B,
+                           int n_units, const float *__restrict__ scl_e, const float *__restrict__ scl_p, unsigned long long *prof = nullptr) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    rm_block<C, PROF>(smem, X, Ae3, Ap3, e_shift, Wd, d_shift, p_shift, Y, B, n_units, scl_e, scl_p, prof);
+}
+
+// TWO consecutive blocks of the same configuration in one launch (round 5: features.5 + 6).  A workgroup marches its units through the first
+// block, then the SAME units through the second: unit u of the second block reads exactly what unit u of the first one wrote (the same
+// faces), so nothing crosses workgroups and the kernel boundary between the two launches -- the drain of one grid, the dispatch of the
+// next, a second prologue on an empty chip -- becomes one workgroup barrier.  The first block's output still goes through global memory
+// (it is the second block's residual too): stored by this CU's service waves, read back by them past the barrier (workgroup-scope
+// release / acquire: one CU, one vector cache, write-through).
+struct RmStageArgs {
+    const float *X; const unsigned *Ae3, *Ap3; const float *e_shift, *Wd, *d_shift, *p_shift; float *Y; const float *scl_e, *scl_p;
+};
+template <class C>
+__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
+void fused_pair_rm_kernel(RmStageArgs a, RmStageArgs b, int B, int n_units) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
+    rm_block<C, false>(smem, a.X, a.Ae3, a.Ap3, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.scl_e, a.scl_p, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores of the first block are out of the CU
+    __syncthreads();                                            // ... and so are everybody's; nobody still reads the first block's LDS
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    rm_block<C, false>(smem, b.X, b.Ae3, b.Ap3, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, B, n_units, b.scl_e, b.scl_p, nullptr);
+}
+
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e && *e ? atoi(e) : dflt;
@@ -647,6 +675,18 @@ template <int U> using R5 = RmCfg< 32, 192,  32, 15, 1, 2, true,  4, U, true, 0,
 template <int U, int NBD> using R2b = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, U, false, 0, NBD>;
 template <int U, int NBD> using R3b = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG, NBD>;
 constexpr int kBand2Min = 40, kBand3Min = 96;
+
+// features.5 + 6 in one launch (B >= 513: the configuration launch_fused_block_rm would pick for either); false: launch them one by one
+bool launch_fused_pair_rm(const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
+    static const bool on = env_int("SYN_RM_PAIR56", 1) != 0;
+    if (!on || B < 513 || a.prof || b.prof) return false;
+    if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p || !b.Arm_e || !b.Arm_p || !b.scl_e || !b.scl_p) return false;
+    using C = R5<2>;
+    const int n_units = (B + C::NF - 1) / C::NF, wgs = (n_units + C::U - 1) / C::U, grid = wgs < 256 ? wgs : 256;
+    fused_pair_rm_kernel<C><<<grid, C::NT, 0, s>>>(RmStageArgs{a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, a.scl_e, a.scl_p},
+                                                  RmStageArgs{b.X, b.Arm_e, b.Arm_p, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, b.scl_e, b.scl_p}, B, n_units);
+    return true;
+}
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p) return false;

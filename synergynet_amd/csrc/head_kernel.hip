@@ -37,7 +37,7 @@ __device__ __forceinline__ float wave64_sum(float v) {          // uniform resul
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /*[B,16,320]*/, const float *__restrict__ Wpk,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ Wfc /*[64,1280]*/, const float *__restrict__ bfc,
-                                                   float *__restrict__ param, float *__restrict__ pool, int B, int ablate) {
+                                                   float *__restrict__ param, float *__restrict__ pool, int B) {
     __shared__ __attribute__((aligned(16))) float Xs[PX * XS];
     __shared__ __attribute__((aligned(16))) float Ps[NF * N];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) a[kc] = an[kc];
         const f32x4 sh = hn;
-        if (!(ablate & 1) && nt + 4 < NTL) fetch(nt + 4);
+        if (nt + 4 < NTL) fetch(nt + 4);
         f32x4 acc[NF];                                // BN shift = accumulator start
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[j] = sh;
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
         f32x4 bc[NF], bn[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) bc[j] = *(const f32x4 *)&Xs[(j * 16 + r16) * XS + 4 * g];
-        if (!(ablate & 2))
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) {
             if (kc + 1 < KCH) {
@@ -92,7 +91,6 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
             __builtin_amdgcn_sched_barrier(0);
         }
         // BN + ReLU6, then mean over the 16 pixels of each face = butterfly over the 16 lanes sharing g
-        if (!(ablate & 4))
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             f32x4 v;
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
             if (f0 + j < B) *(f32x4 *)&pool[(size_t)(f0 + j) * N + 4 * c4] = *(const f32x4 *)&Ps[j * N + 4 * c4];
         }
     }
-    if (!(ablate & 8)) {
+    {
         f32x4 xv[NF][N / 256];
 #pragma unroll
         for (int j = 0; j < NF; ++j)
@@ -140,8 +138,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ X /
 
 void launch_head(const float *X, const float *Wpk, const float *scale, const float *shift, const float *Wfc,
                  const float *bfc, float *param, float *pool, int B, hipStream_t s) {
-    static const int ablate = getenv("SYN_ABLATE_HEAD") ? atoi(getenv("SYN_ABLATE_HEAD")) : 0;   // profiling only
-    head_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wpk, scale, shift, Wfc, bfc, param, pool, B, ablate);
+    head_kernel<<<(B + NF - 1) / NF, 256, 0, s>>>(X, Wpk, scale, shift, Wfc, bfc, param, pool, B);
 }
 
 

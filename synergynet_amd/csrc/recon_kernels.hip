@@ -82,8 +82,7 @@ __global__ __launch_bounds__(64) void recon_prep_kernel(const float *__restrict_
 // -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ rec, const float *__restrict__ basis,
                                                     float *__restrict__ out, int B, int n_vert, int pitch, int n_tiles,
-                                                    int n_split, int ftiles_per_split, int n_ftiles, int n_units,
-                                                    int ablate) {
+                                                    int n_split, int ftiles_per_split, int n_ftiles, int n_units) {
     __shared__ __attribute__((aligned(16))) float smt[4][32][12];
     __shared__ __attribute__((aligned(16))) float stage[96 * kStageStride];   // [face*3 + coord][4 tiles x 32 vertices]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
     const int v_base = tg * 128;                  // first vertex of the workgroup's 128-vertex run
     // the two co-resident workgroups of a CU start together; delaying every second one by about half an
     // iteration lets one's MFMA phase run in the shadow of the other's epilogue / store phase
-    if (!(ablate & 4) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(56);
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(56);
 
     for (int ft = ft0; ft < ft1; ++ft) {
         const int f0 = ft * 32;
@@ -137,7 +136,6 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-            if (ablate & 1) continue;
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -150,7 +148,6 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // pose epilogue in registers -> this wave's 32-vertex column block of the workgroup stage
-        if (!(ablate & 8))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
         }
         lds_barrier();
         // cooperative store: 32 lanes x float4 = one 512-byte run of one (face, coord) row; 2 rows per instruction
-        if (!(ablate & 2)) {
+        {
             const int seg = threadIdx.x & 31, rsub = threadIdx.x >> 5;
             const int vq = v_base + 4 * seg;
 #pragma unroll
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(256) void recon_kernel(const float *__restrict__ re
                 const int row = k * 8 + rsub;                 // = face_in_tile * 3 + coord
                 const int f = f0 + row / 3, c = row % 3;
                 const f32x4 vv = *(const f32x4 *)&stage[row * kStageStride + 4 * seg];
-                if (f < B && !(ablate & 1)) {
+                if (f < B) {
                     float *o = out + ((size_t)f * 3 + c) * pitch + vq;
                     if (vq + 3 < n_vert) *(f32x4 *)o = vv;       // 4-byte aligned 16-byte store (rows are n_vert floats)
                     else {
@@ -202,8 +199,7 @@ void launch_reconstruct(const float *param, const float *mean62, const float *st
     n_split = (n_ftiles + per - 1) / per;
     const int n_units = n_groups * n_split;
     const int grid = ((n_units + 7) / 8) * 8;
-    static const int ablate = getenv("SYN_ABLATE_RECON") ? atoi(getenv("SYN_ABLATE_RECON")) : 0;   // profiling only
-    recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, pitch, n_tiles, n_split, per, n_ftiles, n_units, ablate);
+    recon_kernel<<<grid, 256, 0, s>>>(rec, basis, out, B, n_vert, pitch, n_tiles, n_split, per, n_ftiles, n_units);
 }
 
 // =====================================================================================

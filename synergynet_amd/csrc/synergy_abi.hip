@@ -573,27 +573,47 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         }
         // fused block: expand (li) + depthwise (li+1) + project (li+2) in one launch
         if (h->fusion && L.kind == PW && L.relu6 && L.feature >= 2 && L.feature <= 17) {
-            const Layer &D = n.layers[li + 1], &Pj = n.layers[li + 2];
-            syn::FusedBlockArgs a{X, P + L.dst_wpk, sc, sh, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
-                                  P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, Y};
-            if (prof_feature == L.feature) a.prof = prof;
-            const bool ok1 = !((u1 >> L.feature) & 1u), ok16 = !((u16 >> L.feature) & 1u);     // fp16 x2 kernels allowed at input scale 1 / 16
-            if (h->fusion >= 2 && ok1 && L.dst_wb3 && Pj.dst_wb3) {
-                a.We3 = reinterpret_cast<const unsigned *>(P + L.dst_wb3);
-                a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
+            // the arguments of the block whose expand layer is n.layers[l0], reading xin and writing yout
+            auto block_args = [&](int l0, float *xin, float *yout) {
+                const Layer &E = n.layers[l0], &D = n.layers[l0 + 1], &Pj = n.layers[l0 + 2];
+                syn::FusedBlockArgs a{xin, P + E.dst_wpk, P + E.dst_scale, P + E.dst_shift, P + D.dst_wpk, P + D.dst_scale, P + D.dst_shift,
+                                      P + Pj.dst_wpk, P + Pj.dst_scale, P + Pj.dst_shift, yout};
+                if (prof_feature == E.feature) a.prof = prof;
+                const bool ok1 = !((u1 >> E.feature) & 1u), ok16 = !((u16 >> E.feature) & 1u);     // fp16 x2 kernels allowed at input scale 1 / 16
+                if (h->fusion >= 2 && ok1 && E.dst_wb3 && Pj.dst_wb3) {
+                    a.We3 = reinterpret_cast<const unsigned *>(P + E.dst_wb3);
+                    a.Wp3 = reinterpret_cast<const unsigned *>(P + Pj.dst_wb3);
+                }
+                if (h->fusion >= 2 && E.dst_scl && Pj.dst_scl) { a.scl_e = P + E.dst_scl; a.scl_p = P + Pj.dst_scl; }
+                if (h->fusion >= 2 && ok1 && E.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (E.feature <= 4 ? E.feature - 2 : E.feature)) & 1)) {
+                    a.Arm_e = reinterpret_cast<const unsigned *>(P + E.dst_wrm);
+                    a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
+                }
+                if (h->fusion >= 2 && ok16 && a.We3 && Pj.dst_wlb && E.dst_tlb && (h->early_rm & 128)) {
+                    a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
+                    a.Alb_e = reinterpret_cast<const unsigned *>(P + E.dst_weh);
+                    a.Tlb = P + E.dst_tlb;
+                }
+                if (h->fusion >= 2 && ok16 && E.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + E.dst_glb);
+                a.scratch = H2; a.scratch_floats = (size_t)B * n.max_hidden;       // (the per-layer schedule's second hidden buffer: free here)
+                return a;
+            };
+            syn::FusedBlockArgs a = block_args(li, X, Y);
+            // features.5 + 6 (one row-marching configuration, residual blocks on the same faces) as ONE launch (fused_block_rm.hip)
+            if (L.feature == 5 && a.Arm_e && prof_feature < 0 && (stop_feature < 0 || stop_feature >= 6) && li + 6 <= nl &&
+                n.layers[li + 3].kind == PW && n.layers[li + 3].relu6 && n.layers[li + 3].feature == 6) {
+                const syn::FusedBlockArgs b = block_args(li + 3, Y, X);
+                if (b.Arm_e && syn::launch_fused_pair_rm(a, b, B, s)) {
+                    li += 5;                                    // (two blocks: X -> Y -> X, the chain input buffer holds the output again)
+                    mark(506);
+                    if (stop_feature == 6) {
+                        const Layer &Lp = n.layers[li];
+                        HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
+                        return SYN_OK;
+                    }
+                    continue;
+                }
             }
-            if (h->fusion >= 2 && L.dst_scl && Pj.dst_scl) { a.scl_e = P + L.dst_scl; a.scl_p = P + Pj.dst_scl; }
-            if (h->fusion >= 2 && ok1 && L.dst_wrm && Pj.dst_wrm && ((h->early_rm >> (L.feature <= 4 ? L.feature - 2 : L.feature)) & 1)) {
-                a.Arm_e = reinterpret_cast<const unsigned *>(P + L.dst_wrm);
-                a.Arm_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wrm);
-            }
-            if (h->fusion >= 2 && ok16 && a.We3 && Pj.dst_wlb && L.dst_tlb && (h->early_rm & 128)) {
-                a.Alb_p = reinterpret_cast<const unsigned *>(P + Pj.dst_wlb);
-                a.Alb_e = reinterpret_cast<const unsigned *>(P + L.dst_weh);
-                a.Tlb = P + L.dst_tlb;
-            }
-            if (h->fusion >= 2 && ok16 && L.dst_glb && (h->early_rm & 256)) a.Glb = reinterpret_cast<const unsigned *>(P + L.dst_glb);
-            a.scratch = H2; a.scratch_floats = (size_t)B * n.max_hidden;       // (the per-layer schedule's second hidden buffer: free here)
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.Glb && syn::launch_fused_block_lb4(L.feature, a, B, s)) ||

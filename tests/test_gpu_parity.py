@@ -251,8 +251,7 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
 @pytest.mark.parametrize('B', [1, 3, 31, 32, 127, 128, 255, 256, 257])
 def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd, B):
     """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, eight waves per
-    face, the partial sums of the eight streams added in LDS in a fixed order (fused_chain_lb_small8_kernel; SYN_SMALL_NS=4: the four-stream
-    kernel it replaced) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Round 5: features.7 is the
+    face, the partial sums of the eight streams added in LDS in a fixed order (fused_chain_lb_small8_kernel) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Round 5: features.7 is the
     first stage of that launch (lb7_stage8: a wave = hidden stream x output block; SYN_SMALL_F7=0 keeps it a launch of its own) and the
     exchange buffer no longer aliases the fragments (two barriers per stage fewer) -- the reference schedule below (EARLY_RM without bit
     10) still runs features.7 ... 14 block by block.  Same arithmetic in another summation order: equal to the block-by-block schedule
@@ -802,12 +801,14 @@ np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
 '''
 
 
-@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'}],
+@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
+                                   {'SYN_RM_PAIR56': '0'}],
                          ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
 def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs):
     """features.7-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
     the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
-    faces per workgroup (head_kernel.hip).  Every one of these is a schedule change only: with the chain off (one launch per
+    faces per workgroup (head_kernel.hip); round 5: features.5 + 6 share one launch of the row-marching kernel (fused_pair_rm_kernel, B >= 513:
+    a workgroup marches its faces through both blocks, SYN_RM_PAIR56=0: two launches).  Every one of these is a schedule change only: with the chain off (one launch per
     block), with the shorter features.8-13 / 8-14 chains, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
     read once per process, hence the subprocess."""
     import subprocess
