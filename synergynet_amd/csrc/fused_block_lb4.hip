@@ -89,6 +89,7 @@ struct Lb4Cfg {
 // stays in the accumulator's registers, and the next stage's first weight group is fetched during the last group of this one --
 // no kernel boundary (10-16 us each), no global round trip of the 4x4 activations.
 struct Lb4NoNext { static constexpr int NKB = 0; };
+constexpr int Q15_WE_WP_DW = Lb4Cfg<160, 960, 160, true>::WE_DW + Lb4Cfg<160, 960, 160, true>::WP_DW;     // a 160 -> 960 -> 160 group's table offset
 struct Lb4StageArgs {
     const float *X;          // block input (global): a FIRST stage's input and residual
     const unsigned *Glb;     // [NG][NKB][64][4]: We | Wp | table per group
@@ -96,6 +97,17 @@ struct Lb4StageArgs {
     float *Y;                // block output (global): written by the last stage only
     float *part = nullptr;   // hidden-sliced schedule: partial sums [slice][B][16][COUT] (raw accumulators)
     int g0 = 0, g1 = 0;      // hidden groups [g0, g1) of this workgroup's slice (g1 = 0: all); slice = blockIdx.y
+    // pipelined slices (lb4_pipe_kernel): the face quad / slice of this workgroup (-1: blockIdx.x / .y), and where the block input comes from
+    int quad = -1, slice = -1;
+    const float *pin_part = nullptr;     // the PREVIOUS block's partial sums [slice][B][16][160]: reduced here, in lb4_reduce_kernel's order
+    int pin_S = 0;
+    const float *pin_pshift = nullptr;   // ... its BN shift
+    const unsigned *pin_glb = nullptr;   // ... its group 0 table (accumulator -> output scale)
+    const float *pin_res = nullptr;      // ... its residual (its own block input), or null
+    float *pin_ystore = nullptr;         // slice 0 stores the reduced block input here (the residual source of the block after this one), or null
+    unsigned *ctr_wait = nullptr;        // arrival counter of the previous block's slices of this face quad
+    unsigned *ctr_done = nullptr;        // ... of this block's
+    unsigned ctr_target = 0;             // value ctr_wait reaches when all slices of the previous block have published (counters only ever grow)
 };
 
 // SYN_LB4_ABL: TIMING-ONLY ablations (wrong results; tools/build_variant.sh): 1 no weight fetch from L2 | 2 no park into LDS | 4 no exchange
@@ -126,7 +138,10 @@ __device__ __forceinline__ void lb4_park(const u32x4 *pf, unsigned *dst /* + 4 l
 // PARTIAL (small batches): the workgroup (blockIdx.x = four faces, blockIdx.y = slice) walks only the hidden groups of its slice and
 // stores its raw accumulators; lb4_reduce_kernel adds the slices in fixed order, rescales, adds BN shift and residual.  A batch of 128
 // faces is then 32 x 6 workgroups of five groups each instead of 32 workgroups walking all thirty.
-template <class C, class CN, bool FIRST, int GRPL, bool PARTIAL = false>
+// PIPEIN (with PARTIAL, lb4_pipe_kernel): the block input is the previous block's output, which exists only as that block's per-slice partial
+// sums: wait for its slices of this face quad, add them (+ BN shift, + residual) exactly as lb4_reduce_kernel does, hand the result to the
+// fragment registers through LDS as a chain stage does.
+template <class C, class CN, bool FIRST, int GRPL, bool PARTIAL = false, bool PIPEIN = false>
 __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa, const unsigned *GlbNext, int B, u32x4 (&Xr)[5][2], f32x4 (&vres)[5]) {
     constexpr int KE = C::KE, MTW = C::MTW, CIN = C::CIN, COUT = C::COUT;
     constexpr bool HANDOFF = !__is_same(CN, void);
@@ -137,7 +152,8 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = wave >> 1, t = wave & 1;
-    const int f = blockIdx.x * 4 + fl;
+    const int quad = sa.quad >= 0 ? sa.quad : (int)blockIdx.x, slice = sa.slice >= 0 ? sa.slice : (int)blockIdx.y;
+    const int f = quad * 4 + fl;
     const bool real = f < B;
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
@@ -152,7 +168,45 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     constexpr int NPWN = CNX::NKB / 8;
     u32x4 pf[NPW > NPWN ? NPW : NPWN];
     const int gsl = PARTIAL ? (sa.g1 - sa.g0) : C::NG;   // groups per slice (all slices the same)
-    const int gb = PARTIAL ? (int)blockIdx.y * gsl : 0, ge = gb + gsl;
+    const int gb = PARTIAL ? slice * gsl : 0, ge = gb + gsl;
+    if constexpr (PIPEIN) {
+        static_assert(PARTIAL && !FIRST && KE == 5, "pipelined slices: 160-channel block inputs");
+        lb4_fetch<NPW>(pf, Glb + (size_t)gb * C::GRP_DW + l4, wave);          // (the weights do not depend on anybody: in flight across the wait)
+        if (threadIdx.x == 0) {
+            // every slice of the previous block of this face quad has a LOWER workgroup index than this workgroup: dispatched earlier, i.e.
+            // resident or finished -- the wait cannot starve them (lb4_pipe_kernel).  Bounded all the same: a broken counter gives wrong numbers, not a hang.
+            int spins = 0;
+            while ((int)(__hip_atomic_load(sa.ctr_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sa.ctr_target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float inv_pp = reinterpret_cast<const float *>(sa.pin_glb + Q15_WE_WP_DW)[11 * 32 + 1];
+        unsigned *HO = smem + GRPL;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int mt = t * 5 + i, nch = 16 * mt + g4;
+            const size_t at = ((size_t)fc * 16 + n) * 160 + nch, stride = (size_t)B * 16 * 160;
+            f32x4 a = *(const f32x4 *)&sa.pin_part[at];
+            for (int sl = 1; sl < sa.pin_S; ++sl) a += *(const f32x4 *)&sa.pin_part[(size_t)sl * stride + at];
+            f32x4 v = a * inv_pp + *(const f32x4 *)&sa.pin_pshift[nch];
+            if (sa.pin_res) v += *(const f32x4 *)&sa.pin_res[at];
+            if (sa.pin_ystore && slice == 0 && real) *(f32x4 *)&sa.pin_ystore[at] = v;
+            // channels 16 mt + 4 g .. + 3 of pixel n: k32 step mt >> 1, lane group 2 (mt & 1) + (g >> 1), dwords 2 (g & 1), + 1 (as the chain's hand-over)
+            const int kc = mt >> 1, lt = (2 * (mt & 1) + (g >> 1)) * 16 + n, dw = 2 * (g & 1);
+            const f32x4 vs = real ? v * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
+            unsigned a0, b0, a1, b1;
+            split2q(vs[0], vs[1], a0, b0);
+            split2q(vs[2], vs[3], a1, b1);
+            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 0) * 256 + lt * 4 + dw] = (u32x2){a0, a1};
+            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 1) * 256 + lt * 4 + dw] = (u32x2){b0, b1};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kc = 0; kc < KE; ++kc)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Xr[kc][p] = *(const u32x4 *)&HO[((fl * KE + kc) * 2 + p) * 256 + l4];
+        // (half 1 is rewritten at the end of this block's first group, two barriers from here)
+    }
     if (FIRST) {
         lb4_fetch<NPW>(pf, Glb + (size_t)gb * C::GRP_DW + l4, wave);
         // ---- block input of this face -> pre-split B fragments in registers (x 16; both waves of the face hold it) ----
@@ -178,7 +232,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float c6e = 0.f, inv_p = 0.f;
-    if (FIRST) lb4_park<NPW>(pf, smem + l4, wave);
+    if (FIRST || PIPEIN) lb4_park<NPW>(pf, smem + l4, wave);
 
     {   // ReLU6 ceiling of the scaled expand output, accumulator -> output: constants of the block, kept in group 0's table
         const float *t0 = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW);
@@ -318,7 +372,12 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
         if (real) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
-                *(f32x4 *)&sa.part[(((size_t)blockIdx.y * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4] = acc[i];
+                *(f32x4 *)&sa.part[(((size_t)slice * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4] = acc[i];
+        }
+        if (sa.ctr_done) {                               // pipelined slices: publish (every thread's stores, then one arrival per workgroup)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(sa.ctr_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -448,10 +507,71 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     return true;
 }
 
+// ---- small batches, round 5: features.15, 16, 17 hidden-sliced AND in one launch ("pipelined slices") ----
+// The sliced schedule above is six launches per forward (three blocks x (slices + reduce)), ~9 us of launch, prologue and drain each around
+// ~8 us of arithmetic: 74 of the 290 us of a BASELINE configs[1] step.  Here the grid holds the workgroups of ALL three blocks, block-major:
+// workgroup (block n, face quad q, slice s) has index (n Q + q) S + s.  A workgroup of block n >= 1 waits until the S slices of block n - 1
+// of its face quad have published their partial sums (one arrival counter per (block, quad), device-scope release / acquire), adds them
+// itself -- the arithmetic and order of lb4_reduce_kernel, so the bits of the sliced schedule -- and starts its own groups; slice 0 of
+// block 16 also stores its reduced input (features.15's output), which is the residual of features.16 that block 17's workgroups need.
+// No deadlock: a workgroup only ever waits for workgroups with LOWER indices, and a grid is dispatched in index order -- whatever it waits
+// for is resident or finished, also with other kernels (other replicas' launches of this one included) sharing the chip; the wait is
+// bounded anyway.  Counters only grow (target = epoch x S): nothing to reset, nothing an aborted forward could leave behind.
+// features.17's partial sums are reduced by lb4_reduce_kernel as before.
+struct Lb4PipeArgs {
+    Lb4StageArgs s[3];       // X / Glb / p_shift of features.15, 16, 17 (Y unused)
+    float *part[3];          // partial sums of the three blocks
+    float *y15;              // features.15's output (the residual of features.16)
+    unsigned *ctr;           // [2][Q] arrival counters
+    unsigned target;         // (epoch + 1) x S
+    int Q, S;
+};
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void lb4_pipe_kernel(Lb4PipeArgs pa, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChain4LdsDw];
+    u32x4 Xr[5][2];
+    f32x4 vres[5];
+    const int per = pa.Q * pa.S, lvl = (int)blockIdx.x / per, r = (int)blockIdx.x - lvl * per, q = r / pa.S, sl = r - q * pa.S;
+    Lb4StageArgs sa = pa.s[lvl];
+    sa.quad = q; sa.slice = sl; sa.part = pa.part[lvl]; sa.g0 = 0; sa.g1 = 30 / pa.S;
+    sa.ctr_done = lvl < 2 ? pa.ctr + lvl * pa.Q + q : nullptr;
+    if (lvl == 0) { lb4_stage<Q15, void, true, kChain4Grp, true>(smem, sa, nullptr, B, Xr, vres); return; }
+    sa.pin_part = pa.part[lvl - 1]; sa.pin_S = pa.S; sa.pin_pshift = pa.s[lvl - 1].p_shift; sa.pin_glb = pa.s[lvl - 1].Glb;
+    sa.pin_res = lvl == 1 ? pa.s[0].X : pa.y15;
+    sa.pin_ystore = lvl == 1 ? pa.y15 : nullptr;
+    sa.ctr_wait = pa.ctr + (lvl - 1) * pa.Q + q; sa.ctr_target = pa.target;
+    if (lvl == 1) lb4_stage<Q15, void, false, kChain4Grp, true, true>(smem, sa, nullptr, B, Xr, vres);
+    else lb4_stage<Q17, void, false, kChain4Grp, true, true>(smem, sa, nullptr, B, Xr, vres);
+}
+
+// a[i] = the arguments of features.(15 + i) (a[0].X the chain input, a[2].Y the output); ctr: >= 2 x ceil(B / 4) zero-initialised counters owned
+// by the caller's handle, epoch: how many times this launcher has used them.  false: not applicable (the blocks then run one by one, sliced)
+bool launch_lb4_pipe(const FusedBlockArgs *a, int B, hipStream_t s, unsigned *ctr, unsigned epoch) {
+    static const int on = getenv("SYN_LB4_PIPE") ? atoi(getenv("SYN_LB4_PIPE")) : 1;
+    if (!on || !ctr || !a[0].scratch) return false;
+    for (int i = 0; i < 3; ++i) if (!a[i].Glb || a[i].prof) return false;
+    const int Q = (B + 3) / 4;
+    static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
+    int S = 30;
+    for (int d : divs) if (Q * d >= 192) { S = d; break; }
+    const size_t p160 = (size_t)S * B * 16 * 160, p320 = (size_t)S * B * 16 * 320, y = (size_t)B * 16 * 160;
+    if (2 * p160 + p320 + y > a[0].scratch_floats) return false;
+    Lb4PipeArgs pa;
+    for (int i = 0; i < 3; ++i) pa.s[i] = Lb4StageArgs{a[i].X, a[i].Glb, a[i].p_shift, a[i].Y};
+    pa.part[0] = a[0].scratch; pa.part[1] = pa.part[0] + p160; pa.part[2] = pa.part[1] + p160; pa.y15 = pa.part[2] + p320;
+    pa.ctr = ctr; pa.target = (epoch + 1u) * (unsigned)S; pa.Q = Q; pa.S = S;
+    lb4_pipe_kernel<<<3 * Q * S, 512, 0, s>>>(pa, B);
+    const long total = (long)B * 16 * (Q17::COUT / 4);
+    lb4_reduce_kernel<Q17><<<(int)((total + 255) / 256), 256, 0, s>>>(pa.part[2], S, a[2].Glb, a[2].p_shift, nullptr, a[2].Y, B);
+    return true;
+}
+
 static int lb4_min_batch() {
     constexpr int min_b = 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
     return min_b;
 }
+
+int lb4_chain_min_batch() { return lb4_min_batch(); }
 
 // a[i] = the arguments of features.(15 + i); false: launch them one by one
 bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
