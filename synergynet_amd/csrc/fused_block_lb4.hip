@@ -89,6 +89,7 @@ struct Lb4Cfg {
 // stays in the accumulator's registers, and the next stage's first weight group is fetched during the last group of this one --
 // no kernel boundary (10-16 us each), no global round trip of the 4x4 activations.
 struct Lb4NoNext { static constexpr int NKB = 0; };
+constexpr int kAuxSys = 1 | 16;          // buffer-instruction cache policy sc0 sc1 (gfx940+: bit 0 = sc0, bit 4 = sc1): system scope, past the L2
 constexpr int Q15_WE_WP_DW = Lb4Cfg<160, 960, 160, true>::WE_DW + Lb4Cfg<160, 960, 160, true>::WP_DW;     // a 160 -> 960 -> 160 group's table offset
 struct Lb4StageArgs {
     const float *X;          // block input (global): a FIRST stage's input and residual
@@ -107,7 +108,7 @@ struct Lb4StageArgs {
     float *pin_ystore = nullptr;         // slice 0 stores the reduced block input here (the residual source of the block after this one), or null
     unsigned *ctr_wait = nullptr;        // arrival counter of the previous block's slices of this face quad
     unsigned *ctr_done = nullptr;        // ... of this block's
-    unsigned ctr_target = 0;             // value ctr_wait reaches when all slices of the previous block have published (counters only ever grow)
+    unsigned ctr_target = 0;             // value ctr_wait reaches when all slices of the previous block have published
 };
 
 // SYN_LB4_ABL: TIMING-ONLY ablations (wrong results; tools/build_variant.sh): 1 no weight fetch from L2 | 2 no park into LDS | 4 no exchange
@@ -179,18 +180,28 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
             while ((int)(__hip_atomic_load(sa.ctr_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sa.ctr_target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // The partial sums (and features.15's output) were written by workgroups on OTHER XCDs, whose L2s are not coherent with this one for
+        // ordinary accesses.  An agent-scope acquire would invalidate this XCD's whole L2 -- the weight runs every workgroup streams from it --
+        // and the release on the other side would write a whole L2 back (first version of this kernel: 0.395 instead of 0.289 ms per step).
+        // Instead exactly these tensors travel past the L2s: stored and loaded with sc0 sc1 (system scope: write-through / always miss).
         const float inv_pp = reinterpret_cast<const float *>(sa.pin_glb + Q15_WE_WP_DW)[11 * 32 + 1];
+        const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_part), 0, 0x7fffffff, 0x00027000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_res), 0, 0x7fffffff, 0x00027000);
+        const bool res_cc = sa.pin_ystore == nullptr;      // the residual is features.15's output, written inside this launch (block 17's workgroups); block 16's: the chain input
         unsigned *HO = smem + GRPL;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int mt = t * 5 + i, nch = 16 * mt + g4;
-            const size_t at = ((size_t)fc * 16 + n) * 160 + nch, stride = (size_t)B * 16 * 160;
-            f32x4 a = *(const f32x4 *)&sa.pin_part[at];
-            for (int sl = 1; sl < sa.pin_S; ++sl) a += *(const f32x4 *)&sa.pin_part[(size_t)sl * stride + at];
+            const unsigned at = (unsigned)((fc * 16 + n) * 160 + nch) * 4u, stride = (unsigned)B * 16u * 160u * 4u;      // bytes
+            f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, at, 0, kAuxSys));
+            for (int sl = 1; sl < sa.pin_S; ++sl) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, at, sl * stride, kAuxSys));
             f32x4 v = a * inv_pp + *(const f32x4 *)&sa.pin_pshift[nch];
-            if (sa.pin_res) v += *(const f32x4 *)&sa.pin_res[at];
-            if (sa.pin_ystore && slice == 0 && real) *(f32x4 *)&sa.pin_ystore[at] = v;
+            if (sa.pin_res) v += res_cc ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, kAuxSys))
+                                        : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, 0));
+            if (sa.pin_ystore && slice == 0 && real) {
+                const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(sa.pin_ystore, 0, 0x7fffffff, 0x00027000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, at, 0, kAuxSys);
+            }
             // channels 16 mt + 4 g .. + 3 of pixel n: k32 step mt >> 1, lane group 2 (mt & 1) + (g >> 1), dwords 2 (g & 1), + 1 (as the chain's hand-over)
             const int kc = mt >> 1, lt = (2 * (mt & 1) + (g >> 1)) * 16 + n, dw = 2 * (g & 1);
             const f32x4 vs = real ? v * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -371,13 +382,19 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     if constexpr (PARTIAL) {                             // raw accumulators of this slice -> [slice][B][16][COUT]
         if (real) {
 #pragma unroll
-            for (int i = 0; i < MTW; ++i)
-                *(f32x4 *)&sa.part[(((size_t)slice * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4] = acc[i];
+            for (int i = 0; i < MTW; ++i) {
+                const size_t at = (((size_t)slice * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4;
+                if (sa.ctr_done) {                       // read by workgroups of this launch on other XCDs: past the L2 (see the reading side above)
+                    const __amdgpu_buffer_rsrc_t rs_pt = __builtin_amdgcn_make_buffer_rsrc(sa.part, 0, 0x7fffffff, 0x00027000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs_pt, (unsigned)(at * 4), 0, kAuxSys);
+                } else
+                    *(f32x4 *)&sa.part[at] = acc[i];
+            }
         }
-        if (sa.ctr_done) {                               // pipelined slices: publish (every thread's stores, then one arrival per workgroup)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (sa.ctr_done) {                               // pipelined slices: publish (every wave's stores acknowledged, then one arrival per workgroup)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(sa.ctr_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(sa.ctr_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -435,9 +452,10 @@ void fused_block_lb4_kernel(Lb4StageArgs sa, int B) {
 template <class C>
 __global__ __launch_bounds__(256) void lb4_reduce_kernel(const float *__restrict__ part, int S, const unsigned *__restrict__ Glb,
                                                          const float *__restrict__ p_shift, const float *__restrict__ X,
-                                                         float *__restrict__ Y, int B) {
+                                                         float *__restrict__ Y, int B, unsigned *ctr_zero = nullptr, int n_zero = 0) {
     constexpr int C4 = C::COUT / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * 16 * C4;
+    if (idx < n_zero) ctr_zero[idx] = 0u;                // (behind lb4_pipe_kernel: its arrival counters start the next forward at zero)
     if (idx >= total) return;
     const int c4 = (int)(idx % C4);
     const float inv_p = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW)[11 * 32 + 1];
@@ -516,14 +534,15 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
 // block 16 also stores its reduced input (features.15's output), which is the residual of features.16 that block 17's workgroups need.
 // No deadlock: a workgroup only ever waits for workgroups with LOWER indices, and a grid is dispatched in index order -- whatever it waits
 // for is resident or finished, also with other kernels (other replicas' launches of this one included) sharing the chip; the wait is
-// bounded anyway.  Counters only grow (target = epoch x S): nothing to reset, nothing an aborted forward could leave behind.
-// features.17's partial sums are reduced by lb4_reduce_kernel as before.
+// bounded anyway.  The partial sums of features.15 / 16 and features.15's output cross XCDs inside the launch: they are stored and loaded past the
+// (per-XCD, mutually incoherent) L2s with sc0 sc1 instead of bracketing them with agent-scope fences, which write back / invalidate a whole L2.
+// features.17's partial sums are reduced by lb4_reduce_kernel as before; that launch also zeroes the counters for the next forward.
 struct Lb4PipeArgs {
     Lb4StageArgs s[3];       // X / Glb / p_shift of features.15, 16, 17 (Y unused)
     float *part[3];          // partial sums of the three blocks
     float *y15;              // features.15's output (the residual of features.16)
     unsigned *ctr;           // [2][Q] arrival counters
-    unsigned target;         // (epoch + 1) x S
+    unsigned target;         // S (the counters are zero at the start of a forward)
     int Q, S;
 };
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -559,10 +578,12 @@ bool launch_lb4_pipe(const FusedBlockArgs *a, int B, hipStream_t s, unsigned *ct
     Lb4PipeArgs pa;
     for (int i = 0; i < 3; ++i) pa.s[i] = Lb4StageArgs{a[i].X, a[i].Glb, a[i].p_shift, a[i].Y};
     pa.part[0] = a[0].scratch; pa.part[1] = pa.part[0] + p160; pa.part[2] = pa.part[1] + p160; pa.y15 = pa.part[2] + p320;
-    pa.ctr = ctr; pa.target = (epoch + 1u) * (unsigned)S; pa.Q = Q; pa.S = S;
+    (void)epoch;
+    pa.ctr = ctr; pa.target = (unsigned)S; pa.Q = Q; pa.S = S;
     lb4_pipe_kernel<<<3 * Q * S, 512, 0, s>>>(pa, B);
     const long total = (long)B * 16 * (Q17::COUT / 4);
-    lb4_reduce_kernel<Q17><<<(int)((total + 255) / 256), 256, 0, s>>>(pa.part[2], S, a[2].Glb, a[2].p_shift, nullptr, a[2].Y, B);
+    // features.17's slices (written with ordinary stores: a kernel boundary lies between) -> Y; the same launch zeroes the 2 Q counters used above
+    lb4_reduce_kernel<Q17><<<(int)((total + 255) / 256), 256, 0, s>>>(pa.part[2], S, a[2].Glb, a[2].p_shift, nullptr, a[2].Y, B, ctr, 2 * Q);
     return true;
 }
 
