@@ -185,17 +185,38 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
         // and the release on the other side would write a whole L2 back (first version of this kernel: 0.395 instead of 0.289 ms per step).
         // Instead exactly these tensors travel past the L2s: stored and loaded with sc0 sc1 (system scope: write-through / always miss).
         const float inv_pp = reinterpret_cast<const float *>(sa.pin_glb + Q15_WE_WP_DW)[11 * 32 + 1];
-        const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_part), 0, 0x7fffffff, 0x00027000);
         const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_res), 0, 0x7fffffff, 0x00027000);
         const bool res_cc = sa.pin_ystore == nullptr;      // the residual is features.15's output, written inside this launch (block 17's workgroups); block 16's: the chain input
         unsigned *HO = smem + GRPL;
+        // all loads of a round are issued before the first is consumed (they miss every cache: ~2 us each, and a loop of load -> add would pay
+        // that S x 5 times): five slices x five output tiles = 25 loads in flight; a slice past the last one reads zeros (offset beyond the
+        // resource's range), and a + 0 is a -- the sums keep lb4_reduce_kernel's order
+        const unsigned stride = (unsigned)B * 16u * 160u * 4u;                      // bytes per slice
+        const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_part), 0, (unsigned)sa.pin_S * stride, 0x00027000);
+        unsigned at5[5];
+        f32x4 a5[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            at5[i] = (unsigned)((fc * 16 + n) * 160 + 16 * (t * 5 + i) + g4) * 4u;
+            a5[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pb, at5[i], 0, kAuxSys));
+        }
+        for (int s0 = 1; s0 < sa.pin_S; s0 += 5) {
+            f32x4 tq[5][5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int i = 0; i < 5; ++i)       // (voffset carries the slice: past the last slice it leaves the resource and the load returns 0)
+                    tq[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pb, at5[i] + (unsigned)(s0 + j) * stride, 0, kAuxSys));
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) a5[i] += tq[j][i];
+        }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int mt = t * 5 + i, nch = 16 * mt + g4;
-            const unsigned at = (unsigned)((fc * 16 + n) * 160 + nch) * 4u, stride = (unsigned)B * 16u * 160u * 4u;      // bytes
-            f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, at, 0, kAuxSys));
-            for (int sl = 1; sl < sa.pin_S; ++sl) a += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, at, sl * stride, kAuxSys));
-            f32x4 v = a * inv_pp + *(const f32x4 *)&sa.pin_pshift[nch];
+            const unsigned at = at5[i];
+            f32x4 v = a5[i] * inv_pp + *(const f32x4 *)&sa.pin_pshift[nch];
             if (sa.pin_res) v += res_cc ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, kAuxSys))
                                         : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, 0));
             if (sa.pin_ystore && slice == 0 && real) {
@@ -573,6 +594,9 @@ bool launch_lb4_pipe(const FusedBlockArgs *a, int B, hipStream_t s, unsigned *ct
     static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
     int S = 30;
     for (int d : divs) if (Q * d >= 192) { S = d; break; }
+    // many slices (few faces): every workgroup of a block adds S partial tensors it fetches from memory -- from ~77 faces on (S <= 10) that is two rounds of loads
+    static const int smax = getenv("SYN_LB4_PIPE_SMAX") ? atoi(getenv("SYN_LB4_PIPE_SMAX")) : 10;
+    if (S > smax) return false;
     const size_t p160 = (size_t)S * B * 16 * 160, p320 = (size_t)S * B * 16 * 320, y = (size_t)B * 16 * 160;
     if (2 * p160 + p320 + y > a[0].scratch_floats) return false;
     Lb4PipeArgs pa;

@@ -830,17 +830,21 @@ def test_pipelined_slices_of_features_15_17_equal_the_sliced_launches(model, gol
         pytest.skip('the register-resident blocks belong to the default schedule')
     sizes = [1, 5, 33, 128, 130, 300, 575]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / 'p.npz')
-    r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
-                       env=dict(os.environ, SYN_LB4_PIPE='0'), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    want = np.load(out)
+    def run(tag, **env):
+        o = str(tmp_path / (tag + '.npz'))
+        r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, o, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return np.load(o)
+    want = run('sliced', SYN_LB4_PIPE='0')
+    every = run('pipe_all', SYN_LB4_PIPE='1', SYN_LB4_PIPE_SMAX='30')      # the pipelined launch at EVERY batch size (default: from ~77 faces on, S <= 10)
     for B in sizes:
         crops = torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()
         for rep in range(3):
             got = model.forward_crops_u8(crops).cpu().numpy()
             assert np.isfinite(got).all()
             assert np.array_equal(want['p%d_%d' % (B, rep)], got), f'B={B}, forward {rep}'
+            assert np.array_equal(want['p%d_%d' % (B, rep)], every['p%d_%d' % (B, rep)]), f'B={B}, forward {rep} (pipelined at every size)'
 
 
 @pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
