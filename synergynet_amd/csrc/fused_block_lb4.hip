@@ -89,8 +89,6 @@ struct Lb4Cfg {
 // stays in the accumulator's registers, and the next stage's first weight group is fetched during the last group of this one --
 // no kernel boundary (10-16 us each), no global round trip of the 4x4 activations.
 struct Lb4NoNext { static constexpr int NKB = 0; };
-constexpr int kAuxSys = 1 | 16;          // buffer-instruction cache policy sc0 sc1 (gfx940+: bit 0 = sc0, bit 4 = sc1): system scope, past the L2
-constexpr int Q15_WE_WP_DW = Lb4Cfg<160, 960, 160, true>::WE_DW + Lb4Cfg<160, 960, 160, true>::WP_DW;     // a 160 -> 960 -> 160 group's table offset
 struct Lb4StageArgs {
     const float *X;          // block input (global): a FIRST stage's input and residual
     const unsigned *Glb;     // [NG][NKB][64][4]: We | Wp | table per group
@@ -98,17 +96,6 @@ struct Lb4StageArgs {
     float *Y;                // block output (global): written by the last stage only
     float *part = nullptr;   // hidden-sliced schedule: partial sums [slice][B][16][COUT] (raw accumulators)
     int g0 = 0, g1 = 0;      // hidden groups [g0, g1) of this workgroup's slice (g1 = 0: all); slice = blockIdx.y
-    // pipelined slices (lb4_pipe_kernel): the face quad / slice of this workgroup (-1: blockIdx.x / .y), and where the block input comes from
-    int quad = -1, slice = -1;
-    const float *pin_part = nullptr;     // the PREVIOUS block's partial sums [slice][B][16][160]: reduced here, in lb4_reduce_kernel's order
-    int pin_S = 0;
-    const float *pin_pshift = nullptr;   // ... its BN shift
-    const unsigned *pin_glb = nullptr;   // ... its group 0 table (accumulator -> output scale)
-    const float *pin_res = nullptr;      // ... its residual (its own block input), or null
-    float *pin_ystore = nullptr;         // slice 0 stores the reduced block input here (the residual source of the block after this one), or null
-    unsigned *ctr_wait = nullptr;        // arrival counter of the previous block's slices of this face quad
-    unsigned *ctr_done = nullptr;        // ... of this block's
-    unsigned ctr_target = 0;             // value ctr_wait reaches when all slices of the previous block have published
 };
 
 // SYN_LB4_ABL: TIMING-ONLY ablations (wrong results; tools/build_variant.sh): 1 no weight fetch from L2 | 2 no park into LDS | 4 no exchange
@@ -139,10 +126,7 @@ __device__ __forceinline__ void lb4_park(const u32x4 *pf, unsigned *dst /* + 4 l
 // PARTIAL (small batches): the workgroup (blockIdx.x = four faces, blockIdx.y = slice) walks only the hidden groups of its slice and
 // stores its raw accumulators; lb4_reduce_kernel adds the slices in fixed order, rescales, adds BN shift and residual.  A batch of 128
 // faces is then 32 x 6 workgroups of five groups each instead of 32 workgroups walking all thirty.
-// PIPEIN (with PARTIAL, lb4_pipe_kernel): the block input is the previous block's output, which exists only as that block's per-slice partial
-// sums: wait for its slices of this face quad, add them (+ BN shift, + residual) exactly as lb4_reduce_kernel does, hand the result to the
-// fragment registers through LDS as a chain stage does.
-template <class C, class CN, bool FIRST, int GRPL, bool PARTIAL = false, bool PIPEIN = false>
+template <class C, class CN, bool FIRST, int GRPL, bool PARTIAL = false>
 __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa, const unsigned *GlbNext, int B, u32x4 (&Xr)[5][2], f32x4 (&vres)[5]) {
     constexpr int KE = C::KE, MTW = C::MTW, CIN = C::CIN, COUT = C::COUT;
     constexpr bool HANDOFF = !__is_same(CN, void);
@@ -153,8 +137,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fl = wave >> 1, t = wave & 1;
-    const int quad = sa.quad >= 0 ? sa.quad : (int)blockIdx.x, slice = sa.slice >= 0 ? sa.slice : (int)blockIdx.y;
-    const int f = quad * 4 + fl;
+    const int f = blockIdx.x * 4 + fl;
     const bool real = f < B;
     const int fc = real ? f : B - 1;
     const int n = lane & 15, g = lane >> 4;
@@ -169,76 +152,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     constexpr int NPWN = CNX::NKB / 8;
     u32x4 pf[NPW > NPWN ? NPW : NPWN];
     const int gsl = PARTIAL ? (sa.g1 - sa.g0) : C::NG;   // groups per slice (all slices the same)
-    const int gb = PARTIAL ? slice * gsl : 0, ge = gb + gsl;
-    if constexpr (PIPEIN) {
-        static_assert(PARTIAL && !FIRST && KE == 5, "pipelined slices: 160-channel block inputs");
-        lb4_fetch<NPW>(pf, Glb + (size_t)gb * C::GRP_DW + l4, wave);          // (the weights do not depend on anybody: in flight across the wait)
-        if (threadIdx.x == 0) {
-            // every slice of the previous block of this face quad has a LOWER workgroup index than this workgroup: dispatched earlier, i.e.
-            // resident or finished -- the wait cannot starve them (lb4_pipe_kernel).  Bounded all the same: a broken counter gives wrong numbers, not a hang.
-            int spins = 0;
-            while ((int)(__hip_atomic_load(sa.ctr_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sa.ctr_target) < 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-        // The partial sums (and features.15's output) were written by workgroups on OTHER XCDs, whose L2s are not coherent with this one for
-        // ordinary accesses.  An agent-scope acquire would invalidate this XCD's whole L2 -- the weight runs every workgroup streams from it --
-        // and the release on the other side would write a whole L2 back (first version of this kernel: 0.395 instead of 0.289 ms per step).
-        // Instead exactly these tensors travel past the L2s: stored and loaded with sc0 sc1 (system scope: write-through / always miss).
-        const float inv_pp = reinterpret_cast<const float *>(sa.pin_glb + Q15_WE_WP_DW)[11 * 32 + 1];
-        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_res), 0, 0x7fffffff, 0x00027000);
-        const bool res_cc = sa.pin_ystore == nullptr;      // the residual is features.15's output, written inside this launch (block 17's workgroups); block 16's: the chain input
-        unsigned *HO = smem + GRPL;
-        // all loads of a round are issued before the first is consumed (they miss every cache: ~2 us each, and a loop of load -> add would pay
-        // that S x 5 times): five slices x five output tiles = 25 loads in flight; a slice past the last one reads zeros (offset beyond the
-        // resource's range), and a + 0 is a -- the sums keep lb4_reduce_kernel's order
-        const unsigned stride = (unsigned)B * 16u * 160u * 4u;                      // bytes per slice
-        const __amdgpu_buffer_rsrc_t rs_pb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sa.pin_part), 0, (unsigned)sa.pin_S * stride, 0x00027000);
-        unsigned at5[5];
-        f32x4 a5[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            at5[i] = (unsigned)((fc * 16 + n) * 160 + 16 * (t * 5 + i) + g4) * 4u;
-            a5[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pb, at5[i], 0, kAuxSys));
-        }
-        for (int s0 = 1; s0 < sa.pin_S; s0 += 5) {
-            f32x4 tq[5][5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-#pragma unroll
-                for (int i = 0; i < 5; ++i)       // (voffset carries the slice: past the last slice it leaves the resource and the load returns 0)
-                    tq[j][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pb, at5[i] + (unsigned)(s0 + j) * stride, 0, kAuxSys));
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-#pragma unroll
-                for (int i = 0; i < 5; ++i) a5[i] += tq[j][i];
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int mt = t * 5 + i, nch = 16 * mt + g4;
-            const unsigned at = at5[i];
-            f32x4 v = a5[i] * inv_pp + *(const f32x4 *)&sa.pin_pshift[nch];
-            if (sa.pin_res) v += res_cc ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, kAuxSys))
-                                        : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, at, 0, 0));
-            if (sa.pin_ystore && slice == 0 && real) {
-                const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(sa.pin_ystore, 0, 0x7fffffff, 0x00027000);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, at, 0, kAuxSys);
-            }
-            // channels 16 mt + 4 g .. + 3 of pixel n: k32 step mt >> 1, lane group 2 (mt & 1) + (g >> 1), dwords 2 (g & 1), + 1 (as the chain's hand-over)
-            const int kc = mt >> 1, lt = (2 * (mt & 1) + (g >> 1)) * 16 + n, dw = 2 * (g & 1);
-            const f32x4 vs = real ? v * 16.0f : (f32x4){0.f, 0.f, 0.f, 0.f};
-            unsigned a0, b0, a1, b1;
-            split2q(vs[0], vs[1], a0, b0);
-            split2q(vs[2], vs[3], a1, b1);
-            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 0) * 256 + lt * 4 + dw] = (u32x2){a0, a1};
-            *(u32x2 *)&HO[((fl * KE + kc) * 2 + 1) * 256 + lt * 4 + dw] = (u32x2){b0, b1};
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kc = 0; kc < KE; ++kc)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) Xr[kc][p] = *(const u32x4 *)&HO[((fl * KE + kc) * 2 + p) * 256 + l4];
-        // (half 1 is rewritten at the end of this block's first group, two barriers from here)
-    }
+    const int gb = PARTIAL ? (int)blockIdx.y * gsl : 0, ge = gb + gsl;
     if (FIRST) {
         lb4_fetch<NPW>(pf, Glb + (size_t)gb * C::GRP_DW + l4, wave);
         // ---- block input of this face -> pre-split B fragments in registers (x 16; both waves of the face hold it) ----
@@ -264,7 +178,7 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float c6e = 0.f, inv_p = 0.f;
-    if (FIRST || PIPEIN) lb4_park<NPW>(pf, smem + l4, wave);
+    if (FIRST) lb4_park<NPW>(pf, smem + l4, wave);
 
     {   // ReLU6 ceiling of the scaled expand output, accumulator -> output: constants of the block, kept in group 0's table
         const float *t0 = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW);
@@ -403,19 +317,8 @@ __device__ __forceinline__ void lb4_stage(unsigned *smem, const Lb4StageArgs &sa
     if constexpr (PARTIAL) {                             // raw accumulators of this slice -> [slice][B][16][COUT]
         if (real) {
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                const size_t at = (((size_t)slice * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4;
-                if (sa.ctr_done) {                       // read by workgroups of this launch on other XCDs: past the L2 (see the reading side above)
-                    const __amdgpu_buffer_rsrc_t rs_pt = __builtin_amdgcn_make_buffer_rsrc(sa.part, 0, 0x7fffffff, 0x00027000);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rs_pt, (unsigned)(at * 4), 0, kAuxSys);
-                } else
-                    *(f32x4 *)&sa.part[at] = acc[i];
-            }
-        }
-        if (sa.ctr_done) {                               // pipelined slices: publish (every wave's stores acknowledged, then one arrival per workgroup)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(sa.ctr_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < MTW; ++i)
+                *(f32x4 *)&sa.part[(((size_t)blockIdx.y * B + f) * 16 + n) * COUT + 16 * (t * MTW + i) + g4] = acc[i];
         }
         return;
     }
@@ -473,10 +376,9 @@ void fused_block_lb4_kernel(Lb4StageArgs sa, int B) {
 template <class C>
 __global__ __launch_bounds__(256) void lb4_reduce_kernel(const float *__restrict__ part, int S, const unsigned *__restrict__ Glb,
                                                          const float *__restrict__ p_shift, const float *__restrict__ X,
-                                                         float *__restrict__ Y, int B, unsigned *ctr_zero = nullptr, int n_zero = 0) {
+                                                         float *__restrict__ Y, int B) {
     constexpr int C4 = C::COUT / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)B * 16 * C4;
-    if (idx < n_zero) ctr_zero[idx] = 0u;                // (behind lb4_pipe_kernel: its arrival counters start the next forward at zero)
     if (idx >= total) return;
     const int c4 = (int)(idx % C4);
     const float inv_p = reinterpret_cast<const float *>(Glb + C::WE_DW + C::WP_DW)[11 * 32 + 1];
@@ -546,77 +448,10 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     return true;
 }
 
-// ---- small batches, round 5: features.15, 16, 17 hidden-sliced AND in one launch ("pipelined slices") ----
-// The sliced schedule above is six launches per forward (three blocks x (slices + reduce)), ~9 us of launch, prologue and drain each around
-// ~8 us of arithmetic: 74 of the 290 us of a BASELINE configs[1] step.  Here the grid holds the workgroups of ALL three blocks, block-major:
-// workgroup (block n, face quad q, slice s) has index (n Q + q) S + s.  A workgroup of block n >= 1 waits until the S slices of block n - 1
-// of its face quad have published their partial sums (one arrival counter per (block, quad), device-scope release / acquire), adds them
-// itself -- the arithmetic and order of lb4_reduce_kernel, so the bits of the sliced schedule -- and starts its own groups; slice 0 of
-// block 16 also stores its reduced input (features.15's output), which is the residual of features.16 that block 17's workgroups need.
-// No deadlock: a workgroup only ever waits for workgroups with LOWER indices, and a grid is dispatched in index order -- whatever it waits
-// for is resident or finished, also with other kernels (other replicas' launches of this one included) sharing the chip; the wait is
-// bounded anyway.  The partial sums of features.15 / 16 and features.15's output cross XCDs inside the launch: they are stored and loaded past the
-// (per-XCD, mutually incoherent) L2s with sc0 sc1 instead of bracketing them with agent-scope fences, which write back / invalidate a whole L2.
-// features.17's partial sums are reduced by lb4_reduce_kernel as before; that launch also zeroes the counters for the next forward.
-struct Lb4PipeArgs {
-    Lb4StageArgs s[3];       // X / Glb / p_shift of features.15, 16, 17 (Y unused)
-    float *part[3];          // partial sums of the three blocks
-    float *y15;              // features.15's output (the residual of features.16)
-    unsigned *ctr;           // [2][Q] arrival counters
-    unsigned target;         // S (the counters are zero at the start of a forward)
-    int Q, S;
-};
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void lb4_pipe_kernel(Lb4PipeArgs pa, int B) {
-    __shared__ __attribute__((aligned(16))) unsigned smem[kChain4LdsDw];
-    u32x4 Xr[5][2];
-    f32x4 vres[5];
-    const int per = pa.Q * pa.S, lvl = (int)blockIdx.x / per, r = (int)blockIdx.x - lvl * per, q = r / pa.S, sl = r - q * pa.S;
-    Lb4StageArgs sa = pa.s[lvl];
-    sa.quad = q; sa.slice = sl; sa.part = pa.part[lvl]; sa.g0 = 0; sa.g1 = 30 / pa.S;
-    sa.ctr_done = lvl < 2 ? pa.ctr + lvl * pa.Q + q : nullptr;
-    if (lvl == 0) { lb4_stage<Q15, void, true, kChain4Grp, true>(smem, sa, nullptr, B, Xr, vres); return; }
-    sa.pin_part = pa.part[lvl - 1]; sa.pin_S = pa.S; sa.pin_pshift = pa.s[lvl - 1].p_shift; sa.pin_glb = pa.s[lvl - 1].Glb;
-    sa.pin_res = lvl == 1 ? pa.s[0].X : pa.y15;
-    sa.pin_ystore = lvl == 1 ? pa.y15 : nullptr;
-    sa.ctr_wait = pa.ctr + (lvl - 1) * pa.Q + q; sa.ctr_target = pa.target;
-    if (lvl == 1) lb4_stage<Q15, void, false, kChain4Grp, true, true>(smem, sa, nullptr, B, Xr, vres);
-    else lb4_stage<Q17, void, false, kChain4Grp, true, true>(smem, sa, nullptr, B, Xr, vres);
-}
-
-// a[i] = the arguments of features.(15 + i) (a[0].X the chain input, a[2].Y the output); ctr: >= 2 x ceil(B / 4) zero-initialised counters owned
-// by the caller's handle, epoch: how many times this launcher has used them.  false: not applicable (the blocks then run one by one, sliced)
-bool launch_lb4_pipe(const FusedBlockArgs *a, int B, hipStream_t s, unsigned *ctr, unsigned epoch) {
-    static const int on = getenv("SYN_LB4_PIPE") ? atoi(getenv("SYN_LB4_PIPE")) : 1;
-    if (!on || !ctr || !a[0].scratch) return false;
-    for (int i = 0; i < 3; ++i) if (!a[i].Glb || a[i].prof) return false;
-    const int Q = (B + 3) / 4;
-    static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
-    int S = 30;
-    for (int d : divs) if (Q * d >= 192) { S = d; break; }
-    // many slices (few faces): every workgroup of a block adds S partial tensors it fetches from memory -- from ~77 faces on (S <= 10) that is two rounds of loads
-    static const int smax = getenv("SYN_LB4_PIPE_SMAX") ? atoi(getenv("SYN_LB4_PIPE_SMAX")) : 10;
-    if (S > smax) return false;
-    const size_t p160 = (size_t)S * B * 16 * 160, p320 = (size_t)S * B * 16 * 320, y = (size_t)B * 16 * 160;
-    if (2 * p160 + p320 + y > a[0].scratch_floats) return false;
-    Lb4PipeArgs pa;
-    for (int i = 0; i < 3; ++i) pa.s[i] = Lb4StageArgs{a[i].X, a[i].Glb, a[i].p_shift, a[i].Y};
-    pa.part[0] = a[0].scratch; pa.part[1] = pa.part[0] + p160; pa.part[2] = pa.part[1] + p160; pa.y15 = pa.part[2] + p320;
-    (void)epoch;
-    pa.ctr = ctr; pa.target = (unsigned)S; pa.Q = Q; pa.S = S;
-    lb4_pipe_kernel<<<3 * Q * S, 512, 0, s>>>(pa, B);
-    const long total = (long)B * 16 * (Q17::COUT / 4);
-    // features.17's slices (written with ordinary stores: a kernel boundary lies between) -> Y; the same launch zeroes the 2 Q counters used above
-    lb4_reduce_kernel<Q17><<<(int)((total + 255) / 256), 256, 0, s>>>(pa.part[2], S, a[2].Glb, a[2].p_shift, nullptr, a[2].Y, B, ctr, 2 * Q);
-    return true;
-}
-
 static int lb4_min_batch() {
     constexpr int min_b = 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
     return min_b;
 }
-
-int lb4_chain_min_batch() { return lb4_min_batch(); }
 
 // a[i] = the arguments of features.(15 + i); false: launch them one by one
 bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {

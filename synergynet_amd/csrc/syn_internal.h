@@ -90,9 +90,6 @@ bool launch_fused_block_early(int feature, const FusedBlockArgs &a, int B, hipSt
 constexpr int rm_expand_dwords(int cin, int hid) { return ((hid + 31) / 32) * ((cin + 15) / 16) * 512; }
 constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 512; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
-// features.15-17 of a small batch hidden-sliced in one launch (fused_block_lb4.hip lb4_pipe_kernel); a[0..2], ctr / epoch: the handle's counters
-bool launch_lb4_pipe(const FusedBlockArgs *a, int B, hipStream_t s, unsigned *ctr, unsigned epoch);
-int lb4_chain_min_batch();
 // features.5 + 6 (the same row-marching configuration) in ONE launch; false: not applicable (launch them one by one)
 bool launch_fused_pair_rm(const FusedBlockArgs &a5, const FusedBlockArgs &a6, int B, hipStream_t s);
 // 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip), both GEMMs on v_mfma_f32_16x16x32_f16 with every

@@ -281,8 +281,6 @@ static_assert(sizeof(RangeInfo) <= 64 * sizeof(float), "RangeInfo must fit its s
 }  // namespace
 
 struct syn_handle {
-    unsigned *pipe_ctr = nullptr;  // arrival counters of the pipelined features.15-17 launch (fused_block_lb4.hip lb4_pipe_kernel): 512 words, zeroed once, only ever grow
-    unsigned pipe_epoch = 0;       // ... how many launches have used them
     int device = 0;
     int arch = 0;                  // 0 = mobilenet_v2 (reference default), 1 = resnet50 (BASELINE config 5)
     float *d_backbone = nullptr;   // packed_count floats
@@ -560,18 +558,8 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 ca[i] = syn::FusedBlockArgs{X, P + E.dst_wpk, P + E.dst_scale, P + E.dst_shift, P + Dw.dst_wpk, P + Dw.dst_scale, P + Dw.dst_shift,
                                             P + Pr.dst_wpk, P + Pr.dst_scale, P + Pr.dst_shift, Y};
                 ca[i].Glb = reinterpret_cast<const unsigned *>(P + E.dst_glb);
-                ca[i].scratch = H2; ca[i].scratch_floats = (size_t)B * n.max_hidden;
             }
-            // small batches (below the chain's threshold): the three blocks hidden-sliced in ONE launch (lb4_pipe_kernel)
-            bool launched = false;
-            if (ok && B < syn::lb4_chain_min_batch()) {
-                if (!h->pipe_ctr) {
-                    HIP_TRY(hipMalloc((void **)&h->pipe_ctr, 512 * sizeof(unsigned)));
-                    HIP_TRY(hipMemset(h->pipe_ctr, 0, 512 * sizeof(unsigned)));
-                }
-                if (2 * ((B + 3) / 4) <= 512 && syn::launch_lb4_pipe(ca, B, s, h->pipe_ctr, h->pipe_epoch)) { ++h->pipe_epoch; launched = true; }
-            }
-            if (ok && (launched || syn::launch_fused_chain_lb4(ca, B, s))) {
+            if (ok && syn::launch_fused_chain_lb4(ca, B, s)) {
                 li += 8;
                 { float *t = X; X = Y; Y = t; }
                 mark(1517);
@@ -840,7 +828,6 @@ int syn_destroy(syn_handle *h) {
     DeviceGuard g(h->device);
     if (h->d_backbone) (void)hipFree(h->d_backbone);
     if (h->d_basis) (void)hipFree(h->d_basis);
-    if (h->pipe_ctr) (void)hipFree(h->pipe_ctr);
     if (h->ws) (void)hipFree(h->ws);
     if (h->rec) (void)hipFree(h->rec);
     if (h->d_tri) (void)hipFree(h->d_tri);

@@ -801,52 +801,6 @@ np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
 '''
 
 
-_VARIANT_SCRIPT_MULTI = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from synergynet_amd import synth
-from synergynet_amd.synergy3DMM import SynergyNet
-s_bb, s_3d = int(sys.argv[3]), int(sys.argv[4])
-m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(s_3d), backbone_state=synth.make_backbone_state(s_bb))
-out = {}
-for B in [int(b) for b in sys.argv[5].split(',')]:
-    crops = torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()
-    for rep in range(3):                      # (the arrival counters of the pipelined launch only ever grow: several forwards on one handle)
-        out['p%d_%d' % (B, rep)] = m.forward_crops_u8(crops).cpu().numpy()
-np.savez(sys.argv[2], **out)
-'''
-
-
-def test_pipelined_slices_of_features_15_17_equal_the_sliced_launches(model, golden, tmp_path):
-    """Round 5 (BASELINE configs[1]): below 576 faces features.15-17 run hidden-sliced, and since round 5 in ONE launch -- the workgroups of a block wait
-    for the slices of the block before (arrival counters, device scope), add their partial sums themselves in lb4_reduce_kernel's order and go on
-    (fused_block_lb4.hip lb4_pipe_kernel).  Same arithmetic in the same order as the six launches it replaces (SYN_LB4_PIPE=0): the SAME BITS,
-    at batch sizes with one, a few and many face quads, with a ragged last quad, on repeated forwards of one handle."""
-    import subprocess
-    import sys
-    import torch
-    from synergynet_amd import synth
-    if model._test_fusion != '2':
-        pytest.skip('the register-resident blocks belong to the default schedule')
-    sizes = [1, 5, 33, 128, 130, 300, 575]
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    def run(tag, **env):
-        o = str(tmp_path / (tag + '.npz'))
-        r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, o, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
-                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        return np.load(o)
-    want = run('sliced', SYN_LB4_PIPE='0')
-    every = run('pipe_all', SYN_LB4_PIPE='1', SYN_LB4_PIPE_SMAX='30')      # the pipelined launch at EVERY batch size (default: from ~77 faces on, S <= 10)
-    for B in sizes:
-        crops = torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()
-        for rep in range(3):
-            got = model.forward_crops_u8(crops).cpu().numpy()
-            assert np.isfinite(got).all()
-            assert np.array_equal(want['p%d_%d' % (B, rep)], got), f'B={B}, forward {rep}'
-            assert np.array_equal(want['p%d_%d' % (B, rep)], every['p%d_%d' % (B, rep)]), f'B={B}, forward {rep} (pipelined at every size)'
-
-
 @pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
                                    {'SYN_RM_PAIR56': '0'}],
                          ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
