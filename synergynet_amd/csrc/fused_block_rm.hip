@@ -130,7 +130,7 @@ template <class C, bool PROF>
 __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict__ X, const unsigned *__restrict__ Ae3 /*[NG][KS][2][64][4]*/,
                            const unsigned *__restrict__ Ap3 /*[NG][2][2][64][4]*/, const float *__restrict__ e_shift,
                            const float *__restrict__ Wd /*[9][HID] scaled*/, const float *__restrict__ d_shift,
-                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, int n_units,
+                           const float *__restrict__ p_shift, float *__restrict__ Y, int B, int ub_begin, int ub_end, int ub_step /*this workgroup's units: ub_begin, + ub_step, ... < ub_end (each round: C::U units)*/,
                            const float *__restrict__ scl_e /*{S, 1/S, 6 S} of the expand weights*/, const float *__restrict__ scl_p,
                            unsigned long long *prof) {
     // PROF: s_memtime sums of compute wave 0 per phase {(unused), expand, (unused), depthwise, finalize, barrier wait,
@@ -196,7 +196,7 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
         // =====================================================================================================================
         // service wave of unit uw: block-input rows -> fp16 x2 fragments in LDS; finished output rows: partial sums -> NHWC row
         // =====================================================================================================================
-        for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
+        for (int ub = ub_begin; ub < ub_end; ub += ub_step) {
             const int unit = ub + uw;
             const int fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;     // face unit, first output row of the band
             const int f_in = fu * C::NF + ia, f_out = fu * C::NF + oa;
@@ -334,7 +334,7 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
     }
     // every wave of the workgroup runs the same number of rounds (and barriers); a unit past the end computes on zeros and
     // stores nothing (its faces are >= B)
-    for (int ub = blockIdx.x * C::U; ub < n_units; ub += gridDim.x * C::U) {
+    for (int ub = ub_begin; ub < ub_end; ub += ub_step) {
         const int unit = ub + uw;
         const int fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;
         const int f_in = fu * C::NF + ia;
@@ -612,10 +612,10 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
                            const float *__restrict__ Wd, const float *__restrict__ d_shift, const float *__restrict__ p_shift, float *__restrict__ Y, int B,
                            int n_units, const float *__restrict__ scl_e, const float *__restrict__ scl_p, unsigned long long *prof = nullptr) {
     __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
-    rm_block<C, PROF>(smem, X, Ae3, Ap3, e_shift, Wd, d_shift, p_shift, Y, B, n_units, scl_e, scl_p, prof);
+    rm_block<C, PROF>(smem, X, Ae3, Ap3, e_shift, Wd, d_shift, p_shift, Y, B, blockIdx.x * C::U, n_units, gridDim.x * C::U, scl_e, scl_p, prof);
 }
 
-// TWO consecutive blocks of the same configuration in one launch (round 5: features.5 + 6).  A workgroup marches its units through the first
+// TWO consecutive blocks in one launch (round 5: features.5 + 6, features.3 + 4).  A workgroup marches its units through the first
 // block, then the SAME units through the second: unit u of the second block reads exactly what unit u of the first one wrote (the same
 // faces), so nothing crosses workgroups and the kernel boundary between the two launches -- the drain of one grid, the dispatch of the
 // next, a second prologue on an empty chip -- becomes one workgroup barrier.  The first block's output still goes through global memory
@@ -624,15 +624,27 @@ void fused_block_rm_kernel(const float *__restrict__ X, const unsigned *__restri
 struct RmStageArgs {
     const float *X; const unsigned *Ae3, *Ap3; const float *e_shift, *Wd, *d_shift, *p_shift; float *Y; const float *scl_e, *scl_p;
 };
-template <class C>
-__global__ __launch_bounds__(C::NT) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE)))
-void fused_pair_rm_kernel(RmStageArgs a, RmStageArgs b, int B, int n_units) {
-    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DW];
-    rm_block<C, false>(smem, a.X, a.Ae3, a.Ap3, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, n_units, a.scl_e, a.scl_p, nullptr);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores of the first block are out of the CU
-    __syncthreads();                                            // ... and so are everybody's; nobody still reads the first block's LDS
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    rm_block<C, false>(smem, b.X, b.Ae3, b.Ap3, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, B, n_units, b.scl_e, b.scl_p, nullptr);
+// CA, CB: the two blocks' configurations (same workgroup size and register budget).  A workgroup takes GROUPS of FG faces -- FG = what one round of
+// either configuration covers at most -- through block A (one or two rounds of its units), then through block B.
+template <class CA, class CB>
+__global__ __launch_bounds__(CA::NT) __attribute__((amdgpu_waves_per_eu(CA::WPE, CA::WPE)))
+void fused_pair_rm_kernel(RmStageArgs a, RmStageArgs b, int B) {
+    static_assert(CA::NT == CB::NT && CA::WPE == CB::WPE && CA::NBD == 1 && CB::NBD == 1, "one workgroup shape for both blocks; whole-face marches");
+    constexpr int FA = CA::U * CA::NF, FB = CB::U * CB::NF, FG = FA > FB ? FA : FB;       // faces per round of A / of B / per group
+    static_assert(FG % FA == 0 && FG % FB == 0, "a group is whole rounds of both blocks");
+    __shared__ __attribute__((aligned(16))) unsigned smem[CA::LDS_DW > CB::LDS_DW ? CA::LDS_DW : CB::LDS_DW];
+    const int nua = (B + CA::NF - 1) / CA::NF, nub = (B + CB::NF - 1) / CB::NF;
+    {   // one group per workgroup (not persistent: a loop over groups around the two inlined blocks kept both blocks' lane geometry alive and spilled)
+        const int gq = blockIdx.x;
+        const int ua = gq * (FG / CA::NF), ub = gq * (FG / CB::NF);                        // first unit of the group in A's / B's unit numbering
+        rm_block<CA, false>(smem, a.X, a.Ae3, a.Ap3, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, B, ua, ua + FG / CA::NF < nua ? ua + FG / CA::NF : nua, CA::U,
+                            a.scl_e, a.scl_p, nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores of the first block are out of the CU
+        __syncthreads();                                            // ... and so are everybody's; nobody still reads the first block's LDS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        rm_block<CB, false>(smem, b.X, b.Ae3, b.Ap3, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, B, ub, ub + FG / CB::NF < nub ? ub + FG / CB::NF : nub, CB::U,
+                            b.scl_e, b.scl_p, nullptr);
+    }
 }
 
 static int env_int(const char *name, int dflt) {
@@ -676,16 +688,22 @@ template <int U, int NBD> using R2b = RmCfg< 16,  96,  24, 60, 2, 1, false, 3, U
 template <int U, int NBD> using R3b = RmCfg< 24, 144,  24, 30, 1, 1, true,  3, U, false, SYN_R3_WREG, NBD>;
 constexpr int kBand2Min = 40, kBand3Min = 96;
 
-// features.5 + 6 in one launch (B >= 513: the configuration launch_fused_block_rm would pick for either); false: launch them one by one
-bool launch_fused_pair_rm(const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
-    static const bool on = env_int("SYN_RM_PAIR56", 1) != 0;
-    if (!on || B < 513 || a.prof || b.prof) return false;
+// Two consecutive blocks in one launch (B >= 513: the configurations launch_fused_block_rm would pick for either): features.5 + 6 (first = 5) and
+// features.3 + 4 (first = 3).  false: launch them one by one
+template <class CA, class CB>
+static void launch_pair(const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
+    constexpr int FA = CA::U * CA::NF, FB = CB::U * CB::NF, FG = FA > FB ? FA : FB;
+    const int n_groups = (B + FG - 1) / FG;             // one workgroup per group of FG faces (256 resident at a time)
+    fused_pair_rm_kernel<CA, CB><<<n_groups, CA::NT, 0, s>>>(RmStageArgs{a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, a.scl_e, a.scl_p},
+                                                        RmStageArgs{b.X, b.Arm_e, b.Arm_p, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, b.scl_e, b.scl_p}, B);
+}
+bool launch_fused_pair_rm(int first, const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
+    static const bool on56 = env_int("SYN_RM_PAIR56", 1) != 0, on34 = env_int("SYN_RM_PAIR34", 1) != 0;
+    if (B < 513 || a.prof || b.prof) return false;
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p || !b.Arm_e || !b.Arm_p || !b.scl_e || !b.scl_p) return false;
-    using C = R5<2>;
-    const int n_units = (B + C::NF - 1) / C::NF, wgs = (n_units + C::U - 1) / C::U, grid = wgs < 256 ? wgs : 256;
-    fused_pair_rm_kernel<C><<<grid, C::NT, 0, s>>>(RmStageArgs{a.X, a.Arm_e, a.Arm_p, a.e_shift, a.Wd, a.d_shift, a.p_shift, a.Y, a.scl_e, a.scl_p},
-                                                  RmStageArgs{b.X, b.Arm_e, b.Arm_p, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, b.scl_e, b.scl_p}, B, n_units);
-    return true;
+    if (first == 5 && on56) { launch_pair<R5<2>, R5<2>>(a, b, B, s); return true; }
+    if (first == 3 && on34) { launch_pair<R3<2>, R4<2>>(a, b, B, s); return true; }
+    return false;
 }
 
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s) {

@@ -599,14 +599,14 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 return a;
             };
             syn::FusedBlockArgs a = block_args(li, X, Y);
-            // features.5 + 6 (one row-marching configuration, residual blocks on the same faces) as ONE launch (fused_block_rm.hip)
-            if (L.feature == 5 && a.Arm_e && prof_feature < 0 && (stop_feature < 0 || stop_feature >= 6) && li + 6 <= nl &&
-                n.layers[li + 3].kind == PW && n.layers[li + 3].relu6 && n.layers[li + 3].feature == 6) {
+            // features.3 + 4 and features.5 + 6 as ONE launch each (fused_block_rm.hip: a workgroup marches its faces through both blocks)
+            if ((L.feature == 3 || L.feature == 5) && a.Arm_e && prof_feature < 0 && (stop_feature < 0 || stop_feature >= L.feature + 1) && li + 6 <= nl &&
+                n.layers[li + 3].kind == PW && n.layers[li + 3].relu6 && n.layers[li + 3].feature == L.feature + 1) {
                 const syn::FusedBlockArgs b = block_args(li + 3, Y, X);
-                if (b.Arm_e && syn::launch_fused_pair_rm(a, b, B, s)) {
-                    li += 5;                                    // (two blocks: X -> Y -> X, the chain input buffer holds the output again)
-                    mark(506);
-                    if (stop_feature == 6) {
+                if (b.Arm_e && syn::launch_fused_pair_rm(L.feature, a, b, B, s)) {
+                    li += 5;                                    // (two blocks: X -> Y -> X, the input buffer holds the output again)
+                    mark(100 * L.feature + L.feature + 1);
+                    if (stop_feature == L.feature + 1) {
                         const Layer &Lp = n.layers[li];
                         HIP_TRY(hipMemcpyAsync(feature_out, X, (size_t)B * Lp.cout * Lp.hout * Lp.hout * sizeof(float), hipMemcpyDeviceToDevice, s));
                         return SYN_OK;

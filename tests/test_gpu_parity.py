@@ -802,13 +802,13 @@ np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
 
 
 @pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
-                                   {'SYN_RM_PAIR56': '0'}],
+                                   {'SYN_RM_PAIR56': '0'}, {'SYN_RM_PAIR34': '0'}],
                          ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
 def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs):
     """features.7-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
     the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
-    faces per workgroup (head_kernel.hip); round 5: features.5 + 6 share one launch of the row-marching kernel (fused_pair_rm_kernel, B >= 513:
-    a workgroup marches its faces through both blocks, SYN_RM_PAIR56=0: two launches).  Every one of these is a schedule change only: with the chain off (one launch per
+    faces per workgroup (head_kernel.hip); round 5: features.5 + 6 and features.3 + 4 share one launch of the row-marching kernel each
+    (fused_pair_rm_kernel, B >= 513: a workgroup marches its faces through both blocks; SYN_RM_PAIR56=0 / SYN_RM_PAIR34=0: two launches).  Every one of these is a schedule change only: with the chain off (one launch per
     block), with the shorter features.8-13 / 8-14 chains, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
     read once per process, hence the subprocess."""
     import subprocess
