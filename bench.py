@@ -345,7 +345,7 @@ def _recon_rocprof():
     """(average ms of syn::recon_f16_kernel<4, true, ...> in the newest committed one-stream kernel-stats bundle, its path) -- a second,
     dispatch-free measurement of the kernel extra.reconstruction_alone.kernel times with HIP events."""
     import csv
-    for rnd in ('r4', 'r3'):
+    for rnd in ('r5', 'r4', 'r3'):
         fp = os.path.join(ROOT, 'profiles', rnd, 'kernel_stats_b1024_one_stream.csv')
         if os.path.isfile(fp):
             try:
@@ -572,7 +572,7 @@ def main():
         # tools/make_profiles.py -> profiles/traffic_rN.json).  They are NOT measured by this run: counters_source says which file,
         # which commit and which box they are from, so a reader can tell a stale bundle from a fresh one.
         traffic = pipe_busy = counters_source = traffic_fwd = None
-        for name in ('traffic_r4.json', 'traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
+        for name in ('traffic_r5.json', 'traffic_r4.json', 'traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
             tfp = os.path.join(ROOT, 'profiles', name)
             if os.path.isfile(tfp) and B == 1024:
                 try:
@@ -597,9 +597,9 @@ def main():
                     pass
         ceiling = PEAK_F16X2_TFLOPS
         roof = dict(bound='mfma',
-                    kernel=f'syn::fused_block_rm_kernel, syn::fused_chain_lb_kernel, syn::fused_chain_lb4_kernel (expand 1x1 -> dw 3x3 -> project 1x1 '
+                    kernel=f'syn::fused_block_rm_kernel, syn::fused_pair_rm_kernel, syn::fused_chain_lb_kernel, syn::fused_chain_lb4_kernel (expand 1x1 -> dw 3x3 -> project 1x1 '
                            f'per block; {len(fam)} launches per forward, features.2-17 = {fam_fl / flops.sum() * 100:.1f}% of backbone FLOPs; '
-                           f'features.2-6 row-marching, features.7-14 and 15-17 register-resident chains of blocks in one launch each (launch code '
+                           f'features.2-6 row-marching (3 + 4 and 5 + 6 two blocks per launch), features.7-14 and 15-17 register-resident chains of blocks in one launch each (launch code '
                            f'100 * first + last), hidden activations never leave registers); fp32-accurate '
                            f'results on v_mfma_f32_{{32x32x16,16x16x32}}_f16 with every operand as two fp16 pieces (3 MFMAs per block product): '
                            f'algorithmic fp32 FLOPs priced against the dense fp16 MFMA peak / 3',

@@ -702,7 +702,9 @@ bool launch_fused_pair_rm(int first, const FusedBlockArgs &a, const FusedBlockAr
     if (B < 513 || a.prof || b.prof) return false;
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p || !b.Arm_e || !b.Arm_p || !b.scl_e || !b.scl_p) return false;
     if (first == 5 && on56) { launch_pair<R5<2>, R5<2>>(a, b, B, s); return true; }
-    if (first == 3 && on34) { launch_pair<R3<2>, R4<2>>(a, b, B, s); return true; }
+    // features.3 + 4: one round of workgroups only (B <= 1024) -- a group of four faces is two rounds of features.3 and one of features.4 (~150 us), and
+    // a partly filled LAST round of such workgroups costs more than the boundary saves (B = 2307: 430 against 388 us; B = 1024: 153 against 160)
+    if (first == 3 && on34 && (B + 3) / 4 <= 256) { launch_pair<R3<2>, R4<2>>(a, b, B, s); return true; }
     return false;
 }
 

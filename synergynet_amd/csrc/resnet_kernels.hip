@@ -1169,26 +1169,46 @@ __global__ __launch_bounds__(256) void pool_fc_generic_kernel(const float *__res
     }
     const float *f = feat + (size_t)b * P * C;
     const float inv = 1.0f / (float)P;
+    // (round 5: 74 -> us at B = 512.  The pooling loop used to be load -> add per pixel, and every head row a chain of eight dependent
+    // round trips to L2: four pixels / four rows are now requested together -- the same sums in the same order)
     for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < P; ++p) a += *(const f32x4 *)&f[(size_t)p * C + 4 * c4];
+        int p = 0;
+        for (; p + 4 <= P; p += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *(const f32x4 *)&f[(size_t)(p + i) * C + 4 * c4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a += v[i];
+        }
+        for (; p < P; ++p) a += *(const f32x4 *)&f[(size_t)p * C + 4 * c4];
         a *= inv;
         *(f32x4 *)&sp[4 * c4] = a;
         if (pool) *(f32x4 *)&pool[(size_t)b * C + 4 * c4] = a + poison;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = wave; o < n_out; o += 4) {
-        const float *wr = Wfc + (size_t)o * C;
-        float a = 0.f;
+    for (int o0 = wave; o0 < n_out; o0 += 16) {              // this wave's rows o0, o0 + 4, o0 + 8, o0 + 12 together
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 wv = *(const f32x4 *)&wr[c];
             const f32x4 xv = *(const f32x4 *)&sp[c];
-            a += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            f32x4 wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = o0 + 4 * i < n_out ? o0 + 4 * i : o0;
+                wv[i] = *(const f32x4 *)&Wfc[(size_t)o * C + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] += wv[i][0] * xv[0] + wv[i][1] * xv[1] + wv[i][2] * xv[2] + wv[i][3] * xv[3];
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-        if (lane == 0) param[(size_t)b * out_stride + o] = a + bias[o] + poison;
+        for (int i = 0; i < 4; ++i) {
+            float t = a[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            const int o = o0 + 4 * i;
+            if (lane == 0 && o < n_out) param[(size_t)b * out_stride + o] = t + bias[o] + poison;
+        }
     }
 }
 

@@ -31,7 +31,7 @@ raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
 fetch, write = raw['fetch'], raw['write']
 launches = raw['fetch_launches']
 n_fwd = min(c for k, c in launches.items() if 'stem' in k and 'kernel' in k)          # one stem launch per forward
-fam = [k for k in fetch if 'fused_block' in k or 'fused_chain' in k]      # (chains: several blocks per launch)
+fam = [k for k in fetch if 'fused_block' in k or 'fused_chain' in k or 'fused_pair' in k]      # (chains: several blocks per launch)
 rd = sum(fetch[k]['FETCH_SIZE'] * 2 * 1024 * launches[k] / n_fwd for k in fam)
 n_fwd_w = min(c for k, c in raw['write_launches'].items() if 'stem' in k and 'kernel' in k)      # (the passes run for a time, not a count: each has its own number of forwards)
 wr = sum(write[k]['WRITE_SIZE'] * 1024 * raw['write_launches'][k] / n_fwd_w for k in fam)
