@@ -138,6 +138,9 @@ struct LbCfg {
     static_assert((FPW == 4 || NS >= 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
+#ifndef SYN_LB_DW2
+#define SYN_LB_DW2 1                // 0: lane shifts on the input rows (rounds 2-4), for A/B runs
+#endif
 // compiler fence between the phases of a hidden group: without it every load of a group is hoisted to the top of the loop body
 // and unchained arithmetic floats across the scheduling barriers (~370 registers live)
 #define SYNL_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -343,8 +346,10 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 #pragma unroll
             for (int k = 0; k < 9; ++k) w[k] = *(const f32x2 *)&Tb[k * 32 + c0 + g4];
             const f32x2 dsh = *(const f32x2 *)&Tb[9 * 32 + c0 + g4];
+            if (C::S2 || !SYN_LB_DW2) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
+                for (int dy = 0; dy < 3; ++dy) { w[3 * dy] *= mL; w[3 * dy + 2] *= mR; }
+            }
             f32x2 E[4], O[NB];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -366,6 +371,27 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 O[0] += dpp2<kRowShr1>(E[3]) * w[6];
                 O[0] += E[2] * w[7];
                 O[0] = pk_fma_clamp01(E[3], w[8], O[0]);
+            } else if (SYN_LB_DW2) {
+            // Round 5: the lane shifts move from the INPUT rows to the OUTPUT rows.  A lane shift commutes with the per-channel filter weight, so
+            //   out[r] = B + mL L(A) + mR R(C),   A / B / C = sum over dy of (left / centre / right filter column) x in[r + dy - 1]
+            // needs two shifts per output row (4 rows) where shifting every input row needs two per input row (6 rows: the block's four and the two
+            // halo rows): 20 instead of 28 lane shifts per channel pair, and the image border is a multiplier of the shifted SUM (no filter masking).
+            // Another summation order than rounds 2-4 (dx outermost): same arithmetic class.
+            const f32x2 mL2 = {mL, mL}, mR2 = {mR, mR};
+            f32x2 rowT = E[3], rowB = E[0];
+            asm volatile("" : "+v"(rowT), "+v"(rowB));
+            rowT = dpp2<kRowShr8>(rowT);                 // image row -1 of the block columns (zero fill = the border)
+            rowB = dpp2<kRowShl8>(rowB);                 // image row 4
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 &i0 = r == 0 ? rowT : E[r - 1], &i1 = E[r], &i2 = r == 3 ? rowB : E[r + 1];
+                f32x2 A = i0 * w[0], Cc = i0 * w[2], Bc = O[r] + i0 * w[1];
+                A += i1 * w[3]; Bc += i1 * w[4]; Cc += i1 * w[5];
+                A += i2 * w[6]; Bc += i2 * w[7]; Cc += i2 * w[8];
+                Bc += dpp2<kRowShr1>(A) * mL2;
+                O[r] = pk_fma_clamp01(dpp2<kRowShl1>(Cc), mR2, Bc);
+                asm volatile("" : "+v"(O[r]));           // (one output row at a time: three column sums live, not twelve)
+            }
             } else {
             // input rows q = -1 .. 4 of the block rows (row q feeds outputs q - dy, dy = 0..2: ascending dy per output).  The pins
             // chain the rows: unchained arithmetic is otherwise scheduled all rows at once.
