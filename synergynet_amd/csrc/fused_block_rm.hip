@@ -159,6 +159,49 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
     // light; with the cyclic wave -> SIMD placement the light waves are the third compute wave of their SIMD.
     const int nq_live = (C::HID % 32 == 16 && wave == NW - 1) ? 2 : 4;
 
+    // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
+    int ia, icol[C::NB], oa, ocol;
+    if (C::S == 1 && C::NF == 2) {
+        // two H-wide faces in one block sharing their zero-padding columns: lane 0 | face 0 columns 0..H-1 | lane H+1 | face 1 | (lane 32 = the
+        // other half's lane 0): every neighbour of an image column is either an image column of the same face or a zero lane
+        ia = j > C::H; icol[0] = (j == 0 || j == C::H + 1) ? -1 : j - 1 - (C::H + 1) * ia; oa = ia; ocol = icol[0];
+    } else if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
+    else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
+    else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
+    // Round 5: what the first row step needs from global memory is requested BEFORE the constants are staged (another round trip to L2 / HBM
+    // behind a barrier): the compute waves' weight fragments, and -- as touches whose data is dropped -- the first two input rows of the first unit
+    // of the row-staging service waves (their real loads then hit the cache).  SYN_RM_EARLY=0: the old order.
+#ifndef SYN_RM_EARLY
+#define SYN_RM_EARLY 1
+#endif
+    u32x4 ae[C::KS][2], ap[2][2];
+    unsigned early_sink = 0;
+    if (SYN_RM_EARLY) {
+        if (!service) {
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 2 + p) * 256 + lane * 4);
+            if (!C::LEAN)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
+        } else if (svc_in && ub_begin < ub_end) {
+            const int unit = ub_begin + uw, fu = C::NBD > 1 ? unit / C::NBD : unit, r0 = C::NBD > 1 ? (unit - fu * C::NBD) * C::HB : 0;
+            const int f_in = fu * C::NF + ia, y0 = C::NBD > 1 ? (C::S == 1 ? r0 - 1 : 2 * (r0 - 1)) : 0;
+#pragma unroll
+            for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const int y = y0 + yy;
+                    if ((unsigned)icol[b] < (unsigned)H && f_in < B && (unsigned)y < (unsigned)H) {
+                        const float *src = X + ((size_t)(f_in * H + y) * H + icol[b]) * C::CIN + 8 * h;
+                        asm volatile("global_load_dword %0, %1, off" : "+v"(early_sink) : "v"(src) : "memory");
+                    }
+                }
+        }
+    }
     // power-of-two operand scales of the fp16 pieces (synergy_abi.hip): the expand accumulators start at Se x shift, ReLU6 clamps at
     // 6 Se and the depthwise filter carries 1 / Se; the project sums are rescaled by 1 / Sp where the service wave reduces them
     //
@@ -178,16 +221,8 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
     if (C::LEAN)
         for (int i = tid; i < C::APL_DW / 4; i += NT) *(u32x4 *)&ApL[4 * i] = *(const u32x4 *)&Ap3[4 * i];
 
-    // lane geometry.  Input block b: lane j carries column icol[b] of face (unit*NF + ia); output rows: column ocol of face oa.
-    int ia, icol[C::NB], oa, ocol;
-    if (C::S == 1 && C::NF == 2) {
-        // two H-wide faces in one block sharing their zero-padding columns: lane 0 | face 0 columns 0..H-1 | lane H+1 | face 1 | (lane 32 = the
-        // other half's lane 0): every neighbour of an image column is either an image column of the same face or a zero lane
-        ia = j > C::H; icol[0] = (j == 0 || j == C::H + 1) ? -1 : j - 1 - (C::H + 1) * ia; oa = ia; ocol = icol[0];
-    } else if (C::S == 1) { ia = 0; icol[0] = j - 1; oa = 0; ocol = j - 1; }
-    else if (C::NF == 1) { ia = 0; icol[0] = 2 * j - 1; icol[C::NB - 1] = 2 * j; oa = 0; ocol = j; }
-    else { ia = j >> 4; icol[0] = 2 * (j & 15) - 1; icol[C::NB - 1] = 2 * (j & 15); oa = j >> 4; ocol = j & 15; }
     __syncthreads();
+    asm volatile("" :: "v"(early_sink));                // (the touches have returned: the barrier's wait covers every older load)
 
     if (service) {
         // The service waves are the youngest of their SIMD and would be served last by the issue arbiter, yet every compute wave
@@ -314,16 +349,17 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
     // compute wave: hidden group `wave` of unit uw
     // =========================================================================================================================
     // this wave's weight fragments stay in registers for the whole (persistent) kernel
-    u32x4 ae[C::KS][2], ap[2][2];
+    if (!SYN_RM_EARLY) {
 #pragma unroll
-    for (int s = 0; s < C::KS; ++s)
+        for (int s = 0; s < C::KS; ++s)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 2 + p) * 256 + lane * 4);
-    if (!C::LEAN)
+            for (int p = 0; p < 2; ++p) ae[s][p] = *(const u32x4 *)(Ae3 + ((size_t)(wave * C::KS + s) * 2 + p) * 256 + lane * 4);
+        if (!C::LEAN)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
+                for (int p = 0; p < 2; ++p) ap[s][p] = *(const u32x4 *)(Ap3 + ((size_t)(wave * 2 + s) * 2 + p) * 256 + lane * 4);
+    }
 
     f32x4 wreg[C::WREG > 0 ? C::WREG : 1][9], wbase[C::WREG > 0 ? C::WREG : 1];
 #pragma unroll

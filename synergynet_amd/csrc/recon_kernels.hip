@@ -691,12 +691,21 @@ __global__ __launch_bounds__(256) void lmk_pose_kernel(const float *__restrict__
                                                        const float *__restrict__ roi, int transform, float *__restrict__ lmk /*[B,3,n_lmk]*/,
                                                        double *__restrict__ angles, float *__restrict__ t3d, int B) {
     const int b = blockIdx.x, l = threadIdx.x;
-    __shared__ float p[64], aff[12];
-    extern __shared__ float S[];                     // [3][nlp]
+    __shared__ float p[64];
     if (l < kParam) p[l] = param[(size_t)b * kParam + l] * stdv[l] + mean[l];
-    __syncthreads();
-    if (l < 3) {                                     // out = Mx * S + T of recon_prep_kernel (same expressions)
-        const int c = l;
+    __syncthreads();                                 // the only barrier: a landmark's thread computes all three coordinates and its own copy of
+                                                     // the affine map, so the pose -- double-precision asin / atan2 on ONE lane, the longest chain
+                                                     // of the kernel -- runs BESIDE the contraction on the last thread instead of in front of a barrier
+    if (l == 255 && angles) {
+        float pp[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pp[i] = p[i];
+        pose_of_face(pp, roi ? roi + (size_t)b * 5 : nullptr, angles + (size_t)b * 3, t3d + (size_t)b * 3, nullptr);
+    }
+    // out = Mx * S + T of recon_prep_kernel (same expressions), per thread
+    float aff[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
         float sc = 1.0f, of = 0.0f;
         if (roi) {
             const float sx = roi[b * 5 + 0], sy = roi[b * 5 + 1], ex = roi[b * 5 + 2], ey = roi[b * 5 + 3];
@@ -712,44 +721,39 @@ __global__ __launch_bounds__(256) void lmk_pose_kernel(const float *__restrict__
         aff[3 * c + 2] = m2 * sc;
         aff[9 + c] = t * sc + of;
     }
-    if (l == 0 && angles) {
-        float pp[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) pp[i] = p[i];
-        pose_of_face(pp, roi ? roi + (size_t)b * 5 : nullptr, angles + (size_t)b * 3, t3d + (size_t)b * 3, nullptr);
-    }
-    // S[c][v] = sum_k basis[v][c][k] alpha[k]: element k = 8 t + 4 h + s of (tile T, coord c, column j) sits at
+    // S[c] = sum_k basis[v][c][k] alpha[k]: element k = 8 t + 4 h + s of (tile T, coord c, column j) sits at
     // T * 3 * 52 * 32 + c * 52 * 32 + t * 256 + (32 h + j) * 4 + s; the tail k = 48 + 2 h + s at ... + 6 * 256 + (32 h + j) * 2 + s (k = 50: the mean
     // shape, coefficient 1; k = 51: zero pad)
-    for (int i = l; i < 3 * nlp; i += 256) {
-        const int c = i / nlp, v = i - c * nlp, T = v >> 5, j = v & 31;
-        const float *bc = basis + ((size_t)T * 3 + c) * (kBasisK * 32);
-        float acc = 0.f;
+    for (int v = l; v < n_lmk; v += 256) {
+        const int T = v >> 5, j = v & 31;
+        float S[3];
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int c = 0; c < 3; ++c) {
+            const float *bc = basis + ((size_t)T * 3 + c) * (kBasisK * 32);
+            float acc = 0.f;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 w = *(const f32x4 *)(bc + t * 256 + (32 * h + j) * 4);
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = __builtin_fmaf(w[s], p[12 + 8 * t + 4 * h + s], acc);
-            }
-        const f32x2 w0 = *(const f32x2 *)(bc + 6 * 256 + j * 2), w1 = *(const f32x2 *)(bc + 6 * 256 + (32 + j) * 2);
-        acc = __builtin_fmaf(w0[0], p[12 + 48], acc);
-        acc = __builtin_fmaf(w0[1], p[12 + 49], acc);
-        acc += w1[0];                                // the mean shape
-        S[i] = acc;
-    }
-    __syncthreads();
-    for (int i = l; i < 3 * n_lmk; i += 256) {
-        const int c = i / n_lmk, v = i - c * n_lmk;
-        const float sx = S[v], sy = S[nlp + v], sz = S[2 * nlp + v];
-        lmk[((size_t)b * 3 + c) * n_lmk + v] = aff[3 * c + 0] * sx + aff[3 * c + 1] * sy + aff[3 * c + 2] * sz + aff[9 + c];
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 w = *(const f32x4 *)(bc + t * 256 + (32 * h + j) * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_fmaf(w[s], p[12 + 8 * t + 4 * h + s], acc);
+                }
+            const f32x2 w0 = *(const f32x2 *)(bc + 6 * 256 + j * 2), w1 = *(const f32x2 *)(bc + 6 * 256 + (32 + j) * 2);
+            acc = __builtin_fmaf(w0[0], p[12 + 48], acc);
+            acc = __builtin_fmaf(w0[1], p[12 + 49], acc);
+            acc += w1[0];                            // the mean shape
+            S[c] = acc;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            lmk[((size_t)b * 3 + c) * n_lmk + v] = aff[3 * c + 0] * S[0] + aff[3 * c + 1] * S[1] + aff[3 * c + 2] * S[2] + aff[9 + c];
     }
 }
 
 void launch_lmk_pose(const float *param, const float *mean62, const float *std62, const float *basis_lmk, int n_lmk, int nlp, const float *roi,
                      int transform, float *lmk, double *angles, float *t3d, int B, hipStream_t s) {
-    lmk_pose_kernel<<<B, 256, 3 * nlp * sizeof(float), s>>>(param, mean62, std62, basis_lmk, n_lmk, nlp, roi, transform, lmk, angles, t3d, B);
+    lmk_pose_kernel<<<B, 256, 0, s>>>(param, mean62, std62, basis_lmk, n_lmk, nlp, roi, transform, lmk, angles, t3d, B);
 }
 
 }  // namespace syn
