@@ -17,6 +17,8 @@
 // where they are written to LDS (input tile in stage 0, depthwise output in stage 2).
 #include "syn_internal.h"
 
+#include <cstdlib>
+
 namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -101,14 +103,14 @@ struct Bf3Cfg {   // whole-image tiles only (HIN <= 15): every late block
 // tile of the next group is fetched into registers while the current one computes (the staging -- 10-19 % of a workgroup's life at
 // one group per workgroup -- shrinks to the split and the LDS writes), and the expand weights of chunk 0 arrive through the
 // wrap-around of the per-chunk prefetch.
-template <class C, bool PROF = false, int NS = 1, bool PERSIST = false>
-__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_f16_kernel(
+// the whole block as a device function (`smem`: the workgroup's C::LDS_DWORDS dwords), so that two blocks can share a launch (fused_pair_f16_kernel)
+template <class C, bool PROF, int NS, bool PERSIST>
+__device__ __forceinline__ void f16_block(unsigned *smem,
     const float *__restrict__ X, const unsigned *__restrict__ We3 /*[HID/16][KE][2][64][4]*/, const float *__restrict__ e_shift,
     const float *__restrict__ Wd, const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3 /*[COUTP/16][HID/32][2][64][4]*/,
     const float *__restrict__ p_shift, float *__restrict__ Y, int B, const float *__restrict__ scl_e, const float *__restrict__ scl_p,
-    unsigned long long *prof = nullptr) {
+    unsigned long long *prof) {
     unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, tk = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
-    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
     unsigned *Xb = smem;                                         // 2 planes [PINP][XSD]
     float *Es = reinterpret_cast<float *>(Xb + 2 * C::XPL);      // [PINP][ES] fp32 (scaled by Se)
     unsigned *Db = reinterpret_cast<unsigned *>(Es + C::PINP * C::ES);   // 2 planes [POUTP][DSD]
@@ -384,6 +386,31 @@ __global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::W
     }
 }
 
+template <class C, bool PROF = false, int NS = 1, bool PERSIST = false>
+__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_block_f16_kernel(
+    const float *__restrict__ X, const unsigned *__restrict__ We3, const float *__restrict__ e_shift, const float *__restrict__ Wd,
+    const float *__restrict__ d_shift, const unsigned *__restrict__ Wp3, const float *__restrict__ p_shift, float *__restrict__ Y, int B,
+    const float *__restrict__ scl_e, const float *__restrict__ scl_p, unsigned long long *prof = nullptr) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
+    f16_block<C, PROF, NS, PERSIST>(smem, X, We3, e_shift, Wd, d_shift, Wp3, p_shift, Y, B, scl_e, scl_p, prof);
+}
+
+// Two consecutive blocks of one configuration in ONE launch (round 5, small batches: features.5 + 6 of a batch below 513 faces, where the row-marching
+// pair of fused_block_rm.hip does not apply).  One workgroup per face (group): the second block reads what this workgroup's own waves stored,
+// in the same layout and rows -- a workgroup barrier with workgroup-scope release / acquire instead of a kernel boundary.
+struct F16StageArgs {
+    const float *X; const unsigned *We3; const float *e_shift, *Wd, *d_shift; const unsigned *Wp3; const float *p_shift; float *Y; const float *scl_e, *scl_p;
+};
+template <class C>
+__global__ __launch_bounds__(C::NW * 64) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void fused_pair_f16_kernel(F16StageArgs a, F16StageArgs b, int B) {
+    __shared__ __attribute__((aligned(16))) unsigned smem[C::LDS_DWORDS];
+    f16_block<C, false, 1, false>(smem, a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, B, a.scl_e, a.scl_p, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    f16_block<C, false, 1, false>(smem, b.X, b.We3, b.e_shift, b.Wd, b.d_shift, b.Wp3, b.p_shift, b.Y, B, b.scl_e, b.scl_p, nullptr);
+}
+
 template <class C, int NS>
 static void launch_f16_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     const dim3 grid((B + C::NF - 1) / C::NF, NS);
@@ -416,6 +443,17 @@ using B12 = Bf3Cfg<  96, 576,  96,  8, 1, true,   1, 32, 4, 2, 2, 2, 2>;    // f
 using B14 = Bf3Cfg<  96, 576, 160,  8, 2, false,  1, 64, 4, 4, 4, 1, 2>;    // features.14
 using B15 = Bf3Cfg< 160, 960, 160,  4, 1, true,   4, 64, 4, 4, 2, 2>;    // features.15,16
 using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // features.17
+
+// features.5 + 6 of a small batch in one launch (a[0..1]; one workgroup per face, not persistent: grids up to the resident 256 workgroups); false: one by one
+bool launch_fused_pair_f16(const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
+    static const bool on = !(getenv("SYN_F16_PAIR56") && atoi(getenv("SYN_F16_PAIR56")) == 0);
+    if (!on || a.prof || b.prof || !a.We3 || !a.Wp3 || !a.scl_e || !a.scl_p || !b.We3 || !b.Wp3 || !b.scl_e || !b.scl_p) return false;
+    const int grid = (B + B5::NF - 1) / B5::NF;
+    if (grid > B5::SLOTS) return false;                  // (larger batches take the persistent single launches, or the row-marching pair from 513 faces)
+    fused_pair_f16_kernel<B5><<<grid, B5::NW * 64, 0, s>>>(F16StageArgs{a.X, a.We3, a.e_shift, a.Wd, a.d_shift, a.Wp3, a.p_shift, a.Y, a.scl_e, a.scl_p},
+                                                          F16StageArgs{b.X, b.We3, b.e_shift, b.Wd, b.d_shift, b.Wp3, b.p_shift, b.Y, b.scl_e, b.scl_p}, B);
+    return true;
+}
 
 constexpr int kSliceMaxGrid = 48;      // workgroups (of 4 faces) below which the late blocks are sliced over output channels
 

@@ -92,6 +92,8 @@ constexpr int rm_project_dwords(int hid) { return ((hid + 31) / 32) * 2 * 512; }
 bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStream_t s);
 // features.3 + 4 / features.5 + 6 (first = 3 | 5) in ONE launch of the row-marching kernel; false: not applicable (launch them one by one)
 bool launch_fused_pair_rm(int first, const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s);
+// features.5 + 6 of a small batch (<= 256 faces) in ONE launch of the whole-image tiled kernel (fused_block_f16.hip); false: not applicable
+bool launch_fused_pair_f16(const FusedBlockArgs &a5, const FusedBlockArgs &a6, int B, hipStream_t s);
 // 8x8 blocks (features.8-13), register-resident schedule (fused_block_lb.hip), both GEMMs on v_mfma_f32_16x16x32_f16 with every
 // operand as TWO fp16 pieces (x = a + b, 22 significant bits; three products a a, a b, b a) and power-of-two operand scaling
 // (synergy_abi.hip pack_backbone_mbv2).  Fragments [..][piece 2][lane 64][4 dwords], lane (m = l&15, kg = l>>4):

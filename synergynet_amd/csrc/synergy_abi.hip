@@ -600,7 +600,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             };
             syn::FusedBlockArgs a = block_args(li, X, Y);
             // features.3 + 4 and features.5 + 6 as ONE launch each (fused_block_rm.hip: a workgroup marches its faces through both blocks)
-            if ((L.feature == 3 || L.feature == 5) && a.Arm_e && prof_feature < 0 && (stop_feature < 0 || stop_feature >= L.feature + 1) && li + 6 <= nl &&
+            if ((L.feature == 3 || L.feature == 5) && (a.Arm_e || (L.feature == 5 && a.We3)) && prof_feature < 0 && (stop_feature < 0 || stop_feature >= L.feature + 1) && li + 6 <= nl &&
                 n.layers[li + 3].kind == PW && n.layers[li + 3].relu6 && n.layers[li + 3].feature == L.feature + 1) {
                 // Workgroups run through the two blocks unsynchronised, so a buffer must never hold two tensor LAYOUTS at once: features.6 writes the
                 // rows of its own faces in features.5's input layout (safe), but features.4's 15x15x32 rows would land in the 30x30x24 input rows
@@ -609,7 +609,9 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                 const size_t in_a = (size_t)L.cin * L.hin * L.hin, out_b = (size_t)Pb.cout * Pb.hout * Pb.hout;
                 float *const out2 = (L.feature == 3 && in_a + out_b <= n.max_io) ? X + (size_t)B * in_a : (L.feature == 5 ? X : nullptr);
                 const syn::FusedBlockArgs b = block_args(li + 3, Y, out2);
-                if (out2 && b.Arm_e && syn::launch_fused_pair_rm(L.feature, a, b, B, s)) {
+                // (small batches: features.5 + 6 on the whole-image tiled kernel share a launch the same way -- one workgroup per face)
+                if (out2 && ((a.Arm_e && b.Arm_e && syn::launch_fused_pair_rm(L.feature, a, b, B, s)) ||
+                             (L.feature == 5 && a.We3 && b.We3 && B < 513 && syn::launch_fused_pair_f16(a, b, B, s)))) {
                     X = out2;                                   // (the rest of the region still holds any later block output: they only shrink)
                     li += 5;                                    // (two blocks: X -> Y -> out2)
                     mark(100 * L.feature + L.feature + 1);

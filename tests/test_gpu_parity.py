@@ -801,6 +801,42 @@ np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
 '''
 
 
+_VARIANT_SCRIPT_MULTI = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from synergynet_amd import synth
+from synergynet_amd.synergy3DMM import SynergyNet
+s_bb, s_3d = int(sys.argv[3]), int(sys.argv[4])
+m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(s_3d), backbone_state=synth.make_backbone_state(s_bb))
+out = {}
+for B in [int(b) for b in sys.argv[5].split(',')]:
+    out['p%d' % B] = m.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()).cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_small_batch_pair_launch_of_features_5_6_changes_no_bit(model, golden, tmp_path):
+    """Round 5: below 513 faces features.5 + 6 run on the whole-image tiled kernel, and up to 256 faces as ONE launch (fused_pair_f16_kernel: one
+    workgroup per face carries it through both blocks; SYN_F16_PAIR56=0: two launches).  A schedule change only: the SAME BITS, at one face,
+    a few, configs[1]'s 128, the last size the pair takes (256) and the first it does not (257)."""
+    import subprocess
+    import sys
+    import torch
+    from synergynet_amd import synth
+    if model._test_fusion != '2':
+        pytest.skip('the fp16 x2 tiled kernels belong to the default schedule')
+    sizes = [1, 5, 128, 256, 257]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'p.npz')
+    r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
+                       env=dict(os.environ, SYN_F16_PAIR56='0'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = np.load(out)
+    for B in sizes:
+        got = model.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()).cpu().numpy()
+        assert np.array_equal(want['p%d' % B], got), f'B={B}'
+
+
 @pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
                                    {'SYN_RM_PAIR56': '0'}, {'SYN_RM_PAIR34': '0'}],
                          ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
