@@ -448,6 +448,27 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
     return true;
 }
 
+// features.17 of a small batch: the slices only -- the tail's staging adds them (head_kernel.hip, SIN).  B < 513: the two-face tails.
+bool launch_lb4_sliced17_deferred(const FusedBlockArgs &a, int B, hipStream_t s, HeadSliced *out) {
+    static const bool on = !(getenv("SYN_HEAD_SLICED_IN") && atoi(getenv("SYN_HEAD_SLICED_IN")) == 0);
+    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;
+    if (!on || !out || !a.Glb || a.prof || !a.scratch || B >= wide_min || B >= 576) return false;
+    using C = Q17;
+    const int wg = (B + 3) / 4;
+    static const int divs[] = {2, 3, 5, 6, 10, 15, 30};
+    int S = 30;
+    for (int d : divs) if (wg * d >= 192) { S = d; break; }
+    // only with two or three slices (>= 253 faces): the tail's staging pays a round of loads per pair of slices -- landmarks-only step, deferred against
+    // the reduce launch (ms): B = 512 0.610 / 0.616, 256 0.3744 / 0.3773, 128 (six slices) 0.2837 / 0.2845, 64 0.2575 / 0.2567, 1 (thirty) 0.2167 / 0.2068
+    if (S > 3) return false;
+    if ((size_t)S * B * 16 * C::COUT > a.scratch_floats) return false;
+    Lb4StageArgs sa{a.X, a.Glb, a.p_shift, a.Y};
+    sa.part = a.scratch; sa.g0 = 0; sa.g1 = C::NG / S;
+    fused_block_lb4_kernel<C, true><<<dim3(wg, S), 512, 0, s>>>(sa, B);
+    *out = HeadSliced{a.scratch, S, reinterpret_cast<const float *>(a.Glb + C::WE_DW + C::WP_DW) + 11 * 32 + 1, a.p_shift};
+    return true;
+}
+
 static int lb4_min_batch() {
     constexpr int min_b = 576;     // fewer faces: hidden-sliced (B = 512: 123 us for the three blocks, 640: 209; the chain: 167 whatever the batch up to 1024)
     return min_b;

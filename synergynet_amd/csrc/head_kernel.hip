@@ -214,12 +214,15 @@ constexpr int kFcRounds = (kParam + 3) / 4;      // 16 rounds of 4 rows
 // chip with four faces per CU -- every workgroup streams the 1.6 MB of weight fragments from L2, so four faces per workgroup halve
 // that traffic (0.84 -> 0.42 GB per launch at B = 1024), and eight waves keep two per SIMD (four faces on FOUR waves measured
 // slower than two: 74 vs 65 us).  The per-output arithmetic is the same in every configuration.
-template <int NS, int NFK = NF, int NWV = 4>
+// SIN (round 5, small batches): the input tile is features.17's output as the S hidden-slice partial sums of fused_block_lb4.hip's sliced schedule; the
+// staging below adds them (slice 0 + 1 + ..., x 1 / (16 Sp), + BN shift: lb4_reduce_kernel's arithmetic and order, hence its bits) instead of a reduce
+// launch in front of this kernel.
+template <int NS, int NFK = NF, int NWV = 4, bool SIN = false>
 __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__restrict__ X /*[B,16,320]*/,
                                                           const unsigned *__restrict__ Wb3 /*[80][10][2][64][4] dwords, {S, 1/S}*/,
                                                           const float *__restrict__ shift, const float *__restrict__ Wfc,
                                                           const float *__restrict__ bfc, float *__restrict__ param,
-                                                          float *__restrict__ pool, int B) {
+                                                          float *__restrict__ pool, int B, HeadSliced hs = HeadSliced{nullptr, 0, nullptr, nullptr}) {
     constexpr int PXK = NFK * 16, PLANEK = PXK * XSD, NT = NWV * 64;
     __shared__ __attribute__((aligned(16))) unsigned Xb[2 * PLANEK];
     __shared__ __attribute__((aligned(16))) float Ps[NFK * N];
@@ -259,12 +262,41 @@ __global__ __launch_bounds__(NWV * 64) void head_f16x2_kernel(const float *__res
         constexpr int XI = PXK * (K / 4) / NT;
         static_assert(PXK * (K / 4) % NT == 0, "whole rounds");
         f32x4 xv[XI];
+        if constexpr (SIN) {
+            const size_t total = (size_t)B * 16 * K;                // floats per slice
+            size_t at[XI];
+#pragma unroll
+            for (int ii = 0; ii < XI; ++ii) {
+                const int it = tid + ii * NT, c4 = it % (K / 4), p = it / (K / 4);
+                int f = f0 + (p >> 4);
+                f = f < B ? f : B - 1;
+                at[ii] = ((size_t)f * 16 + (p & 15)) * K + 4 * c4;
+                xv[ii] = *(const f32x4 *)&hs.part[at[ii]];
+            }
+            for (int sl = 1; sl < hs.S; sl += 2) {                  // two slices (2 XI loads) in flight per round
+                const bool two = sl + 1 < hs.S;                     // (uniform)
+                f32x4 t0[XI], t1[XI];
+#pragma unroll
+                for (int ii = 0; ii < XI; ++ii) t0[ii] = *(const f32x4 *)&hs.part[(size_t)sl * total + at[ii]];
+#pragma unroll
+                for (int ii = 0; ii < XI; ++ii) t1[ii] = *(const f32x4 *)&hs.part[(size_t)(two ? sl + 1 : sl) * total + at[ii]];
+#pragma unroll
+                for (int ii = 0; ii < XI; ++ii) { xv[ii] += t0[ii]; if (two) xv[ii] += t1[ii]; }
+            }
+            const float inv_p = *hs.inv_p;
+#pragma unroll
+            for (int ii = 0; ii < XI; ++ii) {
+                const int c4 = (tid + ii * NT) % (K / 4);
+                xv[ii] = xv[ii] * inv_p + *(const f32x4 *)&hs.p_shift[4 * c4];
+            }
+        } else {
 #pragma unroll
         for (int ii = 0; ii < XI; ++ii) {
             const int it = tid + ii * NT, c4 = it % (K / 4), p = it / (K / 4);
             int f = f0 + (p >> 4);
             f = f < B ? f : B - 1;
             xv[ii] = *(const f32x4 *)&X[((size_t)f * 16 + (p & 15)) * K + 4 * c4];
+        }
         }
 #pragma unroll
         for (int ii = 0; ii < XI; ++ii) asm volatile("" : "+v"(xv[ii]));        // (keeps the loads from being sunk to their uses)
@@ -375,12 +407,17 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float *__restrict__ 
 
 // `scratch` ([B,1280] floats) receives the pooled vectors of the sliced schedule when the caller did not ask for them
 void launch_head_f16x2(const float *X, const unsigned *Wb3, const float *shift, const float *Wfc, const float *bfc,
-                        float *param, float *pool, float *scratch, int B, hipStream_t s) {
+                        float *param, float *pool, float *scratch, int B, hipStream_t s, const HeadSliced *sin) {
     const int grid = (B + NF - 1) / NF;
     if (grid <= 96) {                                      // few faces: spread the 1.6 MB of weights over 5 workgroups per face pair
         float *pl = pool ? pool : scratch;
-        head_f16x2_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
+        if (sin) head_f16x2_kernel<5, NF, 4, true><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B, *sin);
+        else head_f16x2_kernel<5><<<dim3(grid, 5), 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pl, B);
         head_fc_kernel<<<dim3(grid, kFcSlices), 256, 0, s>>>(pl, Wfc, bfc, param, B);
+        return;
+    }
+    if (sin) {                                             // (the caller defers the reduce only below the wide tail's threshold)
+        head_f16x2_kernel<1, NF, 4, true><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B, *sin);
         return;
     }
     static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;       // (B = 640 / 768 / 896: 60 / 62 / 61 -> 47 / 48 / 48 us; B = 512: the two-face workgroups, 49 us)

@@ -146,8 +146,19 @@ void launch_head(const float *X, const float *Wpk /*[80][20][64][4]*/, const flo
                  hipStream_t s);
 
 // same tail with the GEMM on the bf16 matrix pipe via an exact 3-way bf16 split of fp32 operands (head_kernel.hip)
+// features.17's output still as the hidden-slice partial sums of the small-batch schedule (fused_block_lb4.hip): the tail adds them while it
+// stages its input tile -- lb4_reduce_kernel's arithmetic and order -- instead of a reduce launch in front of it (round 5, batches below 513 faces)
+struct HeadSliced {
+    const float *part;       // [S][B][16][320] raw accumulators
+    int S;
+    const float *inv_p;      // accumulator -> output scale (one float, device)
+    const float *p_shift;    // [320] BN shift of features.17's projection
+};
 void launch_head_f16x2(const float *X, const unsigned *Wb3 /*[80][10][3][64][4]*/, const float *shift, const float *Wfc,
-                        const float *bfc, float *param, float *pool, float *scratch /*[B,1280]*/, int B, hipStream_t s);
+                        const float *bfc, float *param, float *pool, float *scratch /*[B,1280]*/, int B, hipStream_t s,
+                       const HeadSliced *sliced_in = nullptr);
+// features.17 hidden-sliced WITHOUT its reduce launch: fills `out` for launch_head_f16x2; false: not applicable (run the block as usual)
+bool launch_lb4_sliced17_deferred(const FusedBlockArgs &a, int B, hipStream_t s, HeadSliced *out);
 
 // ---- on-device crop + Lanczos-4 resize (preproc_kernels.hip) ----
 void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, const int *xofs, const short *xcoef,

@@ -468,6 +468,8 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     // load-time range verdict (analyze_mbv2_ranges): bit f set -> .features[f] must not run an fp16 x2 kernel with input scale 1 / 16
     const unsigned u1 = h->range_guard ? h->ri.unsafe1 : 0u, u16 = h->range_guard ? (h->ri.unsafe16 | h->ri.unsafe1) : 0u;
     auto any_unsafe16 = [&](int first, int last) { for (int f = first; f <= last; ++f) if ((u16 >> f) & 1u) return true; return false; };
+    syn::HeadSliced head_sliced{nullptr, 0, nullptr, nullptr};     // features.17 left as hidden-slice partial sums for the tail to add (small batches)
+    bool have_head_sliced = false;
     auto mark = [&](int feature) {          // profiling hook: one event after every launch
         if (!marks) return;
         hipEvent_t e;
@@ -623,6 +625,15 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                     continue;
                 }
             }
+            // features.17 of a small batch: only the hidden slices; the tail adds them while staging its input (no reduce launch).  Taken when the
+            // fp16 x2 tail is what follows and nobody asked for features.17's tensor itself
+            if (L.feature == 17 && a.Glb && stop_feature < 0 && prof_feature < 0 && !((u1 >> 18) & 1u) && syn::launch_lb4_sliced17_deferred(a, B, s, &head_sliced)) {
+                have_head_sliced = true;
+                float *t = X; X = Y; Y = t;
+                li += 2;
+                mark(L.feature);
+                continue;
+            }
             if ((a.Arm_e && syn::launch_fused_block_rm(L.feature, a, B, s)) ||
                 (a.Alb_p && syn::launch_fused_block_lb(L.feature, a, B, s)) ||
                 (a.Glb && syn::launch_fused_block_lb4(L.feature, a, B, s)) ||
@@ -647,7 +658,7 @@ int run_backbone(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
             syn::launch_depthwise(has_expand ? H1 : X, w, sc, sh, H2, B, L.hin, L.hout, L.cout, L.stride, s);
         } else if (L.feature == 18 && h->fusion >= 2 && !((u1 >> 18) & 1u) && stop_feature != 18) {
             syn::launch_head_f16x2(X, reinterpret_cast<const unsigned *>(P + n.dst_head_f16), sh, P + n.dst_fc_w, P + n.dst_fc_b,
-                                    param, pool, H1, B, s);
+                                    param, pool, H1, B, s, have_head_sliced ? &head_sliced : nullptr);
             mark(19);
             HIP_TRY(hipGetLastError());
             return SYN_OK;

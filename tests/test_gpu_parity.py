@@ -815,25 +815,29 @@ np.savez(sys.argv[2], **out)
 '''
 
 
-def test_small_batch_pair_launch_of_features_5_6_changes_no_bit(model, golden, tmp_path):
-    """Round 5: below 513 faces features.5 + 6 run on the whole-image tiled kernel, and up to 256 faces as ONE launch (fused_pair_f16_kernel: one
-    workgroup per face carries it through both blocks; SYN_F16_PAIR56=0: two launches).  A schedule change only: the SAME BITS, at one face,
-    a few, configs[1]'s 128, the last size the pair takes (256) and the first it does not (257)."""
+@pytest.mark.parametrize('knob', ['SYN_F16_PAIR56', 'SYN_HEAD_SLICED_IN'])
+def test_small_batch_launch_fusions_change_no_bit(model, golden, tmp_path, knob):
+    """Round 5, batches below 513 faces: (a) features.5 + 6 run on the whole-image tiled kernel, up to 256 faces as ONE launch (fused_pair_f16_kernel:
+    one workgroup per face carries it through both blocks; SYN_F16_PAIR56=0: two launches); (b) features.17's hidden-slice partial sums are added by
+    the tail while it stages its input tile (head_f16x2_kernel SIN: lb4_reduce_kernel's arithmetic and order) instead of by a reduce launch in front
+    of it (SYN_HEAD_SLICED_IN=0; taken with two or three slices, i.e. from 253 faces).  Schedule changes only: the SAME BITS, at one face, a few, configs[1]'s 128, around the pair's limit (256 / 257),
+    at the last batch the sliced tail input takes (512) and the first it does not (513)."""
     import subprocess
     import sys
     import torch
     from synergynet_amd import synth
     if model._test_fusion != '2':
-        pytest.skip('the fp16 x2 tiled kernels belong to the default schedule')
-    sizes = [1, 5, 128, 256, 257]
+        pytest.skip('the fp16 x2 kernels belong to the default schedule')
+    sizes = [1, 5, 128, 252, 253, 256, 257, 300, 512, 513]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / 'p.npz')
     r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
-                       env=dict(os.environ, SYN_F16_PAIR56='0'), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, **{knob: '0'}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     want = np.load(out)
     for B in sizes:
         got = model.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()).cpu().numpy()
+        assert np.isfinite(got).all()
         assert np.array_equal(want['p%d' % B], got), f'B={B}'
 
 
