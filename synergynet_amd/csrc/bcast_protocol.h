@@ -16,7 +16,9 @@
 //   all:       return agree(local code)                                             -- collective 4: every rank returns the same verdict
 //
 // `Ops` supplies the pieces: int rank(); bool loaded(); uint64 bytes(); void *alloc(uint64) (nullptr on failure); void release(void *);
-// int export_to(void *, uint64); int import_from(void *, uint64); int broadcast(void *buf, uint64 bytes, int root) (transport error -> != 0);
+// int export_to(void *, uint64); int import_from(void *, uint64); int broadcast_word(BcastWord *host_word, int root) (the 16-byte size word, which
+// lives in HOST memory) and int broadcast(void *blob, uint64 bytes, int root) (the blob, in whatever memory alloc() returns) -- two calls, so
+// that no transport has to guess from a byte count which kind of pointer it was handed; transport error -> != 0;
 // int agree(int code) (the most severe = most negative code over all ranks; a transport without a reduction returns `code` unchanged).
 #pragma once
 #include <cstdint>
@@ -28,7 +30,7 @@ struct BcastWord {
     int64_t code;           // the root's error code when size == 0
 };
 
-constexpr uint64_t kBcastMinBytes = 64, kBcastMaxBytes = 1ull << 34;
+constexpr uint64_t kBcastMinBytes = 256 /* = sizeof(ConstHeader): no blob is smaller than its header */, kBcastMaxBytes = 1ull << 34;
 
 // returns 0 or the (negative) error code EVERY rank of the communicator returns; *stage_out: the rank's copy of the blob (caller releases)
 template <class Ops>
@@ -46,7 +48,7 @@ int bcast_constants_protocol(Ops &ops, int root, int err_not_loaded, int err_all
             else if (int rc = ops.export_to(stage, w.size)) { w.size = 0; w.code = rc; *where = "export on the root"; }
         }
     }
-    if (ops.broadcast(&w, sizeof w, root)) {                      // collective 1 (a transport error is the communicator's: nothing to agree on)
+    if (ops.broadcast_word(&w, root)) {                      // collective 1 (a transport error is the communicator's: nothing to agree on)
         if (stage) ops.release(stage);
         *where = "broadcast of the size word";
         return err_transport;

@@ -222,7 +222,10 @@ __device__ __forceinline__ void rm_block(unsigned *smem, const float *__restrict
         for (int i = tid; i < C::APL_DW / 4; i += NT) *(u32x4 *)&ApL[4 * i] = *(const u32x4 *)&Ap3[4 * i];
 
     __syncthreads();
-    asm volatile("" :: "v"(early_sink));                // (the touches have returned: the barrier's wait covers every older load)
+    // the touches are inline assembly the compiler's wait-count bookkeeping does not know, and a barrier alone drains nothing: wait for them
+    // explicitly before early_sink's register may be reused (service waves that stage no constants issue no tracked load a
+    // compiler wait would cover).  By now they have long returned; the compute waves' fragment loads are consumed right behind anyway.
+    l2_touch_done(early_sink);
 
     if (service) {
         // The service waves are the youngest of their SIMD and would be served last by the issue arbiter, yet every compute wave

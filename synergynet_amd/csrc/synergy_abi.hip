@@ -1789,10 +1789,11 @@ int syn_check_constants_host(const void *host_blob, size_t bytes) {
 namespace {
 struct RcclApi {
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclBroadcast
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclAllReduce (optional: the agreement steps)
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;       // ncclAllReduce (the agreement steps: required, a rank without it would diverge)
     int (*CommUserRank)(void *, int *) = nullptr;                                                 // ncclCommUserRank
     const char *(*GetErrorString)(int) = nullptr;                                                 // ncclGetErrorString
     bool ok = false;
+    bool explicit_failed = false;                                                                  // SYNERGY_HIP_RCCL_LIB was set and that instance is unusable
 };
 // SYNERGY_HIP_RCCL_LIB: the path of the RCCL instance that owns the caller's communicator, for a process that holds more than one
 // (ADVICE r4); default: what the process already holds -- global scope, librccl.so.1 as loaded by the caller or by torch
@@ -1805,13 +1806,15 @@ const RcclApi &rccl_api() {
                           dlopen("librccl.so", RTLD_LAZY | RTLD_NOLOAD), nullptr};
         for (int i = (own && *own) ? 0 : 1; i < 5 && !a.ok; ++i) {
             void *lib = i < 4 ? cands[i] : dlopen("librccl.so.1", RTLD_LAZY | RTLD_GLOBAL);
+            // an explicit instance is never silently replaced by another one: if it does not load, or lacks an entry point, there is no RCCL
+            if (i == 0 && !lib) { a.explicit_failed = true; break; }
             if (i != 1 && !lib) continue;
             a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(lib, "ncclBroadcast"));
             a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
             a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
             a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-            a.ok = a.Broadcast && a.CommUserRank && a.GetErrorString;
-            if (own && *own && i == 0) break;            // an explicit instance is not silently replaced by another one
+            a.ok = a.Broadcast && a.AllReduce && a.CommUserRank && a.GetErrorString;
+            if (i == 0) { a.explicit_failed = !a.ok; break; }
         }
         return a;
     }();
@@ -1830,20 +1833,26 @@ struct RcclBcastOps {
     void release(void *p) { (void)hipFree(p); }
     int export_to(void *p, uint64_t n) { return syn_export_constants(h, p, n, s); }
     int import_from(void *p, uint64_t n) { return syn_import_constants(h, p, n, s); }
-    int broadcast(void *buf, uint64_t n, int root) {
-        const bool small = n <= 64;                      // the size word lives on the host: staged through word_dev
-        void *dev = small ? (void *)word_dev : buf;
-        if (small && (hipMemcpyAsync(dev, buf, n, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) { transport_error = "staging a word"; return 1; }
-        if (int e = R.Broadcast(dev, dev, n, 1 /*ncclUint8*/, root, comm, s)) { transport_error = R.GetErrorString(e); return 1; }
-        if (small && (hipMemcpyAsync(buf, dev, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) { transport_error = "reading a word back"; return 1; }
+    int broadcast_word(syn::BcastWord *w, int root) {    // the size word lives on the HOST: staged through word_dev
+        static_assert(sizeof(syn::BcastWord) <= 64, "the word is staged through the first 64 bytes of word_dev");
+        if (hipMemcpyAsync(word_dev, w, sizeof *w, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { transport_error = "staging a word"; return 1; }
+        if (int e = R.Broadcast(word_dev, word_dev, sizeof *w, 1 /*ncclUint8*/, root, comm, s)) { transport_error = R.GetErrorString(e); return 1; }
+        if (hipMemcpyAsync(w, word_dev, sizeof *w, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { transport_error = "reading a word back"; return 1; }
+        return 0;
+    }
+    int broadcast(void *buf, uint64_t n, int root) {     // the blob: device memory of alloc(), whatever its size
+        if (int e = R.Broadcast(buf, buf, n, 1 /*ncclUint8*/, root, comm, s)) { transport_error = R.GetErrorString(e); return 1; }
         return 0;
     }
     int agree(int code) {                                // the most severe (most negative) code of all ranks; codes are <= 0
-        if (!R.AllReduce) return code;                   // (an RCCL without ncclAllReduce does not exist; a stub in a test may leave it out)
+        // every rank ENTERS the all-reduce whatever happened to its own staging copy (a rank that returned here would hang the others);
+        // a rank whose copy failed contributes whatever the word holds and returns at least SYN_ERR_HIP itself
         int v = -code;
-        if (hipMemcpyAsync(word_dev + 8, &v, sizeof v, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return code ? code : SYN_ERR_HIP;
+        const bool staged = hipMemcpyAsync(word_dev + 8, &v, sizeof v, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        if (!staged && !code) code = SYN_ERR_HIP;        // (what sits in the word is then stale: the rank's own verdict is at least this error)
         if (int e = R.AllReduce(word_dev + 8, word_dev + 8, 1, 2 /*ncclInt32*/, 2 /*ncclMax*/, comm, s)) { transport_error = R.GetErrorString(e); return code ? code : SYN_ERR_HIP; }
         if (hipMemcpyAsync(&v, word_dev + 8, sizeof v, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return code ? code : SYN_ERR_HIP;
+        if (!staged) return code;
         return -v;
     }
 };
@@ -1858,6 +1867,7 @@ int syn_bcast_constants(syn_handle *h, void *nccl_comm, int root, void *stream) 
     if (!nccl_comm) return fail(SYN_ERR_INVALID, "syn_bcast_constants: NULL communicator");
     if (root < 0) return fail(SYN_ERR_INVALID, "syn_bcast_constants: root %d", root);
     const RcclApi &R = rccl_api();
+    if (R.explicit_failed) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: SYNERGY_HIP_RCCL_LIB=%s cannot be loaded or lacks ncclBroadcast / ncclAllReduce / ncclCommUserRank / ncclGetErrorString (no other RCCL instance is tried in its place)", getenv("SYNERGY_HIP_RCCL_LIB"));
     if (!R.ok) return fail(SYN_ERR_NOT_LOADED, "syn_bcast_constants: no RCCL in this process (ncclBroadcast / ncclCommUserRank not found, librccl.so.1 not loadable; SYNERGY_HIP_RCCL_LIB names an instance explicitly)");
     DeviceGuard g(h->device);
     int rank = -1;

@@ -522,8 +522,13 @@ class SynergyNet(nn.Module):
         with torch.cuda.device(self.device):
             if out is None:
                 out = torch.empty((B, 3, n), dtype=torch.float32, device=self.device)
-            if tuple(out.shape) != (B, 3, n) or out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous():
-                raise RuntimeError(f'out must be a contiguous float32 [B,3,{n}] tensor on {self.device}')
+            if tuple(out.shape) != (B, 3, n) or out.dtype != torch.float32 or out.device != self.device:
+                raise RuntimeError(f'out must be a float32 [B,3,{n}] tensor on {self.device}')
+            if not out.is_contiguous():
+                # the one-launch kernel writes packed rows only; an equally pitched / sliced view (which `reconstruct` has always taken) goes
+                # through the two calls it replaces -- same landmarks to fp32 rounding, same pose (do not narrow the API silently)
+                self.reconstruct(p, roi=r, dense=False, transform=transform, out=out)
+                return out, self.predict_pose_batch(p, roi=r)
             ang = torch.empty((B, 3), dtype=torch.float64, device=self.device)
             t3d = torch.empty((B, 3), dtype=torch.float32, device=self.device)
             abi.check(self._lib.syn_landmarks_pose(self._h, p.data_ptr(), B, 62, int(transform), r.data_ptr() if r is not None else None,

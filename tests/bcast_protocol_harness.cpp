@@ -71,6 +71,7 @@ struct FakeOps {
         imported = true;
         return 0;
     }
+    int broadcast_word(syn::BcastWord *w, int r) { return t.broadcast(w, sizeof *w, my_rank == r); }
     int broadcast(void *buf, uint64_t n, int r) { return buf ? t.broadcast(buf, n, my_rank == r) : (t.broadcast(nullptr, 0, false), 1); }
     int agree(int code) {
         if (!has_allreduce) return code;

@@ -789,18 +789,6 @@ def test_device_crop_resize_is_bit_identical_to_host_restatement(model):
     assert rel_max(want, model.reconstruct(p, roi=np.asarray(rois, np.float32), dense=False).cpu().numpy()) < 1e-5
 
 
-_VARIANT_SCRIPT = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from synergynet_amd import synth
-from synergynet_amd.synergy3DMM import SynergyNet
-B, s_bb, s_3d = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(s_3d), backbone_state=synth.make_backbone_state(s_bb))
-crops = torch.from_numpy(synth.make_crops(B, seed=4242)).cuda()
-np.save(sys.argv[2], m.forward_crops_u8(crops).cpu().numpy())
-'''
-
-
 _VARIANT_SCRIPT_MULTI = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
@@ -841,10 +829,15 @@ def test_small_batch_launch_fusions_change_no_bit(model, golden, tmp_path, knob)
         assert np.array_equal(want['p%d' % B], got), f'B={B}'
 
 
-@pytest.mark.parametrize('knobs', [{'SYN_LB_CHAIN': '0'}, {'SYN_LB_CHAIN': '1'}, {'SYN_LB_CHAIN': '2'}, {'SYN_LB4_CHAIN': '0'}, {'SYN_HEAD_WIDE_MIN': '1000000'},
-                                   {'SYN_RM_PAIR56': '0'}, {'SYN_RM_PAIR34': '0'}],
-                         ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()))
-def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs):
+# (knobs, batch sizes at which the knob's kernel is actually TAKEN by the default process).  features.3 + 4 share a launch only for one round of
+# workgroups, 513 <= B <= 1024 (fused_block_rm.hip launch_fused_pair_rm): at 1030 both processes would launch the blocks one by one and the
+# comparison would test nothing, so that knob runs at both ends of its window.
+_KNOB_CASES = [({'SYN_LB_CHAIN': '0'}, (1030,)), ({'SYN_LB_CHAIN': '1'}, (1030,)), ({'SYN_LB_CHAIN': '2'}, (1030,)), ({'SYN_LB4_CHAIN': '0'}, (1030,)),
+               ({'SYN_HEAD_WIDE_MIN': '1000000'}, (1030,)), ({'SYN_RM_PAIR56': '0'}, (513, 1030)), ({'SYN_RM_PAIR34': '0'}, (513, 1024))]
+
+
+@pytest.mark.parametrize('knobs,sizes', _KNOB_CASES, ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()) if isinstance(k, dict) else 'B' + '_'.join(map(str, k)))
+def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, knobs, sizes):
     """features.7-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
     the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
     faces per workgroup (head_kernel.hip); round 5: features.5 + 6 and features.3 + 4 share one launch of the row-marching kernel each
@@ -857,12 +850,14 @@ def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, kno
     from synergynet_amd import synth
     if model._test_fusion != '2':
         pytest.skip('the chains belong to the default schedule')
-    B = 1030
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / 'p.npy')
+    out = str(tmp_path / 'p.npz')
     env = dict(os.environ, **knobs)
-    r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT, root, out, str(B), str(int(golden['seeds'][0])), str(int(golden['seeds'][1]))],
+    r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    got = model.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4242)).cuda()).cpu().numpy()
-    assert np.array_equal(np.load(out), got)
+    want = np.load(out)
+    for B in sizes:
+        got = model.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=4300 + B)).cuda()).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.array_equal(want['p%d' % B], got), f'B={B}'

@@ -319,10 +319,14 @@ def test_hot_loops_never_drain_their_loads_in_flight():
         import isa_scan
     finally:
         sys.path.pop(0)
-    checks = [('resnet_kernels.hip', ['conv_lt_kernel<4>', 'conv_lt_kernel<2>'], 48), ('head_kernel.hip', ['head_f16x2_kernel<1, 4, 8>'], 100)]
+    # kernels are matched by PREFIX of the demangled name (a new trailing template parameter must not blind the guard: round 5 ended red
+    # on exactly that), and "kernel not found" is reported apart from "loop drains"
+    checks = [('resnet_kernels.hip', ['conv_lt_kernel<4', 'conv_lt_kernel<2'], 48), ('head_kernel.hip', ['head_f16x2_kernel<1, 4, 8'], 100)]
     for src, kernels, min_mfma in checks:
         loops = isa_scan.loop_sequences(isa_scan.compile_to_asm(src), kernels)
-        assert len(loops) == len(kernels), (src, list(loops))
+        for k in kernels:
+            assert any(name.startswith('syn::' + k) or name.startswith('void syn::' + k) or k in name for name in loops), \
+                f'{src}: no kernel whose name starts with {k!r} in the ISA (renamed? the guard must follow it): found {sorted(loops)}'
         for name, ls in loops.items():
             main = [l for l in ls if l[2] >= min_mfma]
             assert main, f'{name}: no steady-state loop found'
