@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // act: 0 none, 1 ReLU (applied AFTER the residual add: out = relu(bn3(conv3) + identity), resnet_backbone.py:130-134).
 // =====================================================================================
 // Run-time range guard of the fp16 x2 convolutions (ReLU networks have no static activation bound: synergy_abi.hip run_resnet50):
-// every kernel whose output a later convolution splits into fp16 pieces folds max |output| into the status array of the forward --
+// every kernel whose output a later convolution takes as fp16 pieces folds max |output| into the status array of the forward --
 // one v_max per output element, one wave reduction and ONE fire-and-forget atomic per wave.  Non-negative floats order like their
 // bit patterns, so the atomic is an unsigned max.  Tens of thousands of waves report per launch, and device-scope atomics on ONE
 // address serialise in that address's memory-side channel (measured: +100 us per convolution, ResNet-50 8.3 -> 13.7 ms; filtering
@@ -36,12 +36,149 @@ __device__ __forceinline__ void range_note(float *stat, float m) {
         atomicMax(reinterpret_cast<unsigned *>(stat + (size_t)(blockIdx.x % kRangeSub) * kRangeStride), __builtin_bit_cast(unsigned, m));
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// =====================================================================================
+// The PAIR activation format (round 6).  An fp16 x2 convolution takes every operand as two fp16 pieces, x = hi + lo with
+// hi = rtz_f16(x), lo = rtz_f16(x - hi) (22 significant bits, fused_block_f16.hip).  Rounds 2-5 kept the activations between the
+// convolutions in fp32 and every CONSUMER split them -- a third of the vector instructions of the LDS-tiled GEMM's loop, repeated by every
+// workgroup along the output-channel axis.  Now the PRODUCER's epilogue splits once and stores the pieces in the order the consumers'
+// matrix instructions take them:
+//   tensor [M pixels][C channels], C % 32 == 0: per pixel and 32-channel chunk kc 128 bytes = 32 high halves (64 B) | 32 low halves (64 B);
+//   the B operand of v_mfma_f32_16x16x32_f16 for (pixel r, k-group g) of chunk kc is the 16 bytes at dword m C + 32 kc + 4 g, its low
+//   piece the 16 bytes 16 dwords further.  The same 4 bytes per element as fp32, the same bits in the GEMM as the consumer-side split
+//   (it is deterministic); what changes numerically is the identity branch of a bottleneck, which now adds hi + lo (|x - (hi + lo)| <=
+//   2^-22 |x|) instead of x.
+// So that a lane's accumulators ARE whole 16-byte pieces, the output channels of a 32-channel block sit on the MFMA rows in PAIR ORDER:
+//   row rho of tile 2 b + ip  <->  channel 32 b + 8 (rho >> 2) + 4 ip + (rho & 3)   (weights packed so by synergy_abi.hip), i.e. lane group
+//   g holds channels 32 b + 8 g + 0..3 in tile 2 b and + 4..7 in tile 2 b + 1: eight consecutive channels = k-group g of chunk b.
+// Tensors no convolution consumes (the downsample branch, the last block's output) stay fp32; every epilogue takes the two formats
+// (kOutPair / kResPair).  The exact fp32-MFMA convolution (conv_kernel: fp32 handles, weight-unsafe convolutions) reads and writes
+// pairs too when it runs inside an fp16 x2 forward.
+// =====================================================================================
+constexpr int kOutPair = kFmtOutPair, kResPair = kFmtResPair;
+
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (&pc)[2]) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
+        const float x0 = x[2 * d], x1 = x[2 * d + 1];
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+        pc[0][d] = a;
+        pc[1][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    }
+}
+// four values -> their high and low fp16 pieces (two packed dwords each), the same arithmetic as split8
+__device__ __forceinline__ void split4(const f32x4 &x, u32x2 &hi, u32x2 &lo) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float x0 = x[2 * d], x1 = x[2 * d + 1];
+        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+        hi[d] = a;
+        lo[d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+    }
+}
+// eight values back from their pieces: hi + lo is exact in fp32 (at most 22 significant bits)
+__device__ __forceinline__ void unpair8(const u32x4 &hi, const u32x4 &lo, f32x4 &v0, f32x4 &v1) {
+    const f16x8 h = __builtin_bit_cast(f16x8, hi), l = __builtin_bit_cast(f16x8, lo);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { v0[t] = (float)h[t] + (float)l[t]; v1[t] = (float)h[4 + t] + (float)l[4 + t]; }
+}
+__device__ __forceinline__ f32x4 unpair4(const u32x2 &hi, const u32x2 &lo) {
+    // (scalars first: __builtin_bit_cast of a vector ELEMENT expression copies from the vector's address -- element 0 whatever the index)
+    const unsigned hu0 = hi[0], hu1 = hi[1], lu0 = lo[0], lu1 = lo[1];
+    const f16x2 h0 = __builtin_bit_cast(f16x2, hu0), h1 = __builtin_bit_cast(f16x2, hu1);
+    const f16x2 l0 = __builtin_bit_cast(f16x2, lu0), l1 = __builtin_bit_cast(f16x2, lu1);
+    return f32x4{(float)h0[0] + (float)l0[0], (float)h0[1] + (float)l0[1], (float)h1[0] + (float)l1[0], (float)h1[1] + (float)l1[1]};
+}
+
+// The epilogue every convolution kernel of this file ends with: acc[j][i] = tile i (pair order) of the lane's pixel mbase + 16 j + r16, the
+// wave's channels nbase .. nbase + 16 NT - 1 (nbase % 32 == 0, NT even, N % 32 == 0).  out = act(acc x scale x inv_s + shift (+ residual)).
+// In three passes: every load (BN scale / shift, residual) first and branch-free (rows clamped into the matrix), then the arithmetic, then
+// the stores.  Interleaved, each residual load sat between two stores and its wait (vmcnt is in order, and conservative around an `if`)
+// covered the previous store's acknowledgement: 8 serialised round trips per tile.
+// A (pixel, tile) register quad is 16 bytes in either format: fp32 = channels 8 g + 4 ip + 0..3 of the block, pair = the lane's eight
+// channels' high (ip = 0) or low (ip = 1) halves -- one 16-byte access per quad, at a format-dependent dword offset.
 template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MT][NT], const float *__restrict__ scale, const float *__restrict__ shift, float inv_s,
+                                              const float *__restrict__ residual, float *__restrict__ out, int M, int N, int mbase, int nbase,
+                                              int r16, int g, int act, int fmt, float *__restrict__ stat) {
+    static_assert(NT % 2 == 0, "tile pairs");
+    const bool out_pair = fmt & kOutPair, res_pair = fmt & kResPair;
+    f32x4 scv[NT], shv[NT];
+    u32x4 rraw[MT][NT];
+    int qo_res[NT], qo_out[NT];                          // dword offset of quad i inside a pixel row
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int b32 = nbase + 32 * (i >> 1), ip = i & 1;
+        qo_res[i] = b32 + (res_pair ? 4 * g + 16 * ip : 8 * g + 4 * ip);
+        qo_out[i] = b32 + (out_pair ? 4 * g + 16 * ip : 8 * g + 4 * ip);
+        const int n = b32 + 8 * g + 4 * ip;
+        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
+        shv[i] = *(const f32x4 *)&shift[n];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            int m = mbase + j * 16 + r16;
+            m = m < M ? m : 0;
+            if (residual) rraw[j][i] = *(const u32x4 *)&residual[(size_t)m * N + qo_res[i]];     // (kernel-uniform condition)
+        }
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int p = 0; p < NT / 2; ++p)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            f32x4 v0 = acc[j][2 * p] * scv[2 * p] + shv[2 * p], v1 = acc[j][2 * p + 1] * scv[2 * p + 1] + shv[2 * p + 1];
+            if (residual) {
+                f32x4 r0, r1;
+                if (res_pair) unpair8(rraw[j][2 * p], rraw[j][2 * p + 1], r0, r1);
+                else { r0 = __builtin_bit_cast(f32x4, rraw[j][2 * p]); r1 = __builtin_bit_cast(f32x4, rraw[j][2 * p + 1]); }
+                v0 += r0; v1 += r1;
+            }
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { v0[t] = fmaxf(v0[t], 0.0f); v1[t] = fmaxf(v1[t], 0.0f); }
+            }
+            if (stat && mbase + j * 16 + r16 < M)
+                vmax = fmaxf(vmax, fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+                                         fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3])))));
+            if (out_pair) {
+                u32x4 pc[2];
+                split8(v0, v1, pc);
+                acc[j][2 * p] = __builtin_bit_cast(f32x4, pc[0]);
+                acc[j][2 * p + 1] = __builtin_bit_cast(f32x4, pc[1]);
+            } else { acc[j][2 * p] = v0; acc[j][2 * p + 1] = v1; }
+            asm volatile("" : "+v"(acc[j][2 * p]), "+v"(acc[j][2 * p + 1]));         // (keeps the arithmetic from being sunk into the store's branch)
+        }
+    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = mbase + j * 16 + r16;
+            if (m >= M) continue;
+            *(f32x4 *)&out[(size_t)m * N + qo_out[i]] = acc[j][i];
+        }
+}
+
+// PAIR: the convolution runs inside an fp16 x2 forward -- its input is in the pair format (a lane rebuilds its four fp32 channels from two
+// 8-byte pieces), its weight rows are taken in pair order and the epilogue writes what `fmt` says.  !PAIR: fp32 in and out (an fp32 handle).
+template <int MT, int NT, bool PAIR>
 __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in, const float *__restrict__ W,
                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                    const float *__restrict__ residual, float *__restrict__ out, int M,
                                                    int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                   int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
+                                                   int act, int n_tiles, int m_tiles, float *__restrict__ stat, int fmt) {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int nt_idx = q % n_tiles;
     const int mt_idx = (q / n_tiles) * 8 + xcd;           // all channel tiles of one pixel tile share an XCD's L2
@@ -67,7 +204,11 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
     }
     const float *wp[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) wp[i] = W + (size_t)(n0 + i * 16 + r16) * K + 4 * g;     // W rows are padded to Npad
+    for (int i = 0; i < NT; ++i) {
+        // MFMA row r16 of tile i: the channel in pair order (the epilogue's layout), W rows themselves are in natural order
+        const int ch = n0 + 32 * (i >> 1) + 8 * (r16 >> 2) + 4 * (i & 1) + (r16 & 3);
+        wp[i] = W + (size_t)ch * K + 4 * g;
+    }
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
@@ -83,8 +224,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
         for (int j = 0; j < MT; ++j) {
             const int iy = py[j] + ky, ix = px[j] + kx;
             const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
-            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 16 + 4 * g;
-            const f32x4 v = *(const f32x4 *)p;
+            const float *pp = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin;
+            f32x4 v;
+            if (PAIR) {   // channels 16 kc + 4 g + 0..3: chunk kc >> 1, halves 16 (kc & 1) + 4 g ... = dwords 8 (kc & 1) + 2 g, low piece 16 dwords on
+                const float *q2 = pp + 32 * (kc >> 1) + 8 * (kc & 1) + 2 * g;
+                v = unpair4(*(const u32x2 *)q2, *(const u32x2 *)(q2 + 16));
+            } else v = *(const f32x4 *)(pp + kc * 16 + 4 * g);
             af[j] = ok ? v : z4;
         }
     };
@@ -104,99 +249,44 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in,
 #pragma unroll
         for (int j = 0; j < MT; ++j) af[j] = an[j];
     }
-    float vmax = 0.f;                                     // range guard: a later fp16 x2 convolution may split this output
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int n = n0 + i * 16 + 4 * g;
-        if (n >= N) continue;
-        const f32x4 sc = *(const f32x4 *)&scale[n];
-        const f32x4 sh = *(const f32x4 *)&shift[n];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m0 + j * 16 + r16;
-            if (m >= M) continue;
-            f32x4 v = acc[j][i] * sc + sh;
-            if (residual) v += *(const f32x4 *)&residual[(size_t)m * N + n];
-            if (act) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) vmax = fmaxf(vmax, fabsf(v[t]));
-            *(f32x4 *)&out[(size_t)m * N + n] = v;
-        }
-    }
-    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition; the early returns above are wave-uniform)
+    conv_epilogue<MT, NT>(acc, scale, shift, 1.0f, residual, out, M, N, m0, n0, r16, g, act, fmt, stat);
 }
 
 template <int MT, int NT>
 static void launch_conv_t(const float *in, const float *W, const float *scale, const float *shift, const float *residual,
                           float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                          int act, hipStream_t s, float *stat) {
-    const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
+                          int act, hipStream_t s, float *stat, int in_pair, int fmt) {
+    const int n_tiles = N / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
-    conv_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                             act, n_tiles, m_tiles, stat);
+    if (in_pair) conv_kernel<MT, NT, true><<<grid, 256, 0, s>>>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, fmt);
+    else conv_kernel<MT, NT, false><<<grid, 256, 0, s>>>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, fmt);
 }
 
+// in_pair: the input is in the pair format (Cin % 32 == 0); fmt: kOutPair | kResPair.  Every ResNet-50 Cout is a multiple of 64 (required).
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
-                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s, float *stat) {
+                 int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s, float *stat, int in_pair, int fmt) {
     const int M = B * Hout * Hout;
-    const long tiles64 = ((long)M + 255) / 256 * ((N + 63) / 64);      // every ResNet-50 Cout is a multiple of 64
-    if (tiles64 >= 2048) launch_conv_t<4, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-    else if (tiles64 >= 512) launch_conv_t<2, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-    else launch_conv_t<1, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    const long tiles64 = ((long)M + 255) / 256 * (N / 64);
+    if (tiles64 >= 2048) launch_conv_t<4, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, in_pair, fmt);
+    else if (tiles64 >= 512) launch_conv_t<2, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, in_pair, fmt);
+    else launch_conv_t<1, 4>(in, W, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, in_pair, fmt);
 }
 
 // =====================================================================================
 // The same implicit GEMM on v_mfma_f32_16x16x32_f16 with fp32-equivalent accuracy: every operand as two fp16 pieces (x = a + b,
 // 22 significant bits), three partial products per K=32 block -- see fused_block_f16.hip.  Weights are scaled by a power of two
-// S (max |w| S in [2^13, 2^14)), split and lane-ordered offline:
-//   W3[n_tile][tap*Cin/32 + kc][piece 2][lane][4 dwords], {S, 1/S};  lane (channel l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
-// Activations stay fp32 in HBM; a lane fetches its 8 consecutive input channels (two float4) and splits them in registers.
-// Requires Cin % 32 == 0.
+// S (max |w| S in [2^13, 2^14)), split and lane-ordered offline, output channels in pair order (above):
+//   W3[n_tile][tap*Cin/32 + kc][piece 2][lane][4 dwords], {S, 1/S};  lane (row l&15, k-group l>>4) holds k = 32*kc + 8*g + e.
+// Activations arrive in the pair format: a lane's two operand pieces are two 16-byte loads, no arithmetic.  64-bit addressing (the one
+// convolution kernel for tensors of 2 GiB and more).  Requires Cin % 32 == 0, N % 64 == 0.
 // =====================================================================================
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 (&pc)[2]) {
-    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        // a = fp16 pair (toward zero); x - a in ONE v_fma_mix_f32 per value (fp16 source operand: no v_cvt_f32_f16)
-        const float x0 = x[2 * d], x1 = x[2 * d + 1];
-        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-        float r0, r1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
-        pc[0][d] = a;
-        pc[1][d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-    }
-}
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// four values -> their high and low fp16 pieces (two packed dwords each), the same arithmetic as split8
-__device__ __forceinline__ void split4(const f32x4 &x, u32x2 &hi, u32x2 &lo) {
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const float x0 = x[2 * d], x1 = x[2 * d + 1];
-        const unsigned a = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-        float r0, r1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
-        hi[d] = a;
-        lo[d] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-    }
-}
-
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat) {
+                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat, int fmt) {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int nt_idx = q % n_tiles;
     const int mt_idx = (q / n_tiles) * 8 + xcd;
@@ -208,6 +298,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict
     if (m0 >= M) return;
     const int KCH = Cin >> 5, steps = KH * KW * KCH;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 zu = {0u, 0u, 0u, 0u};
     int pb[MT], py[MT], px[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -229,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[j][i] = z4;
 
-    auto fetch = [&](int s, u32x4(&wf)[NT][2], f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+    auto fetch = [&](int s, u32x4(&wf)[NT][2], u32x4(&bp)[MT][2]) {
         const int tap = s / KCH, kc = s - tap * KCH;
         const int ky = tap / KW, kx = tap - ky * KW;
 #pragma unroll
@@ -240,26 +331,22 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict
         for (int j = 0; j < MT; ++j) {
             const int iy = py[j] + ky, ix = px[j] + kx;
             const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
-            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 32 + 8 * g;
-            const f32x4 v0 = *(const f32x4 *)p, v1 = *(const f32x4 *)(p + 4);
-            a0[j] = ok ? v0 : z4;
-            a1[j] = ok ? v1 : z4;
+            const float *p = in + ((size_t)(pb[j] * Hin + (ok ? iy : 0)) * Hin + (ok ? ix : 0)) * Cin + kc * 32 + 4 * g;
+            const u32x4 v0 = *(const u32x4 *)p, v1 = *(const u32x4 *)(p + 16);
+            bp[j][0] = ok ? v0 : zu;
+            bp[j][1] = ok ? v1 : zu;
         }
     };
     auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
-    u32x4 wf[NT][2], wn[NT][2];
-    f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
-    fetch(0, wf, c0, c1);
+    u32x4 wf[NT][2], wn[NT][2], bp[MT][2], bn[MT][2];
+    fetch(0, wf, bp);
     for (int s = 0; s < steps; ++s) {
-        if (s + 1 < steps) fetch(s + 1, wn, n0v, n1v);
-        u32x4 bp[MT][2];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
+        if (s + 1 < steps) fetch(s + 1, wn, bn);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
+            constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 0, 1};      // (w lo, a hi), (w hi, a hi), (w hi, a lo): conv_lt_kernel's order
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -270,52 +357,9 @@ __global__ __launch_bounds__(256) void conv_f16x2_kernel(const float *__restrict
 #pragma unroll
             for (int p = 0; p < 2; ++p) wf[i][p] = wn[i][p];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
+        for (int j = 0; j < MT; ++j) { bp[j][0] = bn[j][0]; bp[j][1] = bn[j][1]; }
     }
-    // Epilogue in two passes: every load (BN scale / shift, residual) first and branch-free (indices clamped into the matrix),
-    // then the arithmetic and the stores.  Interleaved, each residual load sat between two stores and its wait (vmcnt is in
-    // order, and conservative around the `if`) covered the previous store's acknowledgement: 8 serialised round trips per tile.
-    f32x4 scv[NT], shv[NT], rsv[MT][NT];
-    float vmax = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        int n = n0 + i * 16 + 4 * g;
-        n = n < N ? n : 0;
-        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
-        shv[i] = *(const f32x4 *)&shift[n];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            int m = m0 + j * 16 + r16;
-            m = m < M ? m : 0;
-            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            f32x4 v = acc[j][i] * scv[i] + shv[i];
-            if (residual) v += rsv[j][i];
-            if (act) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-            }
-            acc[j][i] = v;
-            asm volatile("" : "+v"(acc[j][i]));         // (keeps the arithmetic from being sunk into the store's branch)
-            if (stat && m0 + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        }
-    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int n = n0 + i * 16 + 4 * g;
-        if (n >= N) continue;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m0 + j * 16 + r16;
-            if (m >= M) continue;
-            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
-        }
-    }
+    conv_epilogue<MT, NT>(acc, scale, shift, inv_s, residual, out, M, N, m0, n0, r16, g, act, fmt, stat);
 }
 
 // Same convolution with the weight fragments shared through LDS: the four waves of a workgroup compute four M tiles of the SAME
@@ -328,7 +372,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        const float *__restrict__ residual, float *__restrict__ out, int M,
                                                        int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad,
-                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat, unsigned in_bytes) {
+                                                       int act, int n_tiles, int m_tiles, float *__restrict__ stat, unsigned in_bytes, int fmt) {
     constexpr int CH_DW = NT * KS * 2 * 256;                     // one chunk of fragments: [tile NT][step KS][piece 2][64][4]
     constexpr int NPW = NT * KS * 2 / 4;                         // fragments per wave and chunk
     static_assert(NT * KS * 2 % 4 == 0, "a quarter of a chunk per wave");
@@ -343,7 +387,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
     const int n0 = nt_idx * (NT * 16);
     const int KCH = Cin >> 5, steps = KH * KW * KCH, chunks = steps / KS;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // activations through buffer loads (byte offset = pixel base + a scalar per step; a tap outside the image gets an offset past the
+    // activations (pair format: the two pieces of a lane's k-group are 64 bytes apart) through buffer loads (byte offset = pixel base + a scalar per step; a tap outside the image gets an offset past the
     // end of the tensor and reads zeros = the padding): no select behind a load -- with one, the compiler waits for every load right
     // after issuing it and the whole memory latency stands in every step (conv_lt_kernel below)
     int py[MT], px[MT];
@@ -357,7 +401,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
         const int r = m - pbi * hw;
         py[j] = (r / Hout) * stride - pad;
         px[j] = (r % Hout) * stride - pad;
-        pbase[j] = (unsigned)(((pbi * Hin + py[j]) * Hin + px[j]) * Cin + 8 * g) * 4u;      // (wraps for padding rows: only used when the tap is inside)
+        pbase[j] = (unsigned)(((pbi * Hin + py[j]) * Hin + px[j]) * Cin + 4 * g) * 4u;      // (wraps for padding rows: only used when the tap is inside)
     }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
     const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
@@ -381,15 +425,15 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
         for (int k = 0; k < NPW; ++k) *(u32x4 *)&wl[buf * CH_DW + (wave + 4 * k) * 256 + lane * 4] = wf[k];
     };
     int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0;                   // the fetch pointer walks the steps in order (no division per step); it stops at the last one
-    auto fetch_a = [&](f32x4(&a0)[MT], f32x4(&a1)[MT]) {
+    auto fetch_a = [&](u32x4(&bq)[MT][2]) {
         const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * Cin + f_kc * 32) * 4u;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int iy = py[j] + f_ky, ix = px[j] + f_kx;
             const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
             const unsigned off = ok ? pbase[j] + dlt : 0x80000000u;
-            a0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
-            a1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 16, 0));
+            bq[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            bq[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 64, 0);
         }
         const int adv = f_s + 1 < steps ? 1 : 0;
         f_s += adv;
@@ -404,9 +448,9 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
     auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
-    f32x4 c0[MT], c1[MT], n0v[MT], n1v[MT];
+    u32x4 bp[MT][2], bn[MT][2];
     fetch_w(0);
-    fetch_a(c0, c1);
+    fetch_a(bp);
     park_w(0);
     for (int c = 0; c < chunks; ++c) {
         // chunk c is in LDS, chunk c - 1 is read.  A raw barrier (__syncthreads() drains the activation loads in flight across it), and
@@ -417,10 +461,7 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
         const unsigned *wc = wl + (c & 1) * CH_DW + lane * 4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            fetch_a(n0v, n1v);                                   // step s + 1 (past the end: the last step again, unused)
-            u32x4 bp[MT][2];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) split8(c0[j], c1[j], bp[j]);
+            fetch_a(bn);                                         // step s + 1 (past the end: the last step again, unused)
             u32x4 wa[NT][2];
 #pragma unroll
             for (int i = 0; i < NT; ++i)
@@ -428,72 +469,31 @@ __global__ __launch_bounds__(256) void conv_h2s_kernel(const float *__restrict__
                 for (int p = 0; p < 2; ++p) wa[i][p] = *(const u32x4 *)(wc + ((i * KS + ks) * 2 + p) * 256);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
+                constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 0, 1};      // (w lo, a hi), (w hi, a hi), (w hi, a lo): conv_lt_kernel's order
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
 #pragma unroll
                     for (int i = 0; i < NT; ++i) acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]);
             }
 #pragma unroll
-            for (int j = 0; j < MT; ++j) { c0[j] = n0v[j]; c1[j] = n1v[j]; }
+            for (int j = 0; j < MT; ++j) { bp[j][0] = bn[j][0]; bp[j][1] = bn[j][1]; }
         }
         park_w((c + 1) & 1);
     }
     if (m0 >= M) return;
-    // epilogue as conv_f16x2_kernel: loads first (branch-free), then arithmetic, then stores
-    f32x4 scv[NT], shv[NT], rsv[MT][NT];
-    float vmax = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        int n = n0 + i * 16 + 4 * g;
-        n = n < N ? n : 0;
-        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
-        shv[i] = *(const f32x4 *)&shift[n];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            int m = m0 + j * 16 + r16;
-            m = m < M ? m : 0;
-            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            f32x4 v = acc[j][i] * scv[i] + shv[i];
-            if (residual) v += rsv[j][i];
-            if (act) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-            }
-            acc[j][i] = v;
-            asm volatile("" : "+v"(acc[j][i]));
-            if (stat && m0 + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        }
-    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int n = n0 + i * 16 + 4 * g;
-        if (n >= N) continue;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m0 + j * 16 + r16;
-            if (m >= M) continue;
-            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
-        }
-    }
+    conv_epilogue<MT, NT>(acc, scale, shift, inv_s, residual, out, M, N, m0, n0, r16, g, act, fmt, stat);
 }
 
 template <int MT, int NT, int KS>
 static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                              hipStream_t s, float *stat) {
+                              hipStream_t s, float *stat, int fmt) {
     const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
     conv_h2s_kernel<MT, NT, KS><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                                     act, n_tiles, m_tiles, stat, in_bytes);
+                                                     act, n_tiles, m_tiles, stat, in_bytes, fmt);
 }
 
 // =====================================================================================
@@ -527,12 +527,12 @@ __device__ __forceinline__ void static_for(F &&f) {
         static_for<N, F, I + 1>(static_cast<F &&>(f));
     }
 }
-template <int MTW>
+template <int MTW, bool FRAG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MTW == 2 ? 4 : 2, MTW == 2 ? 4 : 2)))
 void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ out, int M, int Hin,
                     int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, int n_tiles, int m_tiles,
-                    float *__restrict__ stat, unsigned in_bytes) {
+                    float *__restrict__ stat, unsigned in_bytes, int fmt) {
     constexpr int PT = 4 * MTW;                                  // 16-pixel tiles of the workgroup
     constexpr int U = MTW / 2;                                   // ... staged per wave
     static_assert(MTW == 2 || MTW == 4, "128 | 256 pixels per workgroup");
@@ -549,39 +549,48 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     const int n0 = nt_idx * 128;
     const int KCH = Cin >> 5, steps = KH * KW * KCH;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    // staging: a wave instruction fetches 8 pixels x 128 B (lane = pixel l >> 3, 16-byte chunk l & 7: two whole lines per 16 lanes; the
-    // fragment order -- lane = (pixel, 8 channels) -- would touch 16 lines per 16 lanes and cost the vector cache four times the
-    // tag lookups -- measured: no difference, kept for the contiguous lines).  A lane stages pixels (l >> 3) and 8 + (l >> 3) of the tiles wave U + u.
-    const int sp = lane >> 3, sc = lane & 7;
+    // Staging (round 6).  In the pair format the 128 bytes of a (pixel, k32 chunk) are the high pieces of k-groups 0..3, then their low pieces:
+    // every 16-byte chunk IS a fragment entry -- a staging lane copies it, no arithmetic.  A wave stages its U tiles with 2 U instructions per
+    // step, in one of two shapes:
+    //   FRAG  (3x3 convolutions: taps re-read from L2) a wave instruction fetches one 1 KB fragment PLANE -- lane (pixel r = l & 15, k-group
+    //         gg = l >> 4) the 16 bytes at pixel row + 16 gg (+ 64: low piece) -- and parks it lane-linear: conflict-free writes and reads
+    //         (linear 16-byte accesses fit the hardware's lane groups, MI355X_MICROARCH LDS table).  96 against 102 us for layer 3's conv2;
+    //   !FRAG (1x1 convolutions: activations streamed from HBM) a wave instruction fetches 8 pixels x 128 B -- lane (pixel l >> 3 of half
+    //         h, chunk sc = l & 7 = (piece sc >> 2, k-group sc & 3)): whole lines.  The plane-shaped loads (64-byte runs) cost these
+    //         convolutions 7-10 % (layer 3 conv1 56 -> 61 us, layer 2.0 conv1 142 -> 158).  Its fragment entries go to slot
+    //         gg 16 + ((r + 4 (gg >> 1) + 2 p) & 15) of the plane: the reads stay conflict-free in the lane groups ({0-3, 12-15, 20-27}, ...:
+    //         k-groups 2 q and 2 q + 1 must share a rotation), the writes of an 8-lane group (one pixel: 4 k-groups x 2 pieces) are 2-way
+    //         -- 16 LDS cycles under the 13 a ds_write_b128 takes to move its data anyway.  (Rounds 3-5: rotation 4 gg, reads 2-way.)
     // Buffer loads: a 32-bit byte offset per lane = pixel base + a scalar per (tap, k32 step); a tap outside the image takes an offset
     // past the end of the tensor, which the buffer hardware answers with zeros = the zero padding -- no select behind the load, so
     // nothing consumes a loaded register before the step that parks it (a v_cndmask there made the compiler wait for every load
     // right after issuing it).  in_bytes < 2^31 (launcher).
-    int py[U][2], px[U][2];
+    const int sp = lane >> 3, sc = lane & 7;
+    auto slot = [](int r, int gg, int p) { return gg * 16 + ((r + 4 * (gg >> 1) + 2 * p) & 15); };
+    int py[U][2], px[U][2];                                       // [u][h]; FRAG: h = 0 only (one pixel per lane and tile)
     unsigned pbase[U][2];
+    int woff[2];                                                  // dword offset inside a tile's two planes of what this lane parks ([h] | FRAG: [piece])
+    int roff[2];                                                  // ... of this lane's fragment entry of piece p as a reader
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int m = m0 + (wave * U + u) * 16 + 8 * h + sp;
+        for (int h = 0; h < (FRAG ? 1 : 2); ++h) {
+            int m = m0 + (wave * U + u) * 16 + (FRAG ? r16 : 8 * h + sp);
             m = m < M ? m : M - 1;                               // (rows past the end: clamped loads, no stores)
             const int hw = Hout * Hout;
             const int pbi = m / hw;
             const int r = m - pbi * hw;
             py[u][h] = (r / Hout) * stride - pad;
             px[u][h] = (r % Hout) * stride - pad;
-            pbase[u][h] = (unsigned)(((pbi * Hin + py[u][h]) * Hin + px[u][h]) * Cin + 4 * sc) * 4u;     // (wraps for padding rows: only used when the tap is inside)
+            pbase[u][h] = (unsigned)(((pbi * Hin + py[u][h]) * Hin + px[u][h]) * Cin + 4 * (FRAG ? g : sc)) * 4u;     // (wraps for padding rows: only used when the tap is inside)
         }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        woff[h] = FRAG ? h * 256 + lane * 4 : (sc >> 2) * 256 + slot(8 * h + sp, sc & 3, sc >> 2) * 4;
+        roff[h] = FRAG ? lane * 4 : slot(r16, g, h) * 4;
+    }
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(W3), 0, 0x7fffffff, 0x00027000);
-    // LDS slot (16 bytes) of fragment lane (pixel r, k-group gg): gg 16 + ((r + 4 gg) & 15) -- the rotation spreads the 8-byte writes of
-    // a staging instruction (2 pixels x 8 chunks per 16 lanes: without it all k-groups of a pixel share a bank) and keeps the 16-byte
-    // fragment reads at most 2-way conflicting in the hardware's lane groups (MI355X_MICROARCH LDS table)
-    auto slot = [](int r, int gg) { return gg * 16 + ((r + 4 * gg) & 15); };
-    int woff[2];                                                  // dword offset of this lane's 8 bytes inside a fragment, pixel halves 0 / 1
-#pragma unroll
-    for (int h = 0; h < 2; ++h) woff[h] = slot(8 * h + sp, sc >> 1) * 4 + (sc & 1) * 2;
-    const int roff = slot(r16, g) * 4;                            // ... of this lane's 16 bytes as a reader
     const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
     f32x4 acc[MTW][4];
 #pragma unroll
@@ -593,7 +602,7 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     // step that parks them -- first-touch activations come from HBM (~2 us under load), one step of MFMAs is ~0.7 us.
     constexpr int D = 2;                                         // (4: the same time -- what mattered was that nothing waits for a load right behind it; PMC / variants in DESIGN 7)
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = LT_PROF ? __builtin_amdgcn_s_memtime() : 0, tn;
-    f32x4 sa[D][U][2];
+    u32x4 sa[D][U][2];
     u32x4 sw[D][2];
     const unsigned wbase = (unsigned)((n0 / 16 + wave) * steps) * 2048u;        // this wave's channel tile: both pieces of a step (bytes)
     const unsigned l16 = lane * 16;
@@ -606,10 +615,12 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < (FRAG ? 1 : 2); ++h) {
                 const int iy = py[u][h] + f_ky, ix = px[u][h] + f_kx;
                 const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
-                sa[SL][u][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? pbase[u][h] + dlt : 0x80000000u, 0, 0));
+                const unsigned off = ok ? pbase[u][h] + dlt : 0x80000000u;
+                sa[SL][u][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+                if (FRAG) sa[SL][u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 64, 0);
             }
         const int adv = f_s + 1 < steps ? 1 : 0;
         f_s += adv;
@@ -633,13 +644,7 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32x2 hi, lo;
-                split4(sa[SL][u][h], hi, lo);
-                unsigned *t = b + (wave * U + u) * 512 + woff[h];
-                *(u32x2 *)t = hi;
-                *(u32x2 *)(t + 256) = lo;
-            }
+            for (int h = 0; h < 2; ++h) *(u32x4 *)(b + (wave * U + u) * 512 + woff[h]) = sa[SL][u][h];
 #pragma unroll
         for (int p = 0; p < 2; ++p) *(u32x4 *)&b[BF_DW + (wave * 2 + p) * 256 + lane * 4] = sw[SL][p];
     };
@@ -647,35 +652,52 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     };
     u32x4 wa[4][2], bp[MTW][2];
-    auto read_frags = [&](int s) {
+    auto read_a = [&](int s) {                                   // operands of the first product: weights low, activations high
         const unsigned *b = sm + (s & 1) * ST_DW;
-        // fragments in the order the products need them: (weights low, activations high) first
 #pragma unroll
         for (int i = 0; i < 4; ++i) wa[i][1] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + 1) * 256 + lane * 4);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) bp[j][0] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 0) * 256 + roff);
+        for (int j = 0; j < MTW; ++j) bp[j][0] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 0) * 256 + roff[0]);
+    };
+    auto read_b = [&](int s) {                                   // ... the other two: weights high, activations low
+        const unsigned *b = sm + (s & 1) * ST_DW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) wa[i][0] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + i) * 2 + 0) * 256 + lane * 4);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) bp[j][1] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 1) * 256 + roff);
+        for (int j = 0; j < MTW; ++j) bp[j][1] = *(const u32x4 *)(b + ((wm * MTW + j) * 2 + 1) * 256 + roff[1]);
     };
-    auto products = [&]() {
+    // The three products of a step, and WHEN they run (round 6).  All eight waves pass the barrier together, so a step used to be two phases
+    // in lockstep: every wave reading its 16 KB of fragments (LDS bandwidth: ~1200 cycles per CU with the parking writes) with the matrix
+    // pipe idle, then every wave on the matrix pipe (1536 cycles per SIMD) with the LDS idle.  Now the third product of step s - 1
+    // (weights high x activations low) is DEFERRED past the barrier of step s: it needs no register the first product of step s
+    // (weights low x activations high) loads, so a wave issues the reads of those, runs the 16 deferred MFMAs under their latency, issues the
+    // reads that overwrite the deferred product's operands (in flight under the deferred MFMAs' execution), parks, fetches, and goes on
+    // with products one and two.  No extra registers; the accumulation order per step is (lo x hi), (hi x hi), (hi x lo) in every kernel.
+    auto prod = [&](int pw, int pb_) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 1, 0};
+        for (int j = 0; j < MTW; ++j)
 #pragma unroll
-            for (int j = 0; j < MTW; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = mm(wa[i][pa[t]], bp[j][pbk[t]], acc[j][i]);
-        }
+            for (int i = 0; i < 4; ++i) acc[j][i] = mm(wa[i][pw], bp[j][pb_], acc[j][i]);
     };
     // Raw barriers: __syncthreads() would drain the loads in flight.  No branches inside a step (the last steps park / fetch clamped
     // leftovers nobody reads): the compiler's vmcnt bookkeeping falls back to vmcnt(0) at every join.
 #define LT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    // load segment of step s: this wave's fragments of step s into registers, its share of step s + 1 into the other LDS half, the loads
-    // of step s + 1 + D;  slot_c = ring slot of step s + 1
-    auto load_seg = [&](int s, auto slot_c) {
-        read_frags(s);
+#ifndef SYN_LT_DEFER
+#define SYN_LT_DEFER 1
+#endif
+#ifndef SYN_LT_PIN
+#define SYN_LT_PIN 1
+#endif
+    // step s: slot_c = ring slot of step s + 1 (parked now), which then receives the loads of step s + 1 + D
+    constexpr bool DEFER = SYN_LT_DEFER && MTW == 4;             // (128-pixel tiles: the 24 operand registers kept across the barrier do not fit into the 128 of two workgroups per CU)
+    auto step = [&](int s, auto slot_c) {
+        read_a(s);
+        if (DEFER) {
+            __builtin_amdgcn_sched_barrier(0);
+            prod(0, 1);                                          // step s - 1: weights high x activations low (zeros before step 0)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_b(s);
         if (LT_PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LT_LAP(4);
         park((s + 1) & 1, slot_c);
@@ -683,7 +705,18 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         fetch(slot_c);
         fetch_w(slot_c);
         LT_LAP(3);
+        if (DEFER) __builtin_amdgcn_sched_barrier(0);
+        prod(1, 0);
+        prod(0, 0);
+        if (!DEFER) prod(0, 1);
+        if (DEFER && SYN_LT_PIN) __builtin_amdgcn_sched_barrier(0);      // (else the compiler sinks these MFMAs past the next barrier)
     };
+    if (DEFER) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i][0] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) bp[j][1] = u32x4{0u, 0u, 0u, 0u};
+    }
     // prologue: steps 0 .. D - 1 into their slots, step 0 parked, step D into the freed slot 0   (steps % D == 0: launcher)
     static_for<D>([&](auto d) { fetch(d); });
     static_for<D>([&](auto d) { fetch_w(d); });
@@ -696,120 +729,84 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
             LT_LAP(0);
             LT_BARRIER();                                        // step s is in LDS; the other half (step s - 1) has been read
             LT_LAP(1);
-            load_seg(s0 + dd, std::integral_constant<int, (dd + 1) % D>{});
-            products();
+            step(s0 + dd, std::integral_constant<int, (dd + 1) % D>{});
         });
+    if (DEFER) prod(0, 1);                                       // the last step's third product
     LT_LAP(0);
     if (LT_PROF && blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 5) && steps >= 16)
         printf("lt<%d> M %d N %d steps %d wave %d: mfma %llu barrier %llu park %llu fetch %llu dsread %llu  (shader cycles per step)\n", MTW, M, N, steps, wave,
                pt_[0] / steps, pt_[1] / steps, pt_[2] / steps, pt_[3] / steps, pt_[4] / steps);
     const int mw = m0 + wm * (MTW * 16), nw = n0 + wn * 64;
     if (mw >= M) return;
-    // epilogue as conv_h2s_kernel: loads first (branch-free), then arithmetic, then stores
-    f32x4 scv[4], shv[4], rsv[MTW][4];
-    float vmax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = nw + i * 16 + 4 * g;
-        scv[i] = *(const f32x4 *)&scale[n] * inv_s;
-        shv[i] = *(const f32x4 *)&shift[n];
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) {
-            int m = mw + j * 16 + r16;
-            m = m < M ? m : 0;
-            if (residual) rsv[j][i] = *(const f32x4 *)&residual[(size_t)m * N + n];     // (kernel-uniform condition)
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) {
-            f32x4 v = acc[j][i] * scv[i] + shv[i];
-            if (residual) v += rsv[j][i];
-            if (act) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-            }
-            acc[j][i] = v;
-            asm volatile("" : "+v"(acc[j][i]));
-            if (stat && mw + j * 16 + r16 < M) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-        }
-    if (stat) range_note(stat, vmax);                   // (kernel-uniform condition)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = nw + i * 16 + 4 * g;
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) {
-            const int m = mw + j * 16 + r16;
-            if (m >= M) continue;
-            *(f32x4 *)&out[(size_t)m * N + n] = acc[j][i];
-        }
-    }
+    conv_epilogue<MTW, 4>(acc, scale, shift, inv_s, residual, out, M, N, mw, nw, r16, g, act, fmt, stat);
 }
 
 template <int MTW>
 static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                              float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                             hipStream_t s, float *stat) {
+                             hipStream_t s, float *stat, int fmt) {
     const int n_tiles = N / 128;
     const int m_tiles = (M + 64 * MTW - 1) / (64 * MTW);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
-    conv_lt_kernel<MTW><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act,
-                                             n_tiles, m_tiles, stat, in_bytes);
+    static const int shape = getenv("SYN_LT_STAGE") ? atoi(getenv("SYN_LT_STAGE")) : -1;        // A/B knob: 0 / 1 forces the row- / plane-shaped staging loads
+    const bool frag = shape < 0 ? KH * KW > 1 : shape != 0;       // plane-shaped loads where the taps re-read the activations from L2
+    if (frag) conv_lt_kernel<MTW, true><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, in_bytes, fmt);
+    else conv_lt_kernel<MTW, false><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, in_bytes, fmt);
 }
 
 template <int MT, int NT>
 static void launch_conv_f16x2_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                               float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                              hipStream_t s, float *stat) {
-    const int n_tiles = (N + NT * 16 - 1) / (NT * 16);
+                              hipStream_t s, float *stat, int fmt) {
+    const int n_tiles = N / (NT * 16);
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     conv_f16x2_kernel<MT, NT><<<grid, 256, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad,
-                                                 act, n_tiles, m_tiles, stat);
+                                                 act, n_tiles, m_tiles, stat, fmt);
 }
 
+// in: pair format; fmt: kOutPair | kResPair (the formats of out / residual).  N % 64 == 0, Cin % 64 == 0 (every ResNet-50 convolution behind the stem).
 void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s, float *stat, int lt) {
+                     hipStream_t s, float *stat, int lt, int fmt) {
     const int lt_min_m = lt == 2 ? 1 : 4096;                      // (2 = cross-check mode: 128-pixel tiles on every shape that fits, ragged ones too)
     const int M = B * Hout * Hout;
-    const long tiles = ((long)M + 127) / 128 * ((N + 63) / 64);
+    const long tiles = ((long)M + 127) / 128 * (N / 64);
     const int steps = KH * KW * (Cin / 32);
-    if (lt && N % 128 == 0 && M >= lt_min_m && steps % 2 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31) &&
-        (size_t)N * KH * KW * Cin * 4 < (1ull << 31)) {
+    const bool small = (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31);       // 32-bit buffer offsets
+    if (lt && N % 128 == 0 && M >= lt_min_m && steps % 2 == 0 && small && (size_t)N * KH * KW * Cin * 4 < (1ull << 31)) {
         // 256-pixel tiles (one 8-wave workgroup per CU) for long K when they still give every CU a workgroup; 128-pixel tiles (two workgroups
         // per CU: one's prologue / epilogue beside the other's steps) for K <= 512 -- conv3 and the downsample branches, whose time is their
         // epilogue (layer 3 conv3: 111 -> 96 us; conv1 / conv2 the other way: 56 -> 60, 106 -> 110)
-        if (lt != 2 && steps > 16 && (long)((M + 255) / 256) * (N / 128) >= 256) launch_conv_lt_t<4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-        else launch_conv_lt_t<2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        if (lt != 2 && steps > 16 && (long)((M + 255) / 256) * (N / 128) >= 256) launch_conv_lt_t<4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
+        else launch_conv_lt_t<2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
         return;
     }
-    if (N % 64 == 0 && steps % 2 == 0 && (size_t)B * Hin * Hin * Cin * 4 < (1ull << 31)) {
+    if (steps % 2 == 0 && small) {
         // (64 pixels per wave or 128 channels per workgroup need > 256 registers = one wave per SIMD: 10.4 / 9.4 ms against 8.3)
         // 32-pixel wave tiles from 2048 workgroup tiles on: at 1024 (layer 3's conv1 / conv2: 256 x 4) they are 1.33 rounds of the 768 workgroups
         // the chip holds, the 16-pixel configuration's 2048 are 2.67 (B = 512: 6.96 -> 6.85 ms; from 4097 on instead: 7.06)
-        if (tiles >= 2048) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-        else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+        if (tiles >= 2048) launch_conv_h2s_t<2, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
+        else launch_conv_h2s_t<1, 4, 2>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
         return;
     }
-    if (tiles >= 1024) launch_conv_f16x2_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
-    else launch_conv_f16x2_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat);
+    if (tiles >= 1024) launch_conv_f16x2_t<2, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
+    else launch_conv_f16x2_t<1, 4>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, s, stat, fmt);
 }
 
 // =====================================================================================
 // conv3 + BN + identity + ReLU of a bottleneck FUSED with the NEXT bottleneck's conv1 + BN + ReLU (resnet_backbone.py:122-134 of
 // block k, :116-118 of block k+1).  The convolutions of layer 1 are bound by memory throughput, not by the matrix pipe (counters in
 // 56 % of the wave cycles in s_waitcnt, deeper prefetch buys nothing): conv3 writes the 256-channel block output, the next
-// conv1 reads all of it back as its GEMM operand.  Here a workgroup owns 128 pixels and ALL output channels of conv3, in chunks of 64:
-//   * the conv2 output of its pixels (K = 64 channels) is split once into fp16 pieces and stays in registers (B operand of every chunk);
-//   * per chunk: 64 output channels of conv3 (weights through a double-buffered LDS chunk, as in conv_h2s_kernel), BN, + identity, ReLU,
-//     store -- and the chunk, still in registers, is split IN PLACE into the B operand of the next block's conv1: with K slot (g, e) of
-//     k32 step s := channel 64 c + 16 (2 s + (e >> 2)) + 4 g + (e & 3), the D layout of the conv3 MFMAs is the B layout of conv1's
-//     (the host packs conv1's weights in that K order, chunk-major: W1f[chunk][tile][step 2][piece 2][lane][4]); conv1 accumulates over
-//     the chunks in registers;
-//   * at the end BN + ReLU of conv1 and the store of the next block's 64 / 128-channel input.
+// conv1 reads all of it back as its GEMM operand.  Here a workgroup owns 128 pixels and ALL output channels of conv3, in chunks of 32 / 64:
+//   * the conv2 output of its pixels (K = 64 / 128 channels, pair format) is loaded once as ready-made B operands and stays in registers;
+//   * per chunk: the chunk's output channels of conv3 (weights through a double-buffered LDS chunk, as in conv_h2s_kernel), BN, + identity,
+//     ReLU, the split into the two fp16 pieces -- which are BOTH what is stored (the block output in the pair format) and, still in
+//     registers, the B operand of the next block's conv1: in pair order the lane's eight channels of a 32-channel block are k-group g of
+//     that k32 step, so conv1's weights are its ordinary fragments, step-major (W1f[k32 step][tile][piece 2][lane][4]); conv1 accumulates
+//     over the chunks in registers;
+//   * at the end BN + ReLU of conv1 and the store of the next block's 64 / 128-channel input (pair format).
 // The block output is read back only as the next block's identity: 1.18 GB instead of 1.65 GB per bottleneck of layer 1 at B = 512, and
 // one launch less.
 // =====================================================================================
@@ -821,17 +818,17 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
 // downsample weights of a chunk come straight from L2 (natural K order, one tile ahead), and the 256-channel branch -- 472 MB written by a
 // launch of its own and read back here at B = 512 -- never exists.
 struct DsArgs {
-    const float *X;             // block input [M, 64]
+    const float *X;             // block input [M, 64], pair format
     const unsigned *Wd;         // downsample conv's fp16 x2 fragments [N3/16][2][2][64][4], {S, 1/S}
     const float *scale_d, *shift_d;
 };
 template <int KS3, int NT1, int MT, int TC, bool DS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
-                     const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3]*/,
-                     float *__restrict__ out /*[M, N3]*/, const unsigned *__restrict__ W1f /*[N3/64][2][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
-                     const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1]*/, int M, int N3,
-                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, DsArgs ds = DsArgs{}) {
+void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
+                     const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3], pairs or fp32 (res_pair)*/,
+                     float *__restrict__ out /*[M, N3] pairs*/, const unsigned *__restrict__ W1f /*[N3/32][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
+                     const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1] pairs*/, int M, int N3,
+                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, int res_pair, DsArgs ds = DsArgs{}) {
     // TC = output-channel tiles of conv3 per chunk (4: 64 channels = two k32 steps of conv1; 2: 32 channels = one -- half the LDS per chunk
     // for the wider layers)
     constexpr int K = 32 * KS3, N1 = 16 * NT1, CW = 16 * TC, S1 = TC / 2;
@@ -874,7 +871,7 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
     };
     fetch_w3(0);
     fetch_w1(0);
-    // this wave's pixels (clamped: a wave past the end computes on the last pixel and stores nothing) and their conv2 output as pieces
+    // this wave's pixels (clamped: a wave past the end computes on the last pixel and stores nothing) and their conv2 output: the pieces as stored
     int mp[MT];
     u32x4 bp[MT][KS3][2];
 #pragma unroll
@@ -883,11 +880,12 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
         mp[j] = m < M ? m : M - 1;
 #pragma unroll
         for (int ks = 0; ks < KS3; ++ks) {
-            const float *p = T2 + (size_t)mp[j] * K + ks * 32 + 8 * g;
-            split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), bp[j][ks]);
+            const float *p = T2 + (size_t)mp[j] * K + ks * 32 + 4 * g;
+            bp[j][ks][0] = *(const u32x4 *)p;
+            bp[j][ks][1] = *(const u32x4 *)(p + 16);
         }
     }
-    // DS: the block input of the same pixels as pieces (K = 64: two k32 steps) and the branch's scale
+    // DS: the block input of the same pixels (K = 64: two k32 steps) and the branch's scale
     u32x4 xd[DS ? MT : 1][2][2];
     float inv_sd = 0.f;
     if constexpr (DS) {
@@ -896,8 +894,9 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const float *p = ds.X + (size_t)mp[j] * 64 + ks * 32 + 8 * g;
-                split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), xd[j][ks]);
+                const float *p = ds.X + (size_t)mp[j] * 64 + ks * 32 + 4 * g;
+                xd[j][ks][0] = *(const u32x4 *)p;
+                xd[j][ks][1] = *(const u32x4 *)(p + 16);
             }
     }
     park_w3(0);
@@ -909,6 +908,14 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
 #pragma unroll
         for (int i = 0; i < NT1; ++i) acc1[j][i] = z4;
     float vmax3 = 0.f;
+    // dword offset inside a pixel row of (pixel, tile i of the chunk)'s register quad: see conv_epilogue
+    int qo_res[TC], qo_out[TC], qn[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        qo_res[i] = 32 * (i >> 1) + (res_pair ? 4 * g + 16 * (i & 1) : 8 * g + 4 * (i & 1));
+        qo_out[i] = 32 * (i >> 1) + 4 * g + 16 * (i & 1);
+        qn[i] = 32 * (i >> 1) + 8 * g + 4 * (i & 1);          // the quad's first channel (pair order)
+    }
 
     for (int c = 0; c < chunks; ++c) {
         __syncthreads();                                         // chunk c of both weight sets is in LDS, chunk c-1 is read
@@ -918,7 +925,7 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int i = 0; i < TC; ++i) rsv[j][i] = *(const f32x4 *)&identity[(size_t)mp[j] * N3 + CW * c + 16 * i + 4 * g];
+                for (int i = 0; i < TC; ++i) rsv[j][i] = *(const f32x4 *)&identity[(size_t)mp[j] * N3 + CW * c + qo_res[i]];
         }
         if (c + 1 < chunks) fetch_w3(c + 1);
         if constexpr (DS) {
@@ -934,7 +941,7 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
                 if (i + 1 < TC) fetch_d(i + 1, wd[(i + 1) & 1]);
-                const f32x4 scd = *(const f32x4 *)&ds.scale_d[CW * c + 16 * i + 4 * g] * inv_sd, shd = *(const f32x4 *)&ds.shift_d[CW * c + 16 * i + 4 * g];
+                const f32x4 scd = *(const f32x4 *)&ds.scale_d[CW * c + qn[i]] * inv_sd, shd = *(const f32x4 *)&ds.shift_d[CW * c + qn[i]];
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     f32x4 a = z4;
@@ -970,31 +977,35 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
                 }
             }
         if (c + 1 < chunks) { park_w3((c + 1) & 1); fetch_w1(c + 1); }
-        // ---- BN, + identity, ReLU, store; the chunk stays in registers as conv1's operand ----
+        // ---- BN, + identity, ReLU, split: the pieces are the stored block output AND conv1's operand ----
+        u32x4 op[MT][S1][2];
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const f32x4 scv = *(const f32x4 *)&sc3[CW * c + 16 * i + 4 * g], shv = *(const f32x4 *)&sh3[CW * c + 16 * i + 4 * g];
+        for (int sk = 0; sk < S1; ++sk) {
+            const f32x4 scv0 = *(const f32x4 *)&sc3[CW * c + qn[2 * sk]], shv0 = *(const f32x4 *)&sh3[CW * c + qn[2 * sk]];
+            const f32x4 scv1 = *(const f32x4 *)&sc3[CW * c + qn[2 * sk + 1]], shv1 = *(const f32x4 *)&sh3[CW * c + qn[2 * sk + 1]];
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                f32x4 v = acc3[j][i] * scv + shv;
-                v += rsv[j][i];
+                f32x4 v0 = acc3[j][2 * sk] * scv0 + shv0, v1 = acc3[j][2 * sk + 1] * scv1 + shv1;
+                f32x4 r0, r1;
+                if (!DS && res_pair) unpair8(__builtin_bit_cast(u32x4, rsv[j][2 * sk]), __builtin_bit_cast(u32x4, rsv[j][2 * sk + 1]), r0, r1);
+                else { r0 = rsv[j][2 * sk]; r1 = rsv[j][2 * sk + 1]; }
+                v0 += r0; v1 += r1;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-                acc3[j][i] = v;
-                asm volatile("" : "+v"(acc3[j][i]));
+                for (int t = 0; t < 4; ++t) { v0[t] = fmaxf(v0[t], 0.0f); v1[t] = fmaxf(v1[t], 0.0f); }
+                split8(v0, v1, op[j][sk]);
+                asm volatile("" : "+v"(op[j][sk][0]), "+v"(op[j][sk][1]));
                 if (m0 + j * 16 + r16 < M) {
-                    *(f32x4 *)&out[(size_t)(m0 + j * 16 + r16) * N3 + CW * c + 16 * i + 4 * g] = v;
-                    vmax3 = fmaxf(vmax3, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+                    float *dst = &out[(size_t)(m0 + j * 16 + r16) * N3 + CW * c];
+                    *(u32x4 *)(dst + qo_out[2 * sk]) = op[j][sk][0];
+                    *(u32x4 *)(dst + qo_out[2 * sk + 1]) = op[j][sk][1];
+                    vmax3 = fmaxf(vmax3, fmaxf(fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])), fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3]))));
                 }
             }
         }
-        // ---- conv1 of the next block: K = this chunk's channels, in the D-register order (tiles 2 s, 2 s + 1 = one k32 step) ----
+        // ---- conv1 of the next block: K = this chunk's channels (S1 k32 steps) ----
         const unsigned *w1c = w1l + (c & 1) * W1C_DW + lane * 4;
 #pragma unroll
         for (int sk = 0; sk < S1; ++sk) {
-            u32x4 op[MT][2];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) split8(acc3[j][2 * sk], acc3[j][2 * sk + 1], op[j]);
 #pragma unroll
             for (int i = 0; i < NT1; ++i) {
                 u32x4 wa[2];
@@ -1002,58 +1013,44 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3]*/, const unsigne
                 for (int p = 0; p < 2; ++p) wa[p] = *(const u32x4 *)(w1c + ((sk * NT1 + i) * 2 + p) * 256);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
-                    acc1[j][i] = mm(wa[1], op[j][0], acc1[j][i]);
-                    acc1[j][i] = mm(wa[0], op[j][1], acc1[j][i]);
-                    acc1[j][i] = mm(wa[0], op[j][0], acc1[j][i]);
+                    acc1[j][i] = mm(wa[1], op[j][sk][0], acc1[j][i]);
+                    acc1[j][i] = mm(wa[0], op[j][sk][1], acc1[j][i]);
+                    acc1[j][i] = mm(wa[0], op[j][sk][0], acc1[j][i]);
                 }
             }
         }
         if (c + 1 < chunks) park_w1((c + 1) & 1);
     }
     if (stat3) range_note(stat3, vmax3);                 // (kernel-uniform conditions)
-    // ---- conv1: BN + ReLU, store the next block's input ----
-    float vmax1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NT1; ++i) {
-        const f32x4 scv = *(const f32x4 *)&scale1[16 * i + 4 * g] * inv_s1, shv = *(const f32x4 *)&shift1[16 * i + 4 * g];
-#pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            f32x4 v = acc1[j][i] * scv + shv;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-            if (m0 + j * 16 + r16 < M) {
-                *(f32x4 *)&T1n[(size_t)(m0 + j * 16 + r16) * N1 + 16 * i + 4 * g] = v;
-                vmax1 = fmaxf(vmax1, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-            }
-        }
-    }
-    if (stat1) range_note(stat1, vmax1);
+    // ---- conv1: BN + ReLU, store the next block's input (pair format) ----
+    conv_epilogue<MT, NT1>(acc1, scale1, shift1, inv_s1, nullptr, T1n, M, N1, m0, 0, r16, g, 1, kOutPair, stat1);
 }
 
 template <int KS3, int NT1, int MT, int TC>
 static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                          const unsigned *W1f, const float *s1, const float *scale1, const float *shift1, float *T1n, int M, int N3, hipStream_t s,
-                         float *stat3, float *stat1) {
+                         float *stat3, float *stat1, int res_pair) {
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
-    conv_c3f_kernel<KS3, NT1, MT, TC><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
+    conv_c3f_kernel<KS3, NT1, MT, TC><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, res_pair);
 }
 
-// ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0
+// ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0.  Every tensor in the pair format.
 bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
                         const float *scale_d, const float *shift_d, float *out, const unsigned *W1f, const float *s1, const float *scale1,
                         const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1) {
     if (K != 64 || Kd != 64 || N3 != 256 || N1 != 64) return false;
     const DsArgs ds{X, Wd, scale_d, shift_d};
     const int m_tiles = (M + 127) / 128, grid = ((m_tiles + 7) / 8) * 8;
-    conv_c3f_kernel<2, 4, 2, 2, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);      // (32-channel chunks: with 64 the second B operand spills)
+    conv_c3f_kernel<2, 4, 2, 2, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, 0, ds);      // (32-channel chunks: with 64 the second B operand spills)
     return true;
 }
 
+// T2, out, T1n: pair format; identity: pairs (res_pair) or fp32 (a downsample branch computed by a launch of its own)
 bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                      const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
-                     hipStream_t s, float *stat3, float *stat1) {
+                     hipStream_t s, float *stat3, float *stat1, int res_pair) {
     if (N3 % 64 || N3 > 512) return false;
-#define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1)
+#define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1, res_pair)
     if (K == 64 && N1 == 64) SYN_C3F(2, 4, 2, 4);              // layer 1
     else if (K == 64 && N1 == 128) SYN_C3F(2, 8, 2, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)
     else if (K == 128 && N1 == 128) SYN_C3F(4, 8, SYN_C3F_L2_MT, 2);       // layer 2
@@ -1110,13 +1107,15 @@ void launch_resnet_stem(const float *img, const uint8_t *img8, const float *w, c
     else      resnet_stem_kernel<false><<<(npix + 15) / 16, 256, 0, s>>>(img, nullptr, w, scale, shift, out, npix);
 }
 
-// MaxPool2d(kernel 3, stride 2, padding 1) (resnet_backbone.py:172), NHWC; padding never wins the max (-inf).
+// MaxPool2d(kernel 3, stride 2, padding 1) (resnet_backbone.py:172), NHWC fp32 in; padding never wins the max (-inf).  out_pair: the pooled
+// tensor in the pair format (an fp16 x2 forward: layer 1's conv1 takes it), else fp32.
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ in, float *__restrict__ out, long total,
-                                                           int Hin, int Hout, int C4, float *__restrict__ stat) {
+                                                           int Hin, int Hout, int C4, float *__restrict__ stat, int out_pair) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) { if (stat) range_note(stat, 0.f); return; }       // (whole waves take part in the reduction)
     const int c4 = (int)(idx % C4);
     long p = idx / C4;
+    const long pix = p;
     const int ox = (int)(p % Hout);
     p /= Hout;
     const int oy = (int)(p % Hout), b = (int)(p / Hout);
@@ -1134,13 +1133,19 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
             for (int t = 0; t < 4; ++t) m[t] = fmaxf(m[t], v[t]);
         }
     }
-    *(f32x4 *)&out[(size_t)idx * 4] = m;
+    if (out_pair) {
+        u32x2 hi, lo;
+        split4(m, hi, lo);
+        float *dst = out + (size_t)pix * (C4 * 4) + 32 * (c4 >> 3) + 2 * (c4 & 7);
+        *(u32x2 *)dst = hi;
+        *(u32x2 *)(dst + 16) = lo;
+    } else *(f32x4 *)&out[(size_t)idx * 4] = m;
     if (stat) range_note(stat, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fabsf(m[2]), fabsf(m[3]))));
 }
 
-void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat) {
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat, int out_pair) {
     const long total = (long)B * Hout * Hout * (C / 4);
-    maxpool3x3s2_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, total, Hin, Hout, C / 4, stat);
+    maxpool3x3s2_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, total, Hin, Hout, C / 4, stat, out_pair);
 }
 
 // adaptive_avg_pool2d -> flatten -> linear heads (resnet_backbone.py:236-246): feat [B,P,C] NHWC, Wfc [n_out][C].
@@ -1251,7 +1256,7 @@ template <int U, bool POOL = false>
 __global__ __launch_bounds__((2 * U + 1) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, const unsigned *__restrict__ As3 /*[2][10][2][64][4]*/,
                              const float *__restrict__ s_shift /*[64] folded*/, float *__restrict__ out /*[B,60,60,64]*/, int B,
-                             float *__restrict__ stat = nullptr) {
+                             float *__restrict__ stat = nullptr, int out_pair = 0 /*POOL: the pooled tensor in the pair format*/) {
     constexpr int UNIT_DW = (kRsSlots + 1) * kRsRowEl / 2, NT = (2 * U + 1) * 64;
     __shared__ __attribute__((aligned(16))) unsigned smem[U * UNIT_DW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1388,7 +1393,13 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
                             const f32x4 v = {fmaxf(runmax[c][4 * q], hm[4 * q]), fmaxf(runmax[c][4 * q + 1], hm[4 * q + 1]),
                                              fmaxf(runmax[c][4 * q + 2], hm[4 * q + 2]), fmaxf(runmax[c][4 * q + 3], hm[4 * q + 3])};
                             if (st) {
-                                *(f32x4 *)(dst + 8 * q) = v;
+                                if (out_pair) {                // channels 32 G + 8 q + 4 h + 0..3: half a k-group of chunk G -- 8 bytes of each piece
+                                    u32x2 hi, lo;
+                                    split4(v, hi, lo);
+                                    float *dp = dst - 4 * h + 4 * q + 2 * h;     // pixel row + 32 G + (4 q + 2 h) dwords
+                                    *(u32x2 *)dp = hi;
+                                    *(u32x2 *)(dp + 16) = lo;
+                                } else *(f32x4 *)(dst + 8 * q) = v;
                                 vmaxp = fmaxf(vmaxp, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
                             }
                         }
@@ -1403,11 +1414,11 @@ void resnet_stem_mfma_kernel(const uint8_t *__restrict__ img /*[B,120,120,3]*/, 
     if (POOL && stat) range_note(stat, vmaxp);
 }
 
-bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s, int pool, float *stat) {
+bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s, int pool, float *stat, int out_pair) {
     if (!img8 || !As3) return false;
     constexpr int U = 2;
     const int wgs = (B + U - 1) / U;
-    if (pool) resnet_stem_mfma_kernel<U, true><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B, stat);
+    if (pool) resnet_stem_mfma_kernel<U, true><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B, stat, out_pair);
     else resnet_stem_mfma_kernel<U><<<wgs < 256 ? wgs : 256, (2 * U + 1) * 64, 0, s>>>(img8, As3, s_shift, out, B);
     return true;
 }

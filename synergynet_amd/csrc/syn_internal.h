@@ -167,14 +167,21 @@ void launch_crop_resize(const uint8_t *frame, int H, int W, const int *box, cons
 
 // ---- ResNet-50 variant (resnet_kernels.hip) ----
 // implicit-GEMM conv, NHWC: W [Npad][KH*KW*Cin] (tap-major), act 0 none / 1 ReLU after the optional residual add
+// ResNet-50 activation formats (resnet_kernels.hip "pair format"): inside an fp16 x2 forward every tensor a convolution consumes is stored by
+// its producer as the two fp16 pieces of the consumer's MFMA operands ([pixel][32-channel chunk][32 high halves | 32 low halves]); `fmt` is a
+// bit set: kFmtOutPair = the output is written in that format, kFmtResPair = the residual is read in it (else fp32 NHWC).
+constexpr int kFmtOutPair = 1, kFmtResPair = 2;
+// exact fp32-MFMA convolution; in_pair: the input is in the pair format (an fp16 x2 forward), else fp32.  N % 64 == 0.
 void launch_conv(const float *in, const float *W, const float *scale, const float *shift, const float *residual, float *out,
                  int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, hipStream_t s,
-                 float *stat = nullptr /* range-guard slot of the output, see launch_conv_f16x2 */);
-// same conv on the bf16 matrix pipe (exact 3-way operand split): W3 [N/16][taps*Cin/32][3][64][4] dwords, Cin % 32 == 0
+                 float *stat = nullptr /* range-guard slot of the output, see launch_conv_f16x2 */, int in_pair = 0, int fmt = 0);
+// same conv on the fp16 matrix pipe (two-piece operand split, three products): W3 [N/16][taps*Cin/32][2][64][4] dwords, output channels in pair order,
+// Cin % 64 == 0, N % 64 == 0; the input is in the pair format
 // stat (nullable): one float of the per-forward range-guard array -- max |output| is folded into it (resnet_kernels.hip range_note)
 void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                      float *out, int B, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
-                     hipStream_t s, float *stat = nullptr, int lt = 0 /* 1: the LDS-tiled kernel where its shape fits (N % 128 == 0, M >= 4096); 2: ... 128-pixel tiles only */);
+                     hipStream_t s, float *stat = nullptr, int lt = 0 /* 1: the LDS-tiled kernel where its shape fits (N % 128 == 0, M >= 4096); 2: ... 128-pixel tiles only */,
+                     int fmt = kFmtOutPair);
 // window of a tensor's max |x| inside which the fp16 x2 split of an UNSCALED activation keeps >= 15 bits relative to that maximum:
 // above kRangeHi v_cvt_pkrtz_f16_f32 saturates, below kRangeLo even the largest element's low piece is a 4-bit subnormal
 constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10
@@ -182,12 +189,12 @@ constexpr float kRangeHi = 6.0e4f, kRangeLo = 9.765625e-4f;      // 2^-10
 // launchers receive the tensor's base pointer
 constexpr int kRangeSub = 64, kRangeStride = 64;
 // conv3 + BN + identity + ReLU of a bottleneck fused with the next bottleneck's conv1 + BN + ReLU (resnet_kernels.hip conv_c3f_kernel).
-// W3: conv3's fp16 x2 fragments as launch_conv_f16x2 takes them; W1f: the next conv1's weights x its power of two S1, two fp16 pieces,
-// chunk-major in the D-register K order [Cin/64][step 2][N1/16][piece 2][lane 64][4 dwords]: lane (row l&15, kg = l>>4) slot e of step s =
-// input channel 64 c + 16 (2 s + (e >> 2)) + 4 kg + (e & 3).  false: this (K, N1) combination is not instantiated -- launch the two separately.
+// W3: conv3's fp16 x2 fragments as launch_conv_f16x2 takes them; W1f: the next conv1's fragments step-major [Cin/32][N1/16][piece 2][lane 64][4 dwords]
+// (natural K order: in pair order conv3's accumulators are conv1's operand).  T2 / out / T1n in the pair format, identity in it (res_pair) or fp32.
+// false: this (K, N1) combination is not instantiated -- launch the two separately.
 bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                      const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
-                     hipStream_t s, float *stat3, float *stat1);
+                     hipStream_t s, float *stat3, float *stat1, int res_pair);
 // ... with the block's downsample branch (1x1 conv + BN on the block input X [M, Kd]) evaluated in the same kernel instead of read as identity
 // (layer1.0: Kd = 64, stride 1); Wd: the downsample conv's fragments as launch_conv_f16x2 takes them.  false: not this shape.
 bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
@@ -201,8 +208,8 @@ void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const 
 constexpr int rn_stem_dwords() { return 2 * 10 * 2 * 256 + 64 + 4; }
 // pool != 0: the 3x3 / 2 max-pool in the epilogue, out = [B,30,30,64] (stat: range-guard slot of the pooled tensor, nullable)
 bool launch_resnet_stem_mfma(const uint8_t *img8, const unsigned *As3, const float *s_shift, float *out, int B, hipStream_t s, int pool = 0,
-                             float *stat = nullptr);
-void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat = nullptr);
+                             float *stat = nullptr, int out_pair = 0 /* pool: the pooled tensor in the pair format */);
+void launch_maxpool3x3s2(const float *in, float *out, int B, int Hin, int Hout, int C, hipStream_t s, float *stat = nullptr, int out_pair = 0);
 void launch_pool_fc_generic(const float *feat, const float *Wfc, const float *bias, float *param, float *pool, int B, int P,
                             int C, int n_out, int out_stride, hipStream_t s, const float *stat = nullptr, int n_stat = 0,
                             unsigned *guard_word = nullptr /* host-mapped word: set to 1 by a forward the range guard poisoned */);

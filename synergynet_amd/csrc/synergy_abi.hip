@@ -192,7 +192,7 @@ struct RConv {
     int cin, cout, k, stride, pad, hin, hout;
     size_t src_w, dst_w, dst_scale, dst_shift, dst_w3;   // dst_w3: fp16 x2 split scaled by a power of two, MFMA lane order (dwords), then {S, 1/S}
     size_t dst_wrm = 0;                                   // stem only: fragments + folded shift of resnet_stem_mfma_kernel
-    size_t dst_w1f = 0;                                   // conv1 of a block that follows another block: its weights in the K order of conv_c3f_kernel (dwords), or 0
+    size_t dst_w1f = 0;                                   // conv1 of a block that follows another block: its fragments step-major for conv_c3f_kernel (dwords), or 0
 };
 struct RBlock { int c1, c2, c3, ds; };
 struct ResNet50 {
@@ -266,7 +266,7 @@ struct ConstHeader {   // first 256 bytes of an exported constants buffer
 };
 static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
 constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
-constexpr uint32_t kConstVersion = 4;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring; 4: clamp-form constants of the register-resident blocks)
+constexpr uint32_t kConstVersion = 5;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring; 4: clamp-form constants of the register-resident blocks; 5: ResNet-50 fragments with the output channels in pair order)
 
 // verdict of the load-time range analysis of the fp16 x2 schedule (analyze_mbv2_ranges below); 64 dwords at Net::dst_range
 struct RangeInfo {
@@ -748,43 +748,52 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         stat = h->d_range;
         HIP_TRY(hipMemcpyAsync(stat, stat + kRangeFloats, kRangeFloats * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    auto conv = [&](int ci, const float *in, const float *res, float *out, int act) {
+    // f16: every tensor a convolution consumes travels in the PAIR format (resnet_kernels.hip) -- the max-pool output, the bottleneck
+    // intermediates T1 / T2, the block outputs X / Y; fp32 stay the downsample branch D (only ever a residual) and the last block's output
+    // (the pool reads it).  An fp32 handle (fusion < 2, or after a range event) keeps everything fp32.
+    const int PF = f16 ? 1 : 0;
+    // DEBUG knob (tests only): SYN_RESNET_EXACT_MASK = hex bit set of convolutions forced onto the exact kernel inside an fp16 x2 forward
+    static const unsigned long long force_exact = getenv("SYN_RESNET_EXACT_MASK") ? strtoull(getenv("SYN_RESNET_EXACT_MASK"), nullptr, 16) : 0ull;
+    auto unsafe_w = [&](int ci) { return ((force_exact >> ci) & 1ull) || (h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u)); };
+    auto conv = [&](int ci, const float *in, const float *res, float *out, int act, int out_pair, int res_pair) {
         const RConv &c = n.convs[ci];
-        if (f16 && c.dst_w3 && !(h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u))) {
+        const int fmt = (PF && out_pair ? syn::kFmtOutPair : 0) | (PF && res_pair ? syn::kFmtResPair : 0);
+        if (f16 && c.dst_w3 && !unsafe_w(ci)) {
             syn::launch_conv_f16x2(in, reinterpret_cast<const unsigned *>(P + c.dst_w3), P + c.dst_scale, P + c.dst_shift, res, out, B,
                                  c.hin, c.hout, c.cin, c.cout, c.k, c.k, c.stride, c.pad, act, s,
-                                 stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr, h->resnet_gemm);
+                                 stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr, h->resnet_gemm, fmt);
             return;
         }
-        // (a convolution whose WEIGHTS failed the fp16 criterion runs the exact kernel, but a later fp16 x2 convolution still splits its
-        // output: it reports into its slot like the others -- left at 0 the slot read as "below the window" on every forward)
+        // (a convolution whose WEIGHTS failed the fp16 criterion runs the exact kernel, but a later fp16 x2 convolution still takes its
+        // output as pieces: it reports into its slot like the others -- left at 0 the slot read as "below the window" on every forward)
         syn::launch_conv(in, P + c.dst_w, P + c.dst_scale, P + c.dst_shift, res, out, B, c.hin, c.hout, c.cin, c.cout, c.k, c.k,
-                         c.stride, c.pad, act, s, stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr);
+                         c.stride, c.pad, act, s, stat && resnet_stat_used(1 + ci) ? range_slot(stat, 1 + ci) : nullptr, PF, fmt);
     };
     const RConv &st = n.convs[0];
     // conv1+bn1+relu (:231-233): uint8 crops on the bf16 matrix pipe (batches that give every CU a workgroup), else the direct kernel
     // (the max-pool, :234, rides in the matrix-pipe stem's epilogue: the 60x60x64 tensor never exists)
     if (h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) && h->resnet_fuse &&
-        syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, X, B, s, 1, stat)) {
+        syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, X, B, s, 1, stat, PF)) {
     } else {
         if (!(h->fusion >= 2 && img8 && B >= 128 && (h->early_rm & 16) &&
               syn::launch_resnet_stem_mfma(img8, reinterpret_cast<const unsigned *>(P + st.dst_wrm), P + st.dst_wrm + 2 * 10 * 2 * 256, A, B, s)))
             syn::launch_resnet_stem(img, img8, P + st.dst_w, P + st.dst_scale, P + st.dst_shift, A, B, s);
-        syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat);                                          // maxpool (:234)
+        syn::launch_maxpool3x3s2(A, X, B, 60, 30, 64, s, stat, PF);                                      // maxpool (:234)
     }
     // Bottleneck.forward (:114-136).  Where conv3 of a block and conv1 of the next can run as ONE launch (conv_c3f_kernel: layer 1, whose
     // convolutions are bound by memory throughput), the block output is not read back as conv1's operand and T1 already holds the next
     // block's conv1 output when its turn comes.
     bool have_t1 = false;
-    auto unsafe_w = [&](int ci) { return h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u); };
     for (size_t bi = 0; bi < n.blocks.size(); ++bi) {
         const RBlock &b = n.blocks[bi];
-        if (!have_t1) conv(b.c1, X, nullptr, T1, 1);
-        conv(b.c2, T1, nullptr, T2, 1);
+        const bool last = bi + 1 == n.blocks.size();
+        if (!have_t1) conv(b.c1, X, nullptr, T1, 1, 1, 0);
+        conv(b.c2, T1, nullptr, T2, 1, 1, 0);
         have_t1 = false;
         const float *identity = X;
+        int id_pair = 1;                                   // the block input is a block output / the pooled stem: pair format in an fp16 x2 forward
         bool ds_done = b.ds < 0;
-        if (f16 && h->resnet_fuse && bi + 1 < n.blocks.size()) {
+        if (f16 && h->resnet_fuse && !last) {
             const RConv &c3 = n.convs[b.c3], &c1n = n.convs[n.blocks[bi + 1].c1];
             if (c3.dst_w3 && c1n.dst_w1f && c1n.hin == c3.hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[bi + 1].c1)) {
                 const float *s1 = P + c1n.dst_w3 + (size_t)(c1n.cout / 16) * (c1n.cin / 32) * 512;      // device {S, 1/S} of the next conv1's weights
@@ -800,15 +809,15 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                                                                 M, c3.cin, cd.cin, c3.cout, c1n.cout, s, st3, st1);
                 }
                 if (!have_t1) {
-                    if (!ds_done) { conv(b.ds, X, nullptr, D, 0); identity = D; ds_done = true; }
+                    if (!ds_done) { conv(b.ds, X, nullptr, D, 0, 0, 0); identity = D; id_pair = 0; ds_done = true; }
                     have_t1 = syn::launch_conv_c3f(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, identity, Y,
                                                    reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
-                                                   M, c3.cin, c3.cout, c1n.cout, s, st3, st1);
+                                                   M, c3.cin, c3.cout, c1n.cout, s, st3, st1, id_pair);
                 }
             }
         }
-        if (!ds_done) { conv(b.ds, X, nullptr, D, 0); identity = D; }
-        if (!have_t1) conv(b.c3, T2, identity, Y, 1);      // out = relu(bn3(conv3) + identity)
+        if (!ds_done) { conv(b.ds, X, nullptr, D, 0, 0, 0); identity = D; id_pair = 0; }
+        if (!have_t1) conv(b.c3, T2, identity, Y, 1, last ? 0 : 1, id_pair);      // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;
     }
     // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
@@ -1585,7 +1594,10 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                 for (int st = 0; st < steps; ++st)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int d = 0; d < 4; ++d) {
-                            const int nn = nt * 16 + (lane & 15);
+                            // MFMA row rho = lane & 15 of tile nt: the output channel in PAIR ORDER (resnet_kernels.hip: a lane's accumulators of tiles
+                            // 2 b, 2 b + 1 are eight consecutive channels = one 16-byte piece of the pair format)
+                            const int rho = lane & 15;
+                            const int nn = 32 * (nt >> 1) + 8 * (rho >> 2) + 4 * (nt & 1) + (rho & 3);
                             const int k0 = (st / kch) * c.cin + (st % kch) * 32 + 8 * (lane >> 4) + 2 * d;
                             const float x0 = dw[(size_t)nn * K + k0] * S, x1 = dw[(size_t)nn * K + k0 + 1] * S;
                             const unsigned a0 = f16_rtz(x0), a1 = f16_rtz(x1);
@@ -1594,27 +1606,13 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
                             dp[((((size_t)nt * steps + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
                         }
         }
-        if (c.dst_w1f) {   // the same weights x S for conv_c3f_kernel: chunk-major, K slots in the D-register order of the producing conv3
+        if (c.dst_w1f) {   // the same fragments for conv_c3f_kernel, step-major: [k32 step][tile][piece 2][lane][4] (a copy of dst_w3's [tile][step][...])
             unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + c.dst_w1f);
-            const float S = (pk.data() + c.dst_w3 + (size_t)(c.cout / 16) * (c.cin / 32) * 512)[0];
-            const int nt1 = c.cout / 16;
-            for (int cc = 0; cc < c.cin / 64; ++cc)
+            const unsigned *sp = reinterpret_cast<const unsigned *>(pk.data() + c.dst_w3);
+            const int nt1 = c.cout / 16, kch1 = c.cin / 32;
+            for (int kc = 0; kc < kch1; ++kc)
                 for (int i1 = 0; i1 < nt1; ++i1)
-                    for (int sk = 0; sk < 2; ++sk)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int d = 0; d < 4; ++d) {
-                                const int nn = 16 * i1 + (lane & 15), kg = lane >> 4;
-                                float x[2];
-                                for (int e2 = 0; e2 < 2; ++e2) {
-                                    const int e = 2 * d + e2;
-                                    x[e2] = dw[(size_t)nn * c.cin + 64 * cc + 16 * (2 * sk + (e >> 2)) + 4 * kg + (e & 3)] * S;
-                                }
-                                const unsigned a0 = f16_rtz(x[0]), a1 = f16_rtz(x[1]);
-                                const unsigned b0 = f16_rtz(x[0] - f16_value(a0)), b1 = f16_rtz(x[1] - f16_value(a1));
-                                const size_t frag = ((size_t)(cc * 2 + sk) * nt1 + i1) * 2;
-                                dp[((frag + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
-                                dp[((frag + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
-                            }
+                    memcpy(dp + ((size_t)kc * nt1 + i1) * 512, sp + ((size_t)i1 * kch1 + kc) * 512, 512 * sizeof(unsigned));
         }
         for (int ch = 0; ch < c.cout; ++ch) {
             const float a = gamma[ch] * (1.0f / sqrtf(var[ch] + 1e-5f));
