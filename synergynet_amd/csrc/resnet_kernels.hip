@@ -741,6 +741,180 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     conv_epilogue<MTW, 4>(acc, scale, shift, inv_s, residual, out, M, N, mw, nw, r16, g, act, fmt, stat);
 }
 
+// =====================================================================================
+// conv_lp_kernel (round 6): conv_lt_kernel's tile and fragment images, as a PIPELINE.  What conv_lt_kernel's phase profile shows (LT_PROF, layer 3's
+// conv2: fragment reads 1150 + parking 400 + load issue 600 + matrix issue 900 + barrier 90 = 3190 cycles per step against 1536 on the matrix pipe)
+// is eight waves in lockstep: LDS bandwidth (128 KB of fragment reads + 48 KB of parking writes per step and CU) and the vector memory
+// pipe (48 KB per step) are busy while the matrix pipe idles, and the other way round.  Deferring a third of a step's MFMAs past the
+// barrier changed nothing (100.3 vs 100.7 us): an in-order wave that is issuing MFMAs issues no memory instruction, so nothing new is in
+// flight under them.  Memory work must be ISSUED before the MFMAs that cover it and must not need registers they use:
+//   * both operands go global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction into a lane-linear image): no register
+//     ring, no parking writes, no vector instructions but the address arithmetic; three stages of 48 / 32 KB, a stage is refilled for step
+//     s + 3 right after the barrier that ends step s - 1's reads of it: loads two steps ahead, counted vmcnt (4 / 6 per step stay in flight);
+//   * the fragments of step s + 1 are read into a SECOND register set (the 48 registers of the ring pay for it) right after the barrier
+//     of step s, before its 48 MFMAs: the reads run under them; one barrier per step as before.
+// Activation fragment images: FRAG as conv_lt_kernel (a plane per instruction); !FRAG: whole 128-byte lines (8 pixels per instruction,
+// lane = pixel l >> 3, 16-byte chunk (l & 7) ^ (pixel & 6) -- the swizzle sits in the per-lane GLOBAL address, the LDS image stays
+// lane-linear), fragment entry (pixel r, k-group g, piece p) at 16-byte slot 64 (r >> 3) + 8 (r & 7) + ((4 p + g) ^ (r & 6)): conflict-free
+// in the read lane groups.  Same K order and product order as conv_lt_kernel / conv_h2s_kernel: the same bits.
+// =====================================================================================
+template <int MTW, bool FRAG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3, const float *__restrict__ scale,
+                    const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ out, int M, int Hin,
+                    int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, int n_tiles, int m_tiles,
+                    float *__restrict__ stat, unsigned in_bytes, int fmt) {
+#if __HIP_DEVICE_COMPILE__      // (the HOST pass silently drops the kernel's launch stub when it has to instantiate this body -- the generic lambdas over device builtins; it only needs the signature)
+    constexpr int PT = 4 * MTW, U = MTW / 2, NS = 3;
+    static_assert(MTW == 2 || MTW == 4, "128 | 256 pixels per workgroup");
+    constexpr int BF_DW = PT * 512, AF_DW = 8 * 512, ST_DW = BF_DW + AF_DW;      // one stage: activation | weight fragments
+    constexpr int G = 2 * U + 2;                                                 // LDS-direct loads per wave and step
+    __shared__ __attribute__((aligned(16))) unsigned sm[NS * ST_DW];             // (ONE shared object: a second one makes the compiler drain vmcnt before every ds_read)
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nt_idx = q % n_tiles;
+    const int mt_idx = (q / n_tiles) * 8 + xcd;                  // the channel tiles of one pixel tile share an XCD's L2
+    if (mt_idx >= m_tiles) return;                               // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = mt_idx * (PT * 16);
+    const int n0 = nt_idx * 128;
+    const int KCH = Cin >> 5, steps = KH * KW * KCH;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int sp = lane >> 3, sc = lane & 7;
+    int py[U][2], px[U][2];                                       // [u][h]; FRAG: h = 0 only
+    unsigned pbase[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int h = 0; h < (FRAG ? 1 : 2); ++h) {
+            int m = m0 + (wave * U + u) * 16 + (FRAG ? r16 : 8 * h + sp);
+            m = m < M ? m : M - 1;                               // (rows past the end: clamped loads, no stores)
+            const int hw = Hout * Hout;
+            const int pbi = m / hw;
+            const int r = m - pbi * hw;
+            py[u][h] = (r / Hout) * stride - pad;
+            px[u][h] = (r % Hout) * stride - pad;
+            const int chunk = FRAG ? g : (sc ^ (sp & 6));
+            pbase[u][h] = (unsigned)(((pbi * Hin + py[u][h]) * Hin + px[u][h]) * Cin + 4 * chunk) * 4u;     // (wraps for padding rows: only used when the tap is inside)
+        }
+    int roff[2];                                                  // dword offset inside a tile of this lane's fragment entry of piece p
+#pragma unroll
+    for (int p = 0; p < 2; ++p) roff[p] = FRAG ? p * 256 + lane * 4 : (r16 >> 3) * 256 + ((r16 & 7) * 8 + ((4 * p + g) ^ (r16 & 6))) * 4;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(W3), 0, 0x7fffffff, 0x00027000);
+    const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
+    f32x4 acc[MTW][4];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = z4;
+    const unsigned wbase = (unsigned)((n0 / 16 + wave) * steps) * 2048u;        // this wave's channel tile: both pieces of a step (bytes)
+    const unsigned l16 = lane * 16;
+    // the fetch pointer walks the steps in order: (tap row, tap column, k32 chunk) as running scalars; past the last step it stays there
+    // (the last loads re-fetch it into stages nobody reads).  A tap outside the image: an offset past the end of the tensor = zeros.
+    int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0, w_s = 0;
+    unsigned goff[U][2];                                          // byte offsets of the step the fetch pointer is at
+    unsigned gw = 0;
+    auto prepare = [&]() {                                       // the addresses of the fetch pointer's step; the pointer moves on
+        const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * Cin + f_kc * 32) * 4u;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < (FRAG ? 1 : 2); ++h) {
+                const int iy = py[u][h] + f_ky, ix = px[u][h] + f_kx;
+                const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+                goff[u][h] = ok ? pbase[u][h] + dlt : 0x80000000u;
+            }
+        const int adv = f_s + 1 < steps ? 1 : 0;
+        f_s += adv;
+        f_kc += adv;
+        const int c1 = f_kc == KCH ? 1 : 0;
+        f_kc = c1 ? 0 : f_kc;
+        f_kx += c1;
+        const int c2 = f_kx == KW ? 1 : 0;
+        f_kx = c2 ? 0 : f_kx;
+        f_ky += c2;
+        gw = __builtin_amdgcn_readfirstlane(wbase + w_s * 2048);      // (uniform by construction; said so, or the prologue gets a waterfall loop)
+        w_s += w_s + 1 < steps ? 1 : 0;
+    };
+    auto issue_k = [&](int so, auto k_c) {                       // load k of the G of a step into the stage at dword offset so
+        constexpr int K = decltype(k_c)::value;
+        if constexpr (K < 2 * U) {
+            constexpr int u = K / 2, e = K % 2;                  // e: FRAG piece | row-shaped: pixel half
+            if (FRAG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][0], 64 * e, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][e], 0, 0, 0);
+        } else {
+            constexpr int pz = K - 2 * U;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sm + so + BF_DW + (wave * 2 + pz) * 256), 16, l16, gw + pz * 1024, 0, 0);
+        }
+    };
+    auto issue = [&](int so) { prepare(); static_for<G>([&](auto k) { issue_k(so, k); }); };
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    u32x4 wa[2][4][2], bp[2][MTW][2];                             // two fragment sets: step parity
+    constexpr int NR = 8 + 2 * MTW, NM = 12 * MTW;                // fragment reads / MFMAs of a wave and step
+    auto read_k = [&](int so, auto set_c, auto k_c) {            // read k of the NR of a step: weights low, activations high, weights high, activations low
+        constexpr int S = decltype(set_c)::value, K = decltype(k_c)::value;
+        const unsigned *b = sm + so;
+        if constexpr (K < 4) wa[S][K][1] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + K) * 2 + 1) * 256 + lane * 4);
+        else if constexpr (K < 4 + MTW) bp[S][K - 4][0] = *(const u32x4 *)(b + (wm * MTW + K - 4) * 512 + roff[0]);
+        else if constexpr (K < 8 + MTW) wa[S][K - 4 - MTW][0] = *(const u32x4 *)(b + BF_DW + ((wn * 4 + K - 4 - MTW) * 2 + 0) * 256 + lane * 4);
+        else bp[S][K - 8 - MTW][1] = *(const u32x4 *)(b + (wm * MTW + K - 8 - MTW) * 512 + roff[1]);
+    };
+    auto mfma_k = [&](auto set_c, auto k_c) {                    // MFMA k of the NM of a step: product-major, (w lo, a hi), (w hi, a hi), (w hi, a lo): every kernel's order
+        constexpr int S = decltype(set_c)::value, K = decltype(k_c)::value;
+        constexpr int t = K / (4 * MTW), j = (K % (4 * MTW)) / 4, i = K % 4;
+        constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 0, 1};
+        acc[j][i] = mm(wa[S][i][pa[t]], bp[S][j][pbk[t]], acc[j][i]);
+    };
+    // A step, in G chunks: NM / G MFMAs of step s (registers of set SET_THIS), then ONE load of step s + 3 and NR / G fragment reads of step
+    // s + 1 -- the loads cost an in-order wave 60 - 180 cycles of issue each (MI355X_MICROARCH: LDS-DMA issue cost); in a block in front of
+    // the MFMAs they left the matrix pipe idle, behind 8 queued MFMAs each they are covered (SYN_LP_INTERLEAVE=0: the block form).
+    // Before it: the stage of step s + 1 has landed (own loads: counted vmcnt -- G stay in flight -- then everybody's: barrier), this wave's
+    // fragments of step s are in registers (lgkmcnt 0: every wave is done with the stage of step s before the barrier -> refill it).
+#ifndef SYN_LP_INTERLEAVE
+#define SYN_LP_INTERLEAVE 1
+#endif
+    auto step = [&](int o_this, int o_next, auto set_this, auto set_next) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
+        prepare();
+        if (SYN_LP_INTERLEAVE) {
+            static_for<G>([&](auto c) {
+                constexpr int C = decltype(c)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NM / G>([&](auto k) { mfma_k(set_this, std::integral_constant<int, C * (NM / G) + decltype(k)::value>{}); });
+                __builtin_amdgcn_sched_barrier(0);
+                issue_k(o_this, c);
+                static_for<(C + 1) * NR / G - C * NR / G>([&](auto k) { read_k(o_next, set_next, std::integral_constant<int, C * NR / G + decltype(k)::value>{}); });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            static_for<G>([&](auto k) { issue_k(o_this, k); });
+            static_for<NR>([&](auto k) { read_k(o_next, set_next, k); });
+            static_for<NM>([&](auto k) { mfma_k(set_this, k); });
+        }
+    };
+    int o0 = 0, o1 = ST_DW, o2 = 2 * ST_DW;
+    issue(o0);
+    issue(o1);
+    issue(o2);
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");    // stage 0 has landed
+    static_for<NR>([&](auto k) { read_k(o0, std::integral_constant<int, 0>{}, k); });
+    for (int s0 = 0; s0 < steps; s0 += 2) {                      // (steps is even: launcher)
+        step(o0, o1, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        step(o1, o2, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        const int t = o2; o2 = o1; o1 = o0; o0 = t;              // stages of steps s + 2, s + 3, s + 4
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the clamped leftovers: nothing may land in LDS after the workgroup is gone)
+    const int mw = m0 + wm * (MTW * 16), nw = n0 + wn * 64;
+    if (mw >= M) return;
+    conv_epilogue<MTW, 4>(acc, scale, shift, inv_s, residual, out, M, N, mw, nw, r16, g, act, fmt, stat);
+#endif
+}
+
 template <int MTW>
 static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,
                              float *out, int M, int Hin, int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act,
@@ -749,10 +923,16 @@ static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *s
     const int m_tiles = (M + 64 * MTW - 1) / (64 * MTW);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
-    static const int shape = getenv("SYN_LT_STAGE") ? atoi(getenv("SYN_LT_STAGE")) : -1;        // A/B knob: 0 / 1 forces the row- / plane-shaped staging loads
+    static const int shape = getenv("SYN_LT_STAGE") ? atoi(getenv("SYN_LT_STAGE")) : -1;      // A/B knob: 0 / 1 forces the row- / plane-shaped staging loads
+    static const int glds = getenv("SYN_LT_GLDS") ? atoi(getenv("SYN_LT_GLDS")) : 1;         // A/B knob: 0 = conv_lt_kernel everywhere, 1 = conv_lp_kernel for 256-pixel tiles, 2 = for both
     const bool frag = shape < 0 ? KH * KW > 1 : shape != 0;       // plane-shaped loads where the taps re-read the activations from L2
-    if (frag) conv_lt_kernel<MTW, true><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, in_bytes, fmt);
-    else conv_lt_kernel<MTW, false><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, in_bytes, fmt);
+    // 128-pixel tiles: three 32 KB stages are one workgroup per CU, which the short-K convolutions (conv3, downsample: their time is the epilogue)
+    // pay for -- layer 3 conv3 89 -> 100 us -- and the long-K ones gain from (layer 4 conv1 / conv2 53 -> 48, 100 -> 93)
+    const bool lp = MTW == 4 ? glds >= 1 : (glds >= 2 || (glds == 1 && KH * KW * (Cin / 32) >= 32));
+#define SYN_LT_LAUNCH(K, F) K<MTW, F><<<grid, 512, 0, s>>>(in, W3, scale, shift, residual, out, M, Hin, Hout, Cin, N, KH, KW, stride, pad, act, n_tiles, m_tiles, stat, in_bytes, fmt)
+    if (lp) { if (frag) SYN_LT_LAUNCH(conv_lp_kernel, true); else SYN_LT_LAUNCH(conv_lp_kernel, false); }
+    else { if (frag) SYN_LT_LAUNCH(conv_lt_kernel, true); else SYN_LT_LAUNCH(conv_lt_kernel, false); }
+#undef SYN_LT_LAUNCH
 }
 
 template <int MT, int NT>
@@ -822,13 +1002,14 @@ struct DsArgs {
     const unsigned *Wd;         // downsample conv's fp16 x2 fragments [N3/16][2][2][64][4], {S, 1/S}
     const float *scale_d, *shift_d;
 };
-template <int KS3, int NT1, int MT, int TC, bool DS = false>
+template <int KS3, int NT1, int MT, int TC, bool DS = false, bool RP = true /* identity in the pair format (else fp32) */>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
                      const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3], pairs or fp32 (res_pair)*/,
                      float *__restrict__ out /*[M, N3] pairs*/, const unsigned *__restrict__ W1f /*[N3/32][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
                      const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1] pairs*/, int M, int N3,
-                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, int res_pair, DsArgs ds = DsArgs{}) {
+                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, DsArgs ds = DsArgs{}) {
+    constexpr bool res_pair = RP;
     // TC = output-channel tiles of conv3 per chunk (4: 64 channels = two k32 steps of conv1; 2: 32 channels = one -- half the LDS per chunk
     // for the wider layers)
     constexpr int K = 32 * KS3, N1 = 16 * NT1, CW = 16 * TC, S1 = TC / 2;
@@ -1031,7 +1212,8 @@ static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale
                          const unsigned *W1f, const float *s1, const float *scale1, const float *shift1, float *T1n, int M, int N3, hipStream_t s,
                          float *stat3, float *stat1, int res_pair) {
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
-    conv_c3f_kernel<KS3, NT1, MT, TC><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, res_pair);
+    if (res_pair) conv_c3f_kernel<KS3, NT1, MT, TC, false, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
+    else conv_c3f_kernel<KS3, NT1, MT, TC, false, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
 }
 
 // ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0.  Every tensor in the pair format.
@@ -1041,7 +1223,7 @@ bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3
     if (K != 64 || Kd != 64 || N3 != 256 || N1 != 64) return false;
     const DsArgs ds{X, Wd, scale_d, shift_d};
     const int m_tiles = (M + 127) / 128, grid = ((m_tiles + 7) / 8) * 8;
-    conv_c3f_kernel<2, 4, 2, 2, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, 0, ds);      // (32-channel chunks: with 64 the second B operand spills)
+    conv_c3f_kernel<2, 4, 2, 2, true, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);      // (32-channel chunks: with 64 the second B operand spills)
     return true;
 }
 
