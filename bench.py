@@ -78,7 +78,8 @@ def cpu_baseline(sd, pack, budget_s=26.0):
     (oracle/ref_loader.py imports it from where it lies).  kind "port": the GPU box has no /root/reference -> the oracle's
     restatement of the same torch-CPU / numpy calls (oracle/backbone_torch.py, oracle/recon_numpy.py).
     Two variants: (i) the loop body of get_all_outputs per face (B = 1 forward_test + numpy sparse / dense vertices + pose,
-    synergy3DMM.py:194-201) and (ii) best-case batched (forward_test(B = 64) + reconstruct_vertex_62 sparse and dense).
+    synergy3DMM.py:194-201) and (ii) best-case batched (forward_test(B = 128) + reconstruct_vertex_62 sparse and dense): BASELINE.md
+    section 2's B = 1 and B = 128 (B = 1024 does not fit the time slice of a default bench run).
     Protocol: fp32, no_grad, eval; per thread count 2 warm-up iterations, then the median of >= 10 timed iterations
     (fewer only if the time slice runs out -- the count is reported); thread counts tried: all physical cores (BASELINE.md's
     protocol) and 32 / 16 / 8 (small convolutions do not scale to 128 threads); `value` = the best batched rate."""
@@ -87,7 +88,7 @@ def cpu_baseline(sd, pack, budget_s=26.0):
     model_name, phys = _cpu_info()
     phys = phys or logical
     b = recon_numpy.Basis(pack)
-    Bc = 64
+    Bc = 128
     x = torch.from_numpy(synth.normalize_crops(synth.make_crops(Bc, seed=1)))
     roi = [0.0, 0.0, 120.0, 120.0, 1.0]
     kind = 'port'
@@ -708,6 +709,29 @@ def main():
                 extra['one_stream'] = rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=50, warmup=10)
         except Exception as e:
             extra['error'] = 'extras stopped at: ' + str(e)[:300]
+            torch.cuda.synchronize()
+        # a measured floor under arbitrary checkpoints: the headline runs the fp16x2 kernels because the synthetic weights pass
+        # the load-time range proof; a checkpoint that fails it runs the exact fp32-MFMA kernels block by block (reference behaviour being
+        # replaced: any checkpoint loads and answers, synergy3DMM.py:109-113,156-164).  Same step, one stream, B faces.
+        try:
+            one = OverlappedPipeline(model, overlap=False)
+            prev = lib.syn_set_schedule(model._h, 1)
+            try:
+                extra['exact_schedule'] = dict(rate(B, lambda: one.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=20, warmup=5),
+                                               what='syn_set_schedule(h, 1): EVERY block (and stem, head, reconstruction prologue) on the exact fp32-MFMA / fp32 kernels -- '
+                                                    'the schedule check_numerics() compares the default one against', numerics_fallback_blocks='all (forced)')
+            finally:
+                lib.syn_set_schedule(model._h, prev)
+            madv = SynergyNet(device=dev, pack=pack, backbone_state=synth.make_unprovable_backbone_state())
+            n_fb, _ = madv.numerics_report()
+            padv = OverlappedPipeline(madv, overlap=False)
+            extra['all_blocks_fallback'] = dict(rate(B, lambda: padv.submit(crops, rois, lmk_out=lmk, mesh_out=mesh), steps=20, warmup=5),
+                                                numerics_fallback_blocks=int(n_fb),
+                                                what='an adversarial checkpoint (synth.make_unprovable_backbone_state: every block\'s expand rows spread over 8 decades) '
+                                                     'whose blocks the load-time range proof rejects: default schedule, each rejected block on its exact kernel')
+            del madv, padv
+        except Exception as e:
+            extra['exact_schedule_error'] = str(e)[:300]
             torch.cuda.synchronize()
         # the documented entry point (reference synergy3DMM.py:167-207): frames + detections in, numpy landmarks / meshes / poses out,
         # through get_all_outputs (1 frame) and get_all_outputs_batch (16 frames); detections are given (the detector is timed in

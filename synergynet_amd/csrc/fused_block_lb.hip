@@ -138,6 +138,13 @@ struct LbCfg {
     static_assert((FPW == 4 || NS >= 4 ? 1 : 2) * LDS_DW * 4 <= 160 * 1024, "one 8-wave or two 4-wave workgroups per CU");
 };
 
+#ifndef SYN_LB_SHADOW
+#define SYN_LB_SHADOW 0               // 1: channel tile 1's expand MFMAs inside depthwise passes 0 / 1 (in-wave MFMA shadow: the round-6 experiment,
+                                     //    measured 252.9 against 249.0 us for the features.7-14 chain -- profiles/r6/mfma_shadow_experiment.txt); 0: rounds 2-5
+#endif
+#ifndef SYN_LB_SHADOW_PIN
+#define SYN_LB_SHADOW_PIN 7           // vector instructions pinned behind each shadowed MFMA (sched_group_barrier); 0: the compiler's own order
+#endif
 #ifndef SYN_LB_DW2
 #define SYN_LB_DW2 1                // 0: lane shifts on the input rows (rounds 2-4), for A/B runs
 #endif
@@ -304,6 +311,24 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) D[t][r] = es;
         }
+        // SYN_LB_SHADOW (round 6, VERDICT r5 #3 -- the in-wave interleave experiment): channel tile 0 of the group is expanded first (all k32 steps,
+        // four blocks = four accumulator chains); tile 1's 12 MFMAs per k32 step ride INSIDE depthwise passes 0 and 1 -- which read tile 0 only --
+        // so that this wave's vector instructions issue in the shadow of its own matrix instructions (tools/ubench/mfma_interleave.hip: two
+        // plain VALU hide behind a 16-cycle MFMA inside one wave).  No register of another group is needed; the block-input fragments are read
+        // twice.  Stages with EPF == KE == 2 (features.8-11).
+        constexpr bool SHADOW = SYN_LB_SHADOW && C::EPF == KE && KE == 2 && !C::S2;
+        auto expand_unit = [&](int kc, int t) __attribute__((always_inline)) {       // one k32 step of one channel tile: 12 MFMAs on D[t][0..3]
+            u32x4 Bx[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) Bx[r][p] = *(const u32x4 *)&Xf[((kc * 4 + r) * 2 + p) * 256 + lane * 4];
+            mac3x4(Ae[kc][t], Bx[0], D[t][0], Ae[kc][t], Bx[1], D[t][1], Ae[kc][t], Bx[2], D[t][2], Ae[kc][t], Bx[3], D[t][3]);
+        };
+        if constexpr (SHADOW) {
+#pragma unroll
+            for (int kc = 0; kc < KE; ++kc) { expand_unit(kc, 0); SYNL_FENCE(); }
+        } else {
 #pragma unroll
         for (int kc = 0; kc < KE; ++kc) {
             if (kc + C::EPF < KE) fetch_e(G, kc + C::EPF);
@@ -319,10 +344,12 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 SYNL_FENCE();
             }
         }
+        }
         // EPF == KE: the next group's expand fragments are requested HERE, into the registers the expand just stopped reading -- the depthwise
         // phase (~1600 cycles) and the project stand between the request and its use instead of the project alone (~800 cycles against an L2
         // round trip of about that: with the loads replaced by constants the chain runs 270 -> 252 us, this placement gets 6 of those 18)
-        if (C::EPF == KE && G + C::NS < gend) {
+        // (SHADOW: after depthwise pass 1, when tile 1 has stopped reading them)
+        if (!SHADOW && C::EPF == KE && G + C::NS < gend) {
 #pragma unroll
             for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
         }
@@ -341,6 +368,13 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
         for (int th = 0; th < 4; ++th) {
             const int t = th >> 1, hf = th & 1;
             if (th == 3) fetch_p(0);                    // first project fragments: in flight behind the last depthwise pass
+            if constexpr (SHADOW) {
+                if (th < 2) expand_unit(th, 1);        // tile 1, k32 step th: its MFMAs interleave with this pass's vector work (pattern below)
+                if (th == 2 && G + C::NS < gend) {
+#pragma unroll
+                    for (int kc = 0; kc < C::EPF; ++kc) fetch_e(G + C::NS, kc);
+                }
+            }
             const int c0 = 16 * t + 2 * hf;             // + 4 g per lane group
             f32x2 w[9];
 #pragma unroll
@@ -420,6 +454,15 @@ __device__ __forceinline__ void lb_stage(unsigned *smem, const LbStageArgs &sa, 
                 if (hf) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) asm volatile("" : "+v"(Bd[r][p]));
+                }
+            }
+            if constexpr (SHADOW && SYN_LB_SHADOW_PIN > 0) {
+                if (th < 2) {                           // 12 x (1 MFMA, SYN_LB_SHADOW_PIN vector instructions): the pass's ~95 VALU spread under the MFMAs
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, SYN_LB_SHADOW_PIN, 0);
+                    }
                 }
             }
             SYNL_FENCE();
@@ -1105,7 +1148,10 @@ template <bool WITH7, bool WITH14>
 __global__ __launch_bounds__(L8::NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_lb_kernel(LbChainArgs ca, int B) {
     unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tk = 0;
-    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDw];
+#ifndef SYN_LB_LDS_PAD
+#define SYN_LB_LDS_PAD 0              // experiment knob: extra LDS dwords (22000: one workgroup per CU = ONE wave per SIMD)
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned smem[kChainLdsDw + SYN_LB_LDS_PAD];
     // every stage's weights (2.6 MB for features.7-14) into this XCD's L2 before the walk starts (syn_internal.h l2_touch): the waves fetch their
     // fragments one group ahead, which covers an L2 hit but not the miss the first CU of an XCD takes on every group of a cold run
     // (B = 1024, interleaved on one box: 267.0 against 271.6 us without, gpurun_out/r5c3)

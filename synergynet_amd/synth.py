@@ -328,3 +328,25 @@ def make_frame(height: int, width: int, seed: int = 11) -> np.ndarray:
         cy, cx, r = rng.uniform(0.2, 0.8) * height, rng.uniform(0.2, 0.8) * width, rng.uniform(0.05, 0.15) * min(height, width)
         f += 90.0 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r))[:, :, None]
     return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+
+
+def make_unprovable_backbone_state(seed: int = 1234, decades: float = 8.0) -> dict:
+    """A MobileNetV2 checkpoint none of whose blocks passes the load-time range proof of the fp16x2 kernels (DESIGN 5.3): the output rows
+    of every block's first convolution (the expand 1x1; features.1: the depthwise-free project) are spread over `decades` orders of
+    magnitude with their BatchNorm shift zeroed, so the small rows lose their low fp16 piece to subnormals and the weight criterion
+    sends the block to the exact fp32-MFMA kernel.  A valid network (it computes something else than make_backbone_state's): what a user
+    of an unseen checkpoint gets AT WORST -- bench.py times it as `extra.all_blocks_fallback` (VERDICT r5 #5)."""
+    sd = {k: np.array(v, copy=True) for k, v in make_backbone_state(seed).items()}
+    rng = np.random.default_rng(seed + 77)
+    first = {}
+    for L in mbv2_layers():
+        if L['kind'] == 'pw' and 2 <= L['feature'] <= 17 and L['feature'] not in first:
+            first[L['feature']] = L
+    for f, L in first.items():
+        n = sd[L['key'] + '.weight'].shape[0]
+        sc = (10.0 ** rng.uniform(-decades, 0.0, n)).astype(np.float32)
+        sc[rng.integers(0, n)] = 1.0
+        sd[L['key'] + '.weight'] = sd[L['key'] + '.weight'] * sc[:, None, None, None]
+        sd[L['bn'] + '.bias'] = np.zeros(n, np.float32)
+        sd[L['bn'] + '.running_mean'] = np.zeros(n, np.float32)
+    return sd

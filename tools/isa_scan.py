@@ -69,6 +69,51 @@ def loop_sequences(text, want):
     return out
 
 
+def adjacency(text, want):
+    """Per kernel: how the matrix instructions sit among the vector instructions -- MFMAs followed directly by another MFMA, the MFMA bursts
+    (runs of back-to-back MFMAs: count, mean, max), the histogram of VALU instructions between two consecutive MFMAs (0 = back to back,
+    1-3 = in a shadow a 16-cycle MFMA can cover, >= 4 = a vector phase), and the VALU total.  (VERDICT r5 #3: the evidence next to a timing.)"""
+    out = {}
+    for fn in re.split(r'\n(?=_ZN3syn[^\n]*:\s*(?:;.*)?\n)', text):
+        m = re.match(r'(_ZN3syn\S+):', fn)
+        if not m:
+            continue
+        name = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()
+        short = re.sub(r'\(.*', '', name)
+        if want and not any(w in short for w in want):
+            continue
+        kinds = []
+        for l in fn.split('\n'):
+            t = l.strip().split(' ')[0] if l.strip() else ''
+            if t.startswith('v_mfma'):
+                kinds.append('M')
+            elif t.startswith('v_') and not t.startswith('v_accvgpr'):
+                kinds.append('V')
+            elif t.startswith(('ds_', 'buffer_', 'global_', 's_barrier', 's_waitcnt', 's_cbranch', 's_branch')):
+                kinds.append('o')
+        gaps, bursts, run, since = [], [], 0, None
+        for k in kinds:
+            if k == 'M':
+                if since is not None:
+                    gaps.append(since)
+                if since == 0 or since is None:
+                    run += 1
+                else:
+                    if run:
+                        bursts.append(run)
+                    run = 1
+                since = 0
+            elif k == 'V' and since is not None:
+                since += 1
+        if run:
+            bursts.append(run)
+        n_m = kinds.count('M')
+        hist = {'0': sum(g == 0 for g in gaps), '1-3': sum(1 <= g <= 3 for g in gaps), '4-8': sum(4 <= g <= 8 for g in gaps), '>8': sum(g > 8 for g in gaps)}
+        out[short] = dict(mfma=n_m, valu=kinds.count('V'), back_to_back=hist['0'], gaps=hist, bursts=len(bursts),
+                          burst_mean=round(sum(bursts) / max(1, len(bursts)), 1), burst_max=max(bursts) if bursts else 0)
+    return out
+
+
 def scan(text, want):
     for short, loops in loop_sequences(text, want).items():
         print('==', short[:140])
@@ -91,8 +136,13 @@ def compile_to_asm(src, defines=()):
 def main():
     if len(sys.argv) < 2:
         sys.exit(__doc__)
-    text = compile_to_asm(sys.argv[1], [a for a in sys.argv[2:] if a.startswith('-D')])
-    scan(text, [a for a in sys.argv[2:] if not a.startswith('-D')])
+    args = [a for a in sys.argv[2:] if a != '--adjacency']
+    text = compile_to_asm(sys.argv[1], [a for a in args if a.startswith('-D')])
+    if '--adjacency' in sys.argv:
+        for k, v in adjacency(text, [a for a in args if not a.startswith('-D')]).items():
+            print(k[:100], v)
+        return
+    scan(text, [a for a in args if not a.startswith('-D')])
 
 
 if __name__ == '__main__':
