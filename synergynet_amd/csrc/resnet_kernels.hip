@@ -1002,13 +1002,18 @@ struct DsArgs {
     const unsigned *Wd;         // downsample conv's fp16 x2 fragments [N3/16][2][2][64][4], {S, 1/S}
     const float *scale_d, *shift_d;
 };
-template <int KS3, int NT1, int MT, int TC, bool DS = false, bool RP = true /* identity in the pair format (else fp32) */>
+// C2F (round 6, layer 1): the bottleneck's conv2 (3x3, 32 KS3 -> 32 KS3 channels, pad 1) runs IN FRONT, in the same launch: the workgroup's
+// 128 pixels x 64 channels are accumulated exactly as conv_h2s_kernel<2, 4, 2> does it (weight chunks of two k32 steps through LDS -- the
+// region conv3's and conv1's chunks use afterwards --, activations from T1 by buffer loads one step ahead, out-of-range offset = padding),
+// BN + ReLU + split land in the registers conv3 takes its B operand from: T2 (118 MB written and read back per block at B = 512) never exists,
+// one launch less, and the matrix-heavy front of one workgroup runs beside the HBM-bound back of the other workgroup of its CU.
+template <int KS3, int NT1, int MT, int TC, bool DS = false, bool RP = true /* identity in the pair format (else fp32) */, bool C2F = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
+void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs (unused with C2F)*/, const unsigned *__restrict__ W3 /*[N3/16][KS3][2][64][4], {S, 1/S}*/,
                      const float *__restrict__ scale3, const float *__restrict__ shift3, const float *__restrict__ identity /*[M, N3], pairs or fp32 (res_pair)*/,
                      float *__restrict__ out /*[M, N3] pairs*/, const unsigned *__restrict__ W1f /*[N3/32][NT1][2][64][4]*/, const float *__restrict__ s1 /*{S, 1/S}*/,
                      const float *__restrict__ scale1, const float *__restrict__ shift1, float *__restrict__ T1n /*[M, 16 NT1] pairs*/, int M, int N3,
-                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, DsArgs ds = DsArgs{}) {
+                     int m_tiles, float *__restrict__ stat3, float *__restrict__ stat1, DsArgs ds = DsArgs{}, C2Args c2 = C2Args{}) {
     constexpr bool res_pair = RP;
     // TC = output-channel tiles of conv3 per chunk (4: 64 channels = two k32 steps of conv1; 2: 32 channels = one -- half the LDS per chunk
     // for the wider layers)
@@ -1017,9 +1022,11 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const u
     constexpr int NP3 = TC * KS3 * 2 / 4, NP1 = S1 * NT1 * 2 / 4;                // fragments per wave and chunk
     static_assert(TC == 2 || TC == 4, "a chunk is one or two k32 steps of conv1");
     static_assert((TC * KS3 * 2) % 4 == 0 && (S1 * NT1 * 2) % 4 == 0, "a quarter of a chunk per wave");
-    __shared__ __attribute__((aligned(16))) unsigned w3l[2 * W3C_DW];
-    __shared__ __attribute__((aligned(16))) unsigned w1l[2 * W1C_DW];
-    __shared__ __attribute__((aligned(16))) float sc3[512], sh3[512];
+    constexpr int NT2 = 2 * KS3, KSC = 2, CH2_DW = NT2 * KSC * 2 * 256, NPW2 = NT2 * KSC * 2 / 4;     // C2F: conv2's weight chunk (two k32 steps)
+    static_assert(!C2F || 2 * CH2_DW <= 2 * W3C_DW + 2 * W1C_DW, "conv2's weight chunks live where conv3's and conv1's do afterwards");
+    __shared__ __attribute__((aligned(16))) unsigned sm[2 * W3C_DW + 2 * W1C_DW + 1024];
+    unsigned *w3l = sm, *w1l = sm + 2 * W3C_DW;
+    float *sc3 = reinterpret_cast<float *>(sm + 2 * W3C_DW + 2 * W1C_DW), *sh3 = sc3 + 512;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int mt_idx = q * 8 + xcd;
     if (mt_idx >= m_tiles) return;                               // (workgroup-uniform)
@@ -1029,6 +1036,124 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const u
     const int chunks = N3 / CW;
     const float inv_s3 = __builtin_bit_cast(float, W3[(size_t)(N3 / 16) * KS3 * 512 + 1]), inv_s1 = s1[1];
     for (int i = threadIdx.x; i < N3; i += 256) { sc3[i] = scale3[i] * inv_s3; sh3[i] = shift3[i]; }
+    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // this wave's pixels (clamped: a wave past the end computes on the last pixel and stores nothing)
+    int mp[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m0 + j * 16 + r16;
+        mp[j] = m < M ? m : M - 1;
+    }
+    u32x4 bp[MT][KS3][2];                                         // conv3's B operand: the conv2 output of these pixels as pieces
+    if constexpr (C2F) {
+        // ---- conv2: conv_h2s_kernel<MT, NT2, 2>'s loop (same K order, same product order: the same sums) ----
+        const int Hin = c2.Hin, Hout = c2.Hout, steps2 = 9 * KS3, chunks2 = steps2 / KSC;
+        int py[MT], px[MT];
+        unsigned pbase[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int hw = Hout * Hout, pbi = mp[j] / hw, r = mp[j] - pbi * hw;
+            py[j] = (r / Hout) * c2.stride - 1;
+            px[j] = (r % Hout) * c2.stride - 1;
+            pbase[j] = (unsigned)(((pbi * Hin + py[j]) * Hin + px[j]) * K + 4 * g) * 4u;      // (wraps for padding rows: only used when the tap is inside)
+        }
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c2.T1), 0, (int)c2.in_bytes, 0x00027000);
+        const float inv_s2 = __builtin_bit_cast(float, c2.W2[(size_t)NT2 * steps2 * 512 + 1]);
+        f32x4 acc2[MT][NT2];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT2; ++i) acc2[j][i] = z4;
+        u32x4 wf[NPW2];
+        auto fetch_w2 = [&](int c) {
+#pragma unroll
+            for (int k = 0; k < NPW2; ++k) {
+                const int fi = wave + 4 * k, i = fi / (KSC * 2), ks = (fi / 2) % KSC, p = fi & 1;
+                wf[k] = *(const u32x4 *)(c2.W2 + ((size_t)i * steps2 + c * KSC + ks) * 512 + p * 256 + lane * 4);
+            }
+        };
+        auto park_w2 = [&](int buf) {
+#pragma unroll
+            for (int k = 0; k < NPW2; ++k) *(u32x4 *)&sm[buf * CH2_DW + (wave + 4 * k) * 256 + lane * 4] = wf[k];
+        };
+        int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0;               // the fetch pointer walks the steps in order; it stops at the last one
+        auto fetch_a = [&](u32x4(&bq)[MT][2]) {
+            const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * K + f_kc * 32) * 4u;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int iy = py[j] + f_ky, ix = px[j] + f_kx;
+                const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
+                const unsigned off = ok ? pbase[j] + dlt : 0x80000000u;
+                bq[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+                bq[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 64, 0);
+            }
+            const int adv = f_s + 1 < steps2 ? 1 : 0;
+            f_s += adv;
+            f_kc += adv;
+            const int c1 = f_kc == KS3 ? 1 : 0;
+            f_kc = c1 ? 0 : f_kc;
+            f_kx += c1;
+            const int cc = f_kx == 3 ? 1 : 0;
+            f_kx = cc ? 0 : f_kx;
+            f_ky += cc;
+        };
+        // activations TWO steps ahead in a ring of three register sets (first-touch rows of T1 come from HBM / the Infinity Cache: one step of
+        // 24 MFMAs per wave does not cover that at two waves per SIMD; this phase has the registers to spare): six steps = three chunks per
+        // trip of the loop, so that the ring index is a compile-time constant.  9 KS3 / 2 chunks: a multiple of three for KS3 = 2.
+        static_assert((9 * KS3 / KSC) % 3 == 0, "three chunks per trip");
+        u32x4 ring[3][MT][2];
+        fetch_w2(0);
+        fetch_a(ring[0]);
+        fetch_a(ring[1]);
+        park_w2(0);
+        for (int c0 = 0; c0 < chunks2; c0 += 3)
+            static_for<3>([&](auto cc_c) {
+                constexpr int CC = decltype(cc_c)::value;
+                const int c = c0 + CC;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (raw: __syncthreads() would drain the activation loads in flight)
+                fetch_w2(c + 1 < chunks2 ? c + 1 : c);
+                const unsigned *wc = sm + (c & 1) * CH2_DW + lane * 4;
+                static_for<KSC>([&](auto ks_c) {
+                    constexpr int ks = decltype(ks_c)::value, SL = (CC * KSC + ks) % 3;
+                    fetch_a(ring[(SL + 2) % 3]);                 // step s + 2 (past the end: the last step again, unused)
+                    u32x4 wa[NT2][2];
+#pragma unroll
+                    for (int i = 0; i < NT2; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) wa[i][p] = *(const u32x4 *)(wc + ((i * KSC + ks) * 2 + p) * 256);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        constexpr int pa[3] = {1, 0, 0}, pbk[3] = {0, 0, 1};
+#pragma unroll
+                        for (int j = 0; j < MT; ++j)
+#pragma unroll
+                            for (int i = 0; i < NT2; ++i) acc2[j][i] = mm(wa[i][pa[t]], ring[SL][j][pbk[t]], acc2[j][i]);
+                    }
+                });
+                park_w2((c + 1) & 1);
+            });
+        // BN + ReLU + split: tile pair p of conv2's output = k32 step p of conv3 (pair order)
+        float vmax2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < KS3; ++p) {
+            const int n = 32 * p + 8 * g;
+            const f32x4 sa = *(const f32x4 *)&c2.scale2[n] * inv_s2, sb = *(const f32x4 *)&c2.scale2[n + 4] * inv_s2;
+            const f32x4 ha = *(const f32x4 *)&c2.shift2[n], hb = *(const f32x4 *)&c2.shift2[n + 4];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                f32x4 v0 = acc2[j][2 * p] * sa + ha, v1 = acc2[j][2 * p + 1] * sb + hb;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { v0[t] = fmaxf(v0[t], 0.0f); v1[t] = fmaxf(v1[t], 0.0f); }
+                if (m0 + j * 16 + r16 < M) vmax2 = fmaxf(vmax2, fmaxf(fmaxf(fmaxf(v0[0], v0[1]), fmaxf(v0[2], v0[3])), fmaxf(fmaxf(v1[0], v1[1]), fmaxf(v1[2], v1[3]))));
+                split8(v0, v1, bp[j][p]);
+            }
+        }
+        if (c2.stat2) range_note(c2.stat2, vmax2);             // (kernel-uniform condition)
+        __syncthreads();                                         // every wave is done with conv2's weight chunks: the region becomes conv3's / conv1's
+    }
 
     u32x4 pf3[NP3], pf1[NP1];
     auto fetch_w3 = [&](int c) {
@@ -1047,24 +1172,17 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const u
 #pragma unroll
         for (int k = 0; k < NP1; ++k) *(u32x4 *)&w1l[buf * W1C_DW + (wave + 4 * k) * 256 + lane * 4] = pf1[k];
     };
-    auto mm = [](u32x4 a, u32x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    };
     fetch_w3(0);
     fetch_w1(0);
-    // this wave's pixels (clamped: a wave past the end computes on the last pixel and stores nothing) and their conv2 output: the pieces as stored
-    int mp[MT];
-    u32x4 bp[MT][KS3][2];
+    if constexpr (!C2F) {                                         // the conv2 output of this wave's pixels: the pieces as stored
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m0 + j * 16 + r16;
-        mp[j] = m < M ? m : M - 1;
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
-        for (int ks = 0; ks < KS3; ++ks) {
-            const float *p = T2 + (size_t)mp[j] * K + ks * 32 + 4 * g;
-            bp[j][ks][0] = *(const u32x4 *)p;
-            bp[j][ks][1] = *(const u32x4 *)(p + 16);
-        }
+            for (int ks = 0; ks < KS3; ++ks) {
+                const float *p = T2 + (size_t)mp[j] * K + ks * 32 + 4 * g;
+                bp[j][ks][0] = *(const u32x4 *)p;
+                bp[j][ks][1] = *(const u32x4 *)(p + 16);
+            }
     }
     // DS: the block input of the same pixels (K = 64: two k32 steps) and the branch's scale
     u32x4 xd[DS ? MT : 1][2][2];
@@ -1082,7 +1200,6 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const u
     }
     park_w3(0);
     park_w1(0);
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc1[MT][NT1];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
@@ -1210,29 +1327,37 @@ void conv_c3f_kernel(const float *__restrict__ T2 /*[M, 32 KS3] pairs*/, const u
 template <int KS3, int NT1, int MT, int TC>
 static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                          const unsigned *W1f, const float *s1, const float *scale1, const float *shift1, float *T1n, int M, int N3, hipStream_t s,
-                         float *stat3, float *stat1, int res_pair) {
+                         float *stat3, float *stat1, int res_pair, const C2Args *c2) {
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
-    if (res_pair) conv_c3f_kernel<KS3, NT1, MT, TC, false, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
-    else conv_c3f_kernel<KS3, NT1, MT, TC, false, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1);
+#define SYN_C3F_GO(RP, C2F, C2V) conv_c3f_kernel<KS3, NT1, MT, TC, false, RP, C2F><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, DsArgs{}, C2V)
+    if constexpr (KS3 == 2) {                                    // (conv2 in front: layer 1's 64-channel bottlenecks)
+        if (c2) { if (res_pair) SYN_C3F_GO(true, true, *c2); else SYN_C3F_GO(false, true, *c2); return; }
+    }
+    if (res_pair) SYN_C3F_GO(true, false, C2Args{}); else SYN_C3F_GO(false, false, C2Args{});
+#undef SYN_C3F_GO
 }
 
-// ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0.  Every tensor in the pair format.
+// ... with the block's downsample branch evaluated in the kernel (DS above): layer1.0.  Every tensor in the pair format.  c2 != nullptr: conv2 in front (T2 unused).
 bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
                         const float *scale_d, const float *shift_d, float *out, const unsigned *W1f, const float *s1, const float *scale1,
-                        const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1) {
+                        const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1, const C2Args *c2) {
     if (K != 64 || Kd != 64 || N3 != 256 || N1 != 64) return false;
     const DsArgs ds{X, Wd, scale_d, shift_d};
     const int m_tiles = (M + 127) / 128, grid = ((m_tiles + 7) / 8) * 8;
-    conv_c3f_kernel<2, 4, 2, 2, true, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);      // (32-channel chunks: with 64 the second B operand spills)
+    // (32-channel chunks: with 64 the second B operand spills)
+    if (c2) conv_c3f_kernel<2, 4, 2, 2, true, false, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds, *c2);
+    else conv_c3f_kernel<2, 4, 2, 2, true, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);
     return true;
 }
 
-// T2, out, T1n: pair format; identity: pairs (res_pair) or fp32 (a downsample branch computed by a launch of its own)
+// T2, out, T1n: pair format; identity: pairs (res_pair) or fp32 (a downsample branch computed by a launch of its own).  c2 != nullptr (K == 64 only):
+// the bottleneck's conv2 runs in front, in the same launch, from c2->T1 (T2 unused)
 bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                      const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
-                     hipStream_t s, float *stat3, float *stat1, int res_pair) {
+                     hipStream_t s, float *stat3, float *stat1, int res_pair, const C2Args *c2) {
     if (N3 % 64 || N3 > 512) return false;
-#define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1, res_pair)
+    if (c2 && K != 64) return false;
+#define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1, res_pair, c2)
     if (K == 64 && N1 == 64) SYN_C3F(2, 4, 2, 4);              // layer 1
     else if (K == 64 && N1 == 128) SYN_C3F(2, 8, 2, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)
     else if (K == 128 && N1 == 128) SYN_C3F(4, 8, SYN_C3F_L2_MT, 2);       // layer 2

@@ -192,14 +192,23 @@ constexpr int kRangeSub = 64, kRangeStride = 64;
 // W3: conv3's fp16 x2 fragments as launch_conv_f16x2 takes them; W1f: the next conv1's fragments step-major [Cin/32][N1/16][piece 2][lane 64][4 dwords]
 // (natural K order: in pair order conv3's accumulators are conv1's operand).  T2 / out / T1n in the pair format, identity in it (res_pair) or fp32.
 // false: this (K, N1) combination is not instantiated -- launch the two separately.
+// conv2 of the bottleneck in front of the fused launch (round 6, 64-channel bottlenecks = layer 1): see resnet_kernels.hip C2Args
+struct C2Args {
+    const float *T1 = nullptr;      // conv2 input [B, Hin, Hin, 64], pair format
+    const unsigned *W2 = nullptr;   // conv2's fp16 x2 fragments as launch_conv_f16x2 takes them
+    const float *scale2 = nullptr, *shift2 = nullptr;
+    int Hin = 0, Hout = 0, stride = 1;
+    unsigned in_bytes = 0;
+    float *stat2 = nullptr;         // range-guard slot of conv2's output
+};
 bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *identity, float *out,
                      const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
-                     hipStream_t s, float *stat3, float *stat1, int res_pair);
+                     hipStream_t s, float *stat3, float *stat1, int res_pair, const C2Args *c2 = nullptr);
 // ... with the block's downsample branch (1x1 conv + BN on the block input X [M, Kd]) evaluated in the same kernel instead of read as identity
 // (layer1.0: Kd = 64, stride 1); Wd: the downsample conv's fragments as launch_conv_f16x2 takes them.  false: not this shape.
 bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
                         const float *scale_d, const float *shift_d, float *out, const unsigned *W1f, const float *s1, const float *scale1,
-                        const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1);
+                        const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1, const C2Args *c2 = nullptr);
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 // 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,

@@ -306,7 +306,7 @@ struct syn_handle {
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
     uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
     int resnet_gemm = 1;           // SYNERGY_HIP_RESNET_GEMM=0: every convolution on conv_h2s_kernel (cross-check of conv_lt_kernel; 2: its 128-pixel tiles only)
-    int resnet_fuse = 1;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel)
+    int resnet_fuse = 2;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel); 1: conv3 + conv1 fused; 2: ... and layer 1's conv2 in front of them
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     unsigned *guard_word = nullptr;    // page-locked host word the head kernel of a poisoned forward writes (mapped: guard_word_dev is its device
     unsigned *guard_word_dev = nullptr; // alias); read WITHOUT synchronisation at the entry of the next forward -> automatic switch to fp32-MFMA
@@ -788,14 +788,31 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         const RBlock &b = n.blocks[bi];
         const bool last = bi + 1 == n.blocks.size();
         if (!have_t1) conv(b.c1, X, nullptr, T1, 1, 1, 0);
-        conv(b.c2, T1, nullptr, T2, 1, 1, 0);
         have_t1 = false;
         const float *identity = X;
         int id_pair = 1;                                   // the block input is a block output / the pooled stem: pair format in an fp16 x2 forward
         bool ds_done = b.ds < 0;
-        if (f16 && h->resnet_fuse && !last) {
+        bool c2_done = false;
+        const bool c3f_ok = f16 && h->resnet_fuse && !last && n.convs[b.c3].dst_w3 && n.convs[n.blocks[last ? bi : bi + 1].c1].dst_w1f &&
+                            n.convs[n.blocks[last ? bi : bi + 1].c1].hin == n.convs[b.c3].hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[last ? bi : bi + 1].c1);
+        // conv2 in front of the fused launch (64-channel bottlenecks, SYNERGY_HIP_RESNET_FUSE >= 2 = default): T2 never exists
+        syn::C2Args c2a;
+        const RConv &c2c = n.convs[b.c2];
+        const bool c2f = c3f_ok && h->resnet_fuse >= 2 && c2c.cin == 64 && c2c.cout == 64 && c2c.dst_w3 && !unsafe_w(b.c2) &&
+                         (size_t)B * c2c.hin * c2c.hin * c2c.cin * 4 < (1ull << 31) && (b.ds < 0 || (n.convs[b.ds].stride == 1 && n.convs[b.ds].dst_w3 && !unsafe_w(b.ds)));
+        if (c2f) {
+            c2a.T1 = T1; c2a.W2 = reinterpret_cast<const unsigned *>(P + c2c.dst_w3); c2a.scale2 = P + c2c.dst_scale; c2a.shift2 = P + c2c.dst_shift;
+            c2a.Hin = c2c.hin; c2a.Hout = c2c.hout; c2a.stride = c2c.stride; c2a.in_bytes = (unsigned)((size_t)B * c2c.hin * c2c.hin * c2c.cin * 4);
+            c2a.stat2 = stat && resnet_stat_used(1 + b.c2) ? range_slot(stat, 1 + b.c2) : nullptr;
+            c2_done = true;
+        } else
+            conv(b.c2, T1, nullptr, T2, 1, 1, 0);
+        const syn::C2Args *c2p = c2f ? &c2a : nullptr;
+        // (the fused launch reads T1 and writes the next block's T1: with conv2 in front they must be different buffers)
+        float *T1n = c2f ? T2 : T1;
+        if (c3f_ok) {
             const RConv &c3 = n.convs[b.c3], &c1n = n.convs[n.blocks[bi + 1].c1];
-            if (c3.dst_w3 && c1n.dst_w1f && c1n.hin == c3.hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[bi + 1].c1)) {
+            {
                 const float *s1 = P + c1n.dst_w3 + (size_t)(c1n.cout / 16) * (c1n.cin / 32) * 512;      // device {S, 1/S} of the next conv1's weights
                 float *st3 = stat && resnet_stat_used(1 + b.c3) ? range_slot(stat, 1 + b.c3) : nullptr;
                 float *st1 = stat && resnet_stat_used(1 + n.blocks[bi + 1].c1) ? range_slot(stat, 1 + n.blocks[bi + 1].c1) : nullptr;
@@ -805,17 +822,19 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
                     const RConv &cd = n.convs[b.ds];
                     have_t1 = ds_done = syn::launch_conv_c3f_ds(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, X,
                                                                 reinterpret_cast<const unsigned *>(P + cd.dst_w3), P + cd.dst_scale, P + cd.dst_shift, Y,
-                                                                reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
-                                                                M, c3.cin, cd.cin, c3.cout, c1n.cout, s, st3, st1);
+                                                                reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1n,
+                                                                M, c3.cin, cd.cin, c3.cout, c1n.cout, s, st3, st1, c2p);
                 }
                 if (!have_t1) {
                     if (!ds_done) { conv(b.ds, X, nullptr, D, 0, 0, 0); identity = D; id_pair = 0; ds_done = true; }
                     have_t1 = syn::launch_conv_c3f(T2, reinterpret_cast<const unsigned *>(P + c3.dst_w3), P + c3.dst_scale, P + c3.dst_shift, identity, Y,
-                                                   reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1,
-                                                   M, c3.cin, c3.cout, c1n.cout, s, st3, st1, id_pair);
+                                                   reinterpret_cast<const unsigned *>(P + c1n.dst_w1f), s1, P + c1n.dst_scale, P + c1n.dst_shift, T1n,
+                                                   M, c3.cin, c3.cout, c1n.cout, s, st3, st1, id_pair, c2p);
                 }
             }
         }
+        if (have_t1 && c2f) { float *t = T1; T1 = T2; T2 = t; }       // the next block's conv1 output sits in the other buffer
+        if (c2_done && !have_t1) { conv(b.c2, T1, nullptr, T2, 1, 1, 0); c2_done = false; }      // (the fused launch did not take this shape after all)
         if (!ds_done) { conv(b.ds, X, nullptr, D, 0, 0, 0); identity = D; id_pair = 0; }
         if (!have_t1) conv(b.c3, T2, identity, Y, 1, last ? 0 : 1, id_pair);      // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;

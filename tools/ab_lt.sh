@@ -2,7 +2,7 @@
 # per-launch durations of one ResNet-50 forward (B = 512) for the default library and each variant library given (tags): A/B of conv_lt_kernel
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/ab_lt.txt; : > $out
 for tag in "" "$@"; do
-  unset SYNERGY_HIP_LIB SYNERGY_HIP_RESNET_GEMM SYN_LT_STAGE SYN_LT_GLDS
+  unset SYNERGY_HIP_LIB SYNERGY_HIP_RESNET_GEMM SYN_LT_STAGE SYN_LT_GLDS SYNERGY_HIP_RESNET_FUSE
   case "$tag" in
     "") ;;
     env:*) export "${tag#env:}" ;;
@@ -17,7 +17,7 @@ us=[float(r[-2]) for r in rows]
 names=[r[0] for r in rows]
 print('total %.0f us; conv_lt sum %.0f' % (sum(us), sum(u for n,u in zip(names,us) if 'conv_lt' in n)))
 print(' '.join('%.0f' % u for u in us))
-print('L3 block (conv1 conv2 conv3):', us[21:24], ' L4 block:', us[40:43], ' L2 conv2:', us[11], ' L3.0 c1,c2,ds,c3:', us[16:20])
+print(' '.join(n[:12] for n in names[:12]))
 PY
 done
 cat $out
