@@ -1330,7 +1330,7 @@ static void launch_c3f_t(const float *T2, const unsigned *W3, const float *scale
                          float *stat3, float *stat1, int res_pair, const C2Args *c2) {
     const int m_tiles = (M + 4 * MT * 16 - 1) / (4 * MT * 16), grid = ((m_tiles + 7) / 8) * 8;
 #define SYN_C3F_GO(RP, C2F, C2V) conv_c3f_kernel<KS3, NT1, MT, TC, false, RP, C2F><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, DsArgs{}, C2V)
-    if constexpr (KS3 == 2) {                                    // (conv2 in front: layer 1's 64-channel bottlenecks)
+    if constexpr (KS3 == 2 || KS3 == 4) {                        // (conv2 in front: the 64- and 128-channel bottlenecks of layers 1 / 2)
         if (c2) { if (res_pair) SYN_C3F_GO(true, true, *c2); else SYN_C3F_GO(false, true, *c2); return; }
     }
     if (res_pair) SYN_C3F_GO(true, false, C2Args{}); else SYN_C3F_GO(false, false, C2Args{});
@@ -1356,7 +1356,7 @@ bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, c
                      const unsigned *W1f, const float *s1 /*device {S, 1/S}*/, const float *scale1, const float *shift1, float *T1n, int M, int K, int N3, int N1,
                      hipStream_t s, float *stat3, float *stat1, int res_pair, const C2Args *c2) {
     if (N3 % 64 || N3 > 512) return false;
-    if (c2 && K != 64) return false;
+    if (c2 && K != 64 && K != 128) return false;
 #define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1, res_pair, c2)
     if (K == 64 && N1 == 64) SYN_C3F(2, 4, 2, 4);              // layer 1
     else if (K == 64 && N1 == 128) SYN_C3F(2, 8, 2, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)

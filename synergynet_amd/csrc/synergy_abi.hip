@@ -306,7 +306,7 @@ struct syn_handle {
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
     uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
     int resnet_gemm = 1;           // SYNERGY_HIP_RESNET_GEMM=0: every convolution on conv_h2s_kernel (cross-check of conv_lt_kernel; 2: its 128-pixel tiles only)
-    int resnet_fuse = 2;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel); 1: conv3 + conv1 fused; 2: ... and layer 1's conv2 in front of them
+    int resnet_fuse = 3;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel); 1: conv3 + conv1 fused; 2: ... and layer 1's conv2 in front of them; 3: layer 2's too (three blocks: 270 / 243 / 245 -> 256 / 234 / 235 us)
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     unsigned *guard_word = nullptr;    // page-locked host word the head kernel of a poisoned forward writes (mapped: guard_word_dev is its device
     unsigned *guard_word_dev = nullptr; // alias); read WITHOUT synchronisation at the entry of the next forward -> automatic switch to fp32-MFMA
@@ -798,8 +798,9 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         // conv2 in front of the fused launch (64-channel bottlenecks, SYNERGY_HIP_RESNET_FUSE >= 2 = default): T2 never exists
         syn::C2Args c2a;
         const RConv &c2c = n.convs[b.c2];
-        const bool c2f = c3f_ok && h->resnet_fuse >= 2 && c2c.cin == 64 && c2c.cout == 64 && c2c.dst_w3 && !unsafe_w(b.c2) &&
-                         (size_t)B * c2c.hin * c2c.hin * c2c.cin * 4 < (1ull << 31) && (b.ds < 0 || (n.convs[b.ds].stride == 1 && n.convs[b.ds].dst_w3 && !unsafe_w(b.ds)));
+        const int c2_max = h->resnet_fuse >= 3 ? 128 : 64;   // (3: layer 2's 128-channel bottlenecks too)
+        const bool c2f = c3f_ok && h->resnet_fuse >= 2 && c2c.cin == c2c.cout && (c2c.cin == 64 || c2c.cin == 128) && c2c.cin <= c2_max && c2c.dst_w3 && !unsafe_w(b.c2) &&
+                         (size_t)B * c2c.hin * c2c.hin * c2c.cin * 4 < (1ull << 31);
         if (c2f) {
             c2a.T1 = T1; c2a.W2 = reinterpret_cast<const unsigned *>(P + c2c.dst_w3); c2a.scale2 = P + c2c.dst_scale; c2a.shift2 = P + c2c.dst_shift;
             c2a.Hin = c2c.hin; c2a.Hout = c2c.hout; c2a.stride = c2c.stride; c2a.in_bytes = (unsigned)((size_t)B * c2c.hin * c2c.hin * c2c.cin * 4);
