@@ -446,7 +446,7 @@ using B17 = Bf3Cfg< 160, 960, 320,  4, 1, false,  4, 64, 4, 4, 4, 1>;    // feat
 
 // features.5 + 6 of a small batch in one launch (a[0..1]; one workgroup per face, not persistent: grids up to the resident 256 workgroups); false: one by one
 bool launch_fused_pair_f16(const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
-    static const bool on = !(getenv("SYN_F16_PAIR56") && atoi(getenv("SYN_F16_PAIR56")) == 0);
+    static const bool on = test_knob("f16_pair56", 1) != 0;
     if (!on || a.prof || b.prof || !a.We3 || !a.Wp3 || !a.scl_e || !a.scl_p || !b.We3 || !b.Wp3 || !b.scl_e || !b.scl_p) return false;
     const int grid = (B + B5::NF - 1) / B5::NF;
     if (grid > B5::SLOTS) return false;                  // (larger batches take the persistent single launches, or the row-marching pair from 513 faces)

@@ -1278,11 +1278,11 @@ static void launch_lb(const FusedBlockArgs &a, int B, hipStream_t s) {
 constexpr int kChainMin = 384;          // (us, blocks one by one -> chain: B = 384 239 -> 195, 512 253 -> 201, 640 367 -> 259; B = 256 198 -> 184 but a slower step)
 constexpr int kSmallChainMax = 256;     // the one-face-per-workgroup chain: one round of workgroups
 static bool small_f7() {      // features.7 as the first stage of the eight-wave small-batch chain (SYN_SMALL_F7=0: its own launch, as in round 4)
-    static const bool on = !(getenv("SYN_SMALL_F7") && atoi(getenv("SYN_SMALL_F7")) == 0);
+    static const bool on = test_knob("small_f7", 1) != 0;
     return on;
 }
 int lb_chain_mode(int B, bool small) {
-    static const int chain = getenv("SYN_LB_CHAIN") ? atoi(getenv("SYN_LB_CHAIN")) : 3;
+    static const int chain = (int)test_knob("lb_chain", 3);
     if (chain <= 0) return 0;
     if (B < kChainMin) return (small && B <= kSmallChainMax) ? (small_f7() ? 3 : 2) : 0;      // (2 = features.8 .. 14: launch_fused_chain_lb picks the small-batch kernel)
     return chain > 3 ? 3 : chain;

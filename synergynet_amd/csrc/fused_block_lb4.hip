@@ -450,8 +450,8 @@ static bool launch_lb4_sliced(const FusedBlockArgs &a, int B, hipStream_t s) {
 
 // features.17 of a small batch: the slices only -- the tail's staging adds them (head_kernel.hip, SIN).  B < 513: the two-face tails.
 bool launch_lb4_sliced17_deferred(const FusedBlockArgs &a, int B, hipStream_t s, HeadSliced *out) {
-    static const bool on = !(getenv("SYN_HEAD_SLICED_IN") && atoi(getenv("SYN_HEAD_SLICED_IN")) == 0);
-    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;
+    static const bool on = test_knob("head_sliced_in", 1) != 0;
+    static const int wide_min = (int)test_knob("head_wide_min", 513);
     if (!on || !out || !a.Glb || a.prof || !a.scratch || B >= wide_min || B >= 576) return false;
     using C = Q17;
     const int wg = (B + 3) / 4;
@@ -476,7 +476,7 @@ static int lb4_min_batch() {
 
 // a[i] = the arguments of features.(15 + i); false: launch them one by one
 bool launch_fused_chain_lb4(const FusedBlockArgs *a, int B, hipStream_t s) {
-    static const int chain = getenv("SYN_LB4_CHAIN") ? atoi(getenv("SYN_LB4_CHAIN")) : 1;
+    static const int chain = (int)test_knob("lb4_chain", 1);
     if (!chain || B < lb4_min_batch()) return false;
     Lb4ChainArgs ca;
     for (int i = 0; i < 3; ++i) {

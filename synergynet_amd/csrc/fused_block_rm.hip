@@ -686,11 +686,6 @@ void fused_pair_rm_kernel(RmStageArgs a, RmStageArgs b, int B) {
     }
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-}
-
 template <class C>
 static void launch_rm(const FusedBlockArgs &a, int B, hipStream_t s, int wgs_per_cu) {
     const int n_units = (B + C::NF - 1) / C::NF * C::NBD;
@@ -737,7 +732,7 @@ static void launch_pair(const FusedBlockArgs &a, const FusedBlockArgs &b, int B,
                                                         RmStageArgs{b.X, b.Arm_e, b.Arm_p, b.e_shift, b.Wd, b.d_shift, b.p_shift, b.Y, b.scl_e, b.scl_p}, B);
 }
 bool launch_fused_pair_rm(int first, const FusedBlockArgs &a, const FusedBlockArgs &b, int B, hipStream_t s) {
-    static const bool on56 = env_int("SYN_RM_PAIR56", 1) != 0, on34 = env_int("SYN_RM_PAIR34", 1) != 0;
+    static const bool on56 = test_knob("rm_pair56", 1) != 0, on34 = test_knob("rm_pair34", 1) != 0;
     if (B < 513 || a.prof || b.prof) return false;
     if (!a.Arm_e || !a.Arm_p || !a.scl_e || !a.scl_p || !b.Arm_e || !b.Arm_p || !b.scl_e || !b.scl_p) return false;
     if (first == 5 && on56) { launch_pair<R5<2>, R5<2>>(a, b, B, s); return true; }
@@ -752,7 +747,7 @@ bool launch_fused_block_rm(int feature, const FusedBlockArgs &a, int B, hipStrea
     // faces at which a configuration starts to pay (measured, tools/perlaunch.py --batch N).  The kernels are
     // persistent over 256 workgroups: 513 faces is where the smaller configuration needs a second round of workgroups (B = 640, us: features.2
     // 123 -> 91, features.4 74 -> 52, features.5/6 51 / 49 -> 43 / 42 with the larger one; at B = 512 the smaller one wins: 66 / 42 / 36 vs 88 / 50 / 41)
-    static const bool bands2 = env_int("SYN_RM_BAND2", 1) != 0, bands3 = env_int("SYN_RM_BAND3", 1) != 0;     // (0: the tiled kernels below the thresholds, as before round 4)
+    static const bool bands2 = test_knob("rm_band2", 1) != 0, bands3 = test_knob("rm_band3", 1) != 0;     // (0: the tiled kernels below the thresholds, as before round 4)
     switch (feature) {
         case 2:
             if (B >= 513) { launch_rm<R2<4>>(a, B, s, 1); return true; }

@@ -420,7 +420,7 @@ void launch_head_f16x2(const float *X, const unsigned *Wb3, const float *shift, 
         head_f16x2_kernel<1, NF, 4, true><<<grid, 256, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B, *sin);
         return;
     }
-    static const int wide_min = getenv("SYN_HEAD_WIDE_MIN") ? atoi(getenv("SYN_HEAD_WIDE_MIN")) : 513;       // (B = 640 / 768 / 896: 60 / 62 / 61 -> 47 / 48 / 48 us; B = 512: the two-face workgroups, 49 us)
+    static const int wide_min = (int)test_knob("head_wide_min", 513);       // (B = 640 / 768 / 896: 60 / 62 / 61 -> 47 / 48 / 48 us; B = 512: the two-face workgroups, 49 us)
     if (B >= wide_min) {
         head_f16x2_kernel<1, 4, 8><<<(B + 3) / 4, 512, 0, s>>>(X, Wb3, shift, Wfc, bfc, param, pool, B);
         return;

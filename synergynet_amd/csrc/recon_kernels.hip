@@ -566,18 +566,18 @@ void launch_reconstruct_f16(const float *param, const float *mean62, const float
     // caller with pitch == n_vert AND pad_writable used to reach the FAST kernel with PK's group count and leave vertices >= 128 x that unwritten)
     const int fast_groups = (n_tiles + WPG - 1) / WPG;
     const bool fast_ok = pad_writable && pitch >= fast_groups * WPG * 32;
-    const bool pk = !fast_ok && pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !getenv("SYN_RECON_NO_PK");
-    static const int pk_wpg = getenv("SYN_RECON_PK_WPG") ? atoi(getenv("SYN_RECON_PK_WPG")) : 8;       // tiles a PK workgroup computes: 8 (stores 7 lines per row) | 4 (stores 3)
+    const bool pk = !fast_ok && pitch == n_vert && n_vert >= 4096 && (reinterpret_cast<uintptr_t>(out) & 127) == 0 && !test_knob("recon_no_pk", 0);
+    static const int pk_wpg = (int)test_knob("recon_pk_wpg", 8);       // tiles a PK workgroup computes: 8 (stores 7 lines per row) | 4 (stores 3)
     const int pkw = (pk_wpg == 8 ? 7 : 3) * 32;
     const int n_groups = pk ? (n_vert + pkw - 1) / pkw : fast_groups;       // a workgroup = WPG consecutive vertex tiles (PK: a stride of WPG - 1)
-    static const int wg_target = getenv("SYN_RECON_WGS") ? atoi(getenv("SYN_RECON_WGS")) : 1664;   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
-    static const int prof3 = getenv("SYN_RECON_PROF") ? atoi(getenv("SYN_RECON_PROF")) : 0;              // profiling only
+    static const int wg_target = (int)test_knob("recon_wgs", 1664);   // (3072: -0.8 % in the two-stream pipeline at B = 1024)
+    static const int prof3 = (int)test_knob("recon_prof", 0);              // profiling only
     // face tiles [lo, hi) in one launch of >= wg_target workgroups: vertex groups x splits of the face-tile range
     auto run = [&](int lo, int hi, bool fast) {
         const int nft = hi - lo;
         if (nft <= 0) return;
         // (eight-wave PK workgroups, one per CU: half the target -- 832: 0.153 ms, 1664: 0.167, 512: 0.156 at B = 1024)
-        const int target = (pk && pk_wpg == 8 && !getenv("SYN_RECON_WGS")) ? wg_target / 2 : wg_target;
+        const int target = (pk && pk_wpg == 8 && !test_knob_set("recon_wgs")) ? wg_target / 2 : wg_target;
         int n_split = (target + n_groups - 1) / n_groups;
         n_split = n_split < 1 ? 1 : n_split;
         n_split = n_split > nft ? nft : n_split;

@@ -923,8 +923,8 @@ static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *s
     const int m_tiles = (M + 64 * MTW - 1) / (64 * MTW);
     const int grid = ((m_tiles + 7) / 8) * n_tiles * 8;
     const unsigned in_bytes = (unsigned)((size_t)(M / (Hout * Hout)) * Hin * Hin * Cin * 4);
-    static const int shape = getenv("SYN_LT_STAGE") ? atoi(getenv("SYN_LT_STAGE")) : -1;      // A/B knob: 0 / 1 forces the row- / plane-shaped staging loads
-    static const int glds = getenv("SYN_LT_GLDS") ? atoi(getenv("SYN_LT_GLDS")) : 1;         // A/B knob: 0 = conv_lt_kernel everywhere, 1 = conv_lp_kernel for 256-pixel tiles, 2 = for both
+    static const int shape = (int)test_knob("lt_stage", -1);      // A/B knob: 0 / 1 forces the row- / plane-shaped staging loads
+    static const int glds = (int)test_knob("lt_glds", 1);         // A/B knob: 0 = conv_lt_kernel everywhere, 1 = conv_lp_kernel for 256-pixel tiles, 2 = for both
     const bool frag = shape < 0 ? KH * KW > 1 : shape != 0;       // plane-shaped loads where the taps re-read the activations from L2
     // 128-pixel tiles: three 32 KB stages are one workgroup per CU, which the short-K convolutions (conv3, downsample: their time is the epilogue)
     // pay for -- layer 3 conv3 89 -> 100 us -- and the long-K ones gain from (layer 4 conv1 / conv2 53 -> 48, 100 -> 93)

@@ -307,7 +307,7 @@ void launch_stem_block1(const float *img, const uint8_t *img8, const float *w0, 
     // persistent: the register budget (~200 VGPRs, 4 waves per workgroup) admits two resident workgroups per CU; a third
     // layer would only start when the first two finish (measured 361 -> 322 us at B = 1024 going from 3 to 2)
     const int grid = total < 256 * 2 ? total : 256 * 2;
-    static const int ablate = getenv("SYN_ABLATE_STEM") ? atoi(getenv("SYN_ABLATE_STEM")) : 0;   // profiling only: skip stages
+    static const int ablate = (int)test_knob("ablate_stem", 0);   // profiling only: skip stages
     if (img8 && w0b3 && ablate) stem_block1_kernel<true, true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);
     else if (img8 && w0b3) stem_block1_kernel<true, true><<<grid, NTH, 0, s>>>(nullptr, img8, w0, w0b3, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, 0);
     else if (img8)    stem_block1_kernel<true, false><<<grid, NTH, 0, s>>>(nullptr, img8, w0, nullptr, s0, b0, wd, sd, bd, wp, sp, bp, Y, total, ablate);

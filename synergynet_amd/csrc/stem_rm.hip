@@ -481,7 +481,7 @@ bool launch_stem_rm(const uint8_t *img8, const unsigned *As3, const float *s_shi
     if (B >= kStemMin2) { launch_stem_cfg<StemRmCfg<2, 2>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     // six bands of ten output rows, four faces per workgroup (12 steps + 2 lead stages per round; step time of configs[1] - tiled stem, us:
     // B = 64 +6, 96 -1, 128 -6, 256 -12, 400 -20; four bands, or two faces per workgroup: +3 ... -3 at B = 128; tools/band_ab.sh)
-    static const bool bands = !getenv("SYN_STEM_BAND") || atoi(getenv("SYN_STEM_BAND")) != 0;
+    static const bool bands = test_knob("stem_band", 1) != 0;
     if (bands && B >= kStemBandMin) { launch_stem_cfg<StemRmCfg<4, 2, false, 6>>(img8, As3, s_shift, Wd, d_shift, Ap3, p_shift, scl_p, Y, B, s); return true; }
     return false;
 }

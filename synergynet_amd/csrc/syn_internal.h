@@ -28,6 +28,14 @@ __device__ __forceinline__ void l2_touch(const void *base, unsigned bytes, unsig
 __device__ __forceinline__ void l2_touch_done(unsigned &sink) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory"); }
 #endif
 
+// Test / A-B knobs of the launchers (never needed in production: every default is the measured best).  ONE environment variable,
+//   SYNERGY_HIP_TEST_KNOBS = "name=value,name=value,..."   (integers; 0x.. hexadecimal accepted)
+// read once per process (synergy_abi.hip); rounds 2-5 had 18 separate SYN_* variables.  Names: lb_chain, lb4_chain, small_f7, head_sliced_in,
+// head_wide_min, f16_pair56, rm_pair56, rm_pair34, rm_band2, rm_band3, stem_band, ablate_stem, recon_no_pk, recon_pk_wpg, recon_wgs, recon_prof,
+// lt_stage, lt_glds, resnet_exact_mask.
+long long test_knob(const char *name, long long dflt);
+bool test_knob_set(const char *name);
+
 constexpr int kImg = 120;           // utils/params.py:34
 constexpr int kParam = 62;
 constexpr int kPool = 1280;

@@ -752,8 +752,8 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
     // intermediates T1 / T2, the block outputs X / Y; fp32 stay the downsample branch D (only ever a residual) and the last block's output
     // (the pool reads it).  An fp32 handle (fusion < 2, or after a range event) keeps everything fp32.
     const int PF = f16 ? 1 : 0;
-    // DEBUG knob (tests only): SYN_RESNET_EXACT_MASK = hex bit set of convolutions forced onto the exact kernel inside an fp16 x2 forward
-    static const unsigned long long force_exact = getenv("SYN_RESNET_EXACT_MASK") ? strtoull(getenv("SYN_RESNET_EXACT_MASK"), nullptr, 16) : 0ull;
+    // test knob resnet_exact_mask = bit set of convolutions forced onto the exact kernel inside an fp16 x2 forward (tools/dbg_resnet_exact.py)
+    static const unsigned long long force_exact = (unsigned long long)syn::test_knob("resnet_exact_mask", 0);
     auto unsafe_w = [&](int ci) { return ((force_exact >> ci) & 1ull) || (h->range_guard && ((h->resnet_w_unsafe[ci >> 5] >> (ci & 31)) & 1u)); };
     auto conv = [&](int ci, const float *in, const float *res, float *out, int act, int out_pair, int res_pair) {
         const RConv &c = n.convs[ci];
@@ -848,6 +848,38 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
 }
 
 }  // namespace
+
+namespace syn {
+namespace {
+struct KnobTable {
+    std::vector<std::pair<std::string, long long>> kv;
+    KnobTable() {
+        const char *e = getenv("SYNERGY_HIP_TEST_KNOBS");
+        if (!e) return;
+        std::string str(e);
+        size_t pos = 0;
+        while (pos < str.size()) {
+            size_t end = str.find(',', pos);
+            if (end == std::string::npos) end = str.size();
+            const std::string item = str.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos && eq > 0) kv.emplace_back(item.substr(0, eq), strtoll(item.c_str() + eq + 1, nullptr, 0));
+            else if (!item.empty()) fprintf(stderr, "SYNERGY_HIP_TEST_KNOBS: ignoring '%s' (expected name=value)\n", item.c_str());
+            pos = end + 1;
+        }
+    }
+};
+const KnobTable &knobs() { static const KnobTable t; return t; }
+}  // namespace
+long long test_knob(const char *name, long long dflt) {
+    for (const auto &p : knobs().kv) if (p.first == name) return p.second;
+    return dflt;
+}
+bool test_knob_set(const char *name) {
+    for (const auto &p : knobs().kv) if (p.first == name) return true;
+    return false;
+}
+}  // namespace syn
 
 extern "C" {
 

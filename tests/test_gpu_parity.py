@@ -252,7 +252,7 @@ def test_small_batch_schedules_are_bitwise_batch_independent(model_tiled_early, 
 def test_small_batch_chain_equals_the_block_by_block_schedule(pack, backbone_sd, B):
     """Round 4 (BASELINE configs[1]): batches of <= 256 faces run features.8-14 as ONE launch -- one face per workgroup, eight waves per
     face, the partial sums of the eight streams added in LDS in a fixed order (fused_chain_lb_small8_kernel) -- instead of 14 hidden-sliced + reduce launches (or the tiled kernels below 32 faces).  Round 5: features.7 is the
-    first stage of that launch (lb7_stage8: a wave = hidden stream x output block; SYN_SMALL_F7=0 keeps it a launch of its own) and the
+    first stage of that launch (lb7_stage8: a wave = hidden stream x output block; test knob small_f7=0 keeps it a launch of its own) and the
     exchange buffer no longer aliases the fragments (two barriers per stage fewer) -- the reference schedule below (EARLY_RM without bit
     10) still runs features.7 ... 14 block by block.  Same arithmetic in another summation order: equal to the block-by-block schedule
     (SYNERGY_HIP_EARLY_RM without bit 10) to fp32 rounding on distinct faces, bitwise independent of the position in the batch, and
@@ -803,12 +803,12 @@ np.savez(sys.argv[2], **out)
 '''
 
 
-@pytest.mark.parametrize('knob', ['SYN_F16_PAIR56', 'SYN_HEAD_SLICED_IN'])
+@pytest.mark.parametrize('knob', ['f16_pair56', 'head_sliced_in'])
 def test_small_batch_launch_fusions_change_no_bit(model, golden, tmp_path, knob):
     """Round 5, batches below 513 faces: (a) features.5 + 6 run on the whole-image tiled kernel, up to 256 faces as ONE launch (fused_pair_f16_kernel:
-    one workgroup per face carries it through both blocks; SYN_F16_PAIR56=0: two launches); (b) features.17's hidden-slice partial sums are added by
+    one workgroup per face carries it through both blocks; test knob f16_pair56=0: two launches); (b) features.17's hidden-slice partial sums are added by
     the tail while it stages its input tile (head_f16x2_kernel SIN: lb4_reduce_kernel's arithmetic and order) instead of by a reduce launch in front
-    of it (SYN_HEAD_SLICED_IN=0; taken with two or three slices, i.e. from 253 faces).  Schedule changes only: the SAME BITS, at one face, a few, configs[1]'s 128, around the pair's limit (256 / 257),
+    of it (test knob head_sliced_in=0; taken with two or three slices, i.e. from 253 faces).  Schedule changes only: the SAME BITS, at one face, a few, configs[1]'s 128, around the pair's limit (256 / 257),
     at the last batch the sliced tail input takes (512) and the first it does not (513)."""
     import subprocess
     import sys
@@ -820,7 +820,7 @@ def test_small_batch_launch_fusions_change_no_bit(model, golden, tmp_path, knob)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / 'p.npz')
     r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
-                       env=dict(os.environ, **{knob: '0'}), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, SYNERGY_HIP_TEST_KNOBS=knob + '=0'), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     want = np.load(out)
     for B in sizes:
@@ -832,8 +832,9 @@ def test_small_batch_launch_fusions_change_no_bit(model, golden, tmp_path, knob)
 # (knobs, batch sizes at which the knob's kernel is actually TAKEN by the default process).  features.3 + 4 share a launch only for one round of
 # workgroups, 513 <= B <= 1024 (fused_block_rm.hip launch_fused_pair_rm): at 1030 both processes would launch the blocks one by one and the
 # comparison would test nothing, so that knob runs at both ends of its window.
-_KNOB_CASES = [({'SYN_LB_CHAIN': '0'}, (1030,)), ({'SYN_LB_CHAIN': '1'}, (1030,)), ({'SYN_LB_CHAIN': '2'}, (1030,)), ({'SYN_LB4_CHAIN': '0'}, (1030,)),
-               ({'SYN_HEAD_WIDE_MIN': '1000000'}, (1030,)), ({'SYN_RM_PAIR56': '0'}, (513, 1030)), ({'SYN_RM_PAIR34': '0'}, (513, 1024))]
+# (the knobs travel in ONE variable, SYNERGY_HIP_TEST_KNOBS = "name=value,...": csrc/syn_internal.h test_knob)
+_KNOB_CASES = [({'lb_chain': '0'}, (1030,)), ({'lb_chain': '1'}, (1030,)), ({'lb_chain': '2'}, (1030,)), ({'lb4_chain': '0'}, (1030,)),
+               ({'head_wide_min': '1000000'}, (1030,)), ({'rm_pair56': '0'}, (513, 1030)), ({'rm_pair34': '0'}, (513, 1024))]
 
 
 @pytest.mark.parametrize('knobs,sizes', _KNOB_CASES, ids=lambda k: ','.join(f'{a}={b}' for a, b in k.items()) if isinstance(k, dict) else 'B' + '_'.join(map(str, k)))
@@ -841,7 +842,7 @@ def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, kno
     """features.7-14 and features.15-17 run as chains of stages inside one launch each (fused_block_lb.hip, fused_block_lb4.hip:
     the activations go from stage to stage through LDS, the residual stays in registers), and from B = 1024 the tail takes four
     faces per workgroup (head_kernel.hip); round 5: features.5 + 6 and features.3 + 4 share one launch of the row-marching kernel each
-    (fused_pair_rm_kernel, B >= 513: a workgroup marches its faces through both blocks; SYN_RM_PAIR56=0 / SYN_RM_PAIR34=0: two launches).  Every one of these is a schedule change only: with the chain off (one launch per
+    (fused_pair_rm_kernel, B >= 513: a workgroup marches its faces through both blocks; test knobs rm_pair56=0 / rm_pair34=0: two launches).  Every one of these is a schedule change only: with the chain off (one launch per
     block), with the shorter features.8-13 / 8-14 chains, and with the two-face tail the parameters must be the SAME BITS.  The knobs are
     read once per process, hence the subprocess."""
     import subprocess
@@ -852,7 +853,7 @@ def test_chain_launches_and_wide_head_change_no_bit(model, golden, tmp_path, kno
         pytest.skip('the chains belong to the default schedule')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / 'p.npz')
-    env = dict(os.environ, **knobs)
+    env = dict(os.environ, SYNERGY_HIP_TEST_KNOBS=','.join(f'{a}={b}' for a, b in knobs.items()))
     r = subprocess.run([sys.executable, '-c', _VARIANT_SCRIPT_MULTI, root, out, str(int(golden['seeds'][0])), str(int(golden['seeds'][1])), ','.join(map(str, sizes))],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

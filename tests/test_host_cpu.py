@@ -170,6 +170,13 @@ def test_documented_knobs_exist_in_the_sources():
                 stem = knob
             if stem not in src:
                 missing.append(f'{doc}: {knob}')
+    # ... and every name INTEGRATION.md lists for SYNERGY_HIP_TEST_KNOBS is a test_knob("...") somewhere in csrc/
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    m = re.search(r'SYNERGY_HIP_TEST_KNOBS.*?[Nn]ames?:(.*?)\n\n', text, re.S)
+    assert m, 'INTEGRATION.md documents SYNERGY_HIP_TEST_KNOBS and its names'
+    for name in re.findall(r'`([a-z0-9_]+)`', m.group(1)):
+        if f'test_knob("{name}"' not in src and f'test_knob_set("{name}"' not in src:
+            missing.append(f'INTEGRATION.md: test knob {name}')
     assert not missing, missing
 
 

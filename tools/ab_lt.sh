@@ -2,7 +2,7 @@
 # per-launch durations of one ResNet-50 forward (B = 512) for the default library and each variant library given (tags): A/B of conv_lt_kernel
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/ab_lt.txt; : > $out
 for tag in "" "$@"; do
-  unset SYNERGY_HIP_LIB SYNERGY_HIP_RESNET_GEMM SYN_LT_STAGE SYN_LT_GLDS SYNERGY_HIP_RESNET_FUSE
+  unset SYNERGY_HIP_LIB SYNERGY_HIP_RESNET_GEMM SYNERGY_HIP_TEST_KNOBS SYNERGY_HIP_RESNET_FUSE
   case "$tag" in
     "") ;;
     env:*) export "${tag#env:}" ;;

@@ -1,4 +1,4 @@
-"""GPU box: ResNet-50 at B = 9 with a set of convolutions forced onto the exact kernel (SYN_RESNET_EXACT_MASK) vs the oracle."""
+"""GPU box: ResNet-50 at B = 9 with a set of convolutions forced onto the exact kernel (SYNERGY_HIP_TEST_KNOBS=resnet_exact_mask=0x...) vs the oracle."""
 import os, sys, subprocess
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +17,6 @@ got = m.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
 print('%.3e' % (np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)).max())
 '''
 for mask in sys.argv[1:]:
-    env = dict(os.environ, SYN_RESNET_EXACT_MASK=mask)
+    env = dict(os.environ, SYNERGY_HIP_TEST_KNOBS='resnet_exact_mask=0x' + mask)
     r = subprocess.run([sys.executable, '-c', SCRIPT, ROOT], env=env, capture_output=True, text=True)
     print(mask, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else '')

@@ -1,7 +1,7 @@
-"""GPU box: per-stage ticks of recon_f16_kernel (SYN_RECON_PROF=1 makes launch_reconstruct_f16 run the instrumented variant
+"""GPU box: per-stage ticks of recon_f16_kernel (SYNERGY_HIP_TEST_KNOBS=recon_prof=1 makes launch_reconstruct_f16 run the instrumented variant
 and print averages per workgroup to stderr; s_memtime ticks are 10 ns)."""
 import os, sys
-os.environ['SYN_RECON_PROF'] = '1'
+os.environ['SYNERGY_HIP_TEST_KNOBS'] = 'recon_prof=1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from synergynet_amd import synth

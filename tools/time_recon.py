@@ -21,4 +21,4 @@ for rep in range(3):
     for _ in range(it): m.reconstruct(p, roi, dense=True, out=out)
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / it)
-print(('packed ' if len(sys.argv) > 3 else 'pitched ') + 'recon B=%d  %.4f ms  %.2f TB/s of mesh writes  env WGS=%s' % (B, best, B * 3 * 53215 * 4 / best / 1e9, os.environ.get('SYN_RECON_WGS', '-')))
+print(('packed ' if len(sys.argv) > 3 else 'pitched ') + 'recon B=%d  %.4f ms  %.2f TB/s of mesh writes  knobs=%s' % (B, best, B * 3 * 53215 * 4 / best / 1e9, os.environ.get('SYNERGY_HIP_TEST_KNOBS', '-')))
