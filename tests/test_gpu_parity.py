@@ -731,6 +731,50 @@ def test_resnet50_lds_tiled_gemm_is_bit_identical_to_the_wave_tiled_one(pack, B,
     assert tiled.range_status()[0] == 0
 
 
+_RESNET_VARIANT_SCRIPT = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from synergynet_amd import synth
+from synergynet_amd.synergy3DMM import SynergyNet
+m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_resnet50_state(int(sys.argv[3])), arch='resnet50')
+out = {}
+for B in [int(b) for b in sys.argv[4].split(',')]:
+    p, pool = m.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=900 + B)).cuda(), return_pool=True)
+    out['p%d' % B] = p.cpu().numpy(); out['q%d' % B] = pool.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+@pytest.mark.parametrize('env', [{'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=0'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=2'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=0'},
+                                 {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=1'}, {'SYNERGY_HIP_RESNET_FUSE': '1'}, {'SYNERGY_HIP_RESNET_FUSE': '2'}],
+                         ids=lambda e: ','.join(f'{a}={b}' for a, b in e.items()))
+def test_resnet50_round6_schedules_change_no_bit(pack, tmp_path, env):
+    """Round 6 (csrc/resnet_kernels.hip): the pipelined LDS-tiled GEMM (conv_lp_kernel: LDS-direct loads, three stages, two fragment sets) against the
+    register-staged one (conv_lt_kernel: test knob lt_glds=0; lt_glds=2: the pipeline on the 128-pixel tiles too), the two staging shapes
+    (lt_stage=0 / 1: whole 128-byte rows / fragment planes), and the bottleneck's conv2 in front of the fused conv3 + conv1 launch
+    (SYNERGY_HIP_RESNET_FUSE=1: conv2 as a launch of its own; 2: in front for layer 1 only) -- same K order, same product order, same epilogue
+    expression everywhere: the SAME BITS, on ragged pixel tiles (B = 9) and on batches that take every tile size (B = 136, 512)."""
+    import subprocess
+    import sys
+    import torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sizes = [9, 136, 512]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'r.npz')
+    r = subprocess.run([sys.executable, '-c', _RESNET_VARIANT_SCRIPT, root, out, '1357', ','.join(map(str, sizes))],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = np.load(out)
+    m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_resnet50_state(1357), arch='resnet50')
+    for B in sizes:
+        p, pool = m.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=900 + B)).cuda(), return_pool=True)
+        assert np.isfinite(p.cpu().numpy()).all()
+        assert np.array_equal(want['p%d' % B], p.cpu().numpy()), f'param B={B}'
+        assert np.array_equal(want['q%d' % B], pool.cpu().numpy()), f'pool B={B}'
+    assert m.range_status()[0] == 0
+
+
 def test_replica_ring_returns_the_bits_of_a_lone_replica(pack, backbone_sd):
     """streams.ReplicaRing: small batches submitted round-robin to three replicas (handle + stream each) while the others are still
     running -- different batches, different sizes, landmarks-only and dense -- give exactly what one model gives batch by batch."""
