@@ -522,7 +522,7 @@ void recon_f16_kernel(const unsigned *__restrict__ rec3, const unsigned *__restr
                 // the fetched operands is s_waitcnt vmcnt(12) -- these stores stay in flight across the barrier and into the
                 // next tile's MFMAs (with any branch around a store the wait degrades to vmcnt(0))
 #pragma unroll
-                for (int k = 0; k < 96 / RPI; ++k, o += ostep) *(f32x4 *)o = *(const f32x4 *)(sp + k * RPI * SS);
+                for (int k = 0; k < 96 / RPI; ++k, o += ostep) *(f32x4 *)o = *(const f32x4 *)(sp + k * RPI * SS);      // (non-temporal stores: 0.136 vs 0.137 ms alone, 1.036 vs 1.026 ms in the step -- no)
             } else {
                 const bool whole = vq + 3 < n_vert;
 #pragma unroll
