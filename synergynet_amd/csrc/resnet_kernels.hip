@@ -993,6 +993,12 @@ void launch_conv_f16x2(const float *in, const unsigned *W3, const float *scale, 
 #ifndef SYN_C3F_L2_MT
 #define SYN_C3F_L2_MT 2
 #endif
+#ifndef SYN_C3F_L1_MT
+#define SYN_C3F_L1_MT 2                // 16-pixel tiles per wave in layer 1's fused launches (1: half the registers, three workgroups per CU)
+#endif
+#ifndef SYN_C3F_L1_TC
+#define SYN_C3F_L1_TC 4                // output-channel tiles of conv3 per chunk in layer 1's middle blocks
+#endif
 // DS (layer1.0: 64 -> 256, stride 1): the block's downsample branch (1x1 conv + BN, resnet_backbone.py:127-128) is evaluated IN the kernel
 // instead of being read as `identity`: the block input of the workgroup's pixels (64 channels) stays in registers as a second B operand, the
 // downsample weights of a chunk come straight from L2 (natural K order, one tile ahead), and the 256-channel branch -- 472 MB written by a
@@ -1343,10 +1349,11 @@ bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3
                         const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1, const C2Args *c2) {
     if (K != 64 || Kd != 64 || N3 != 256 || N1 != 64) return false;
     const DsArgs ds{X, Wd, scale_d, shift_d};
-    const int m_tiles = (M + 127) / 128, grid = ((m_tiles + 7) / 8) * 8;
+    constexpr int MT = SYN_C3F_L1_MT;
+    const int m_tiles = (M + 64 * MT - 1) / (64 * MT), grid = ((m_tiles + 7) / 8) * 8;
     // (32-channel chunks: with 64 the second B operand spills)
-    if (c2) conv_c3f_kernel<2, 4, 2, 2, true, false, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds, *c2);
-    else conv_c3f_kernel<2, 4, 2, 2, true, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);
+    if (c2) conv_c3f_kernel<2, 4, MT, 2, true, false, true><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds, *c2);
+    else conv_c3f_kernel<2, 4, MT, 2, true, false><<<grid, 256, 0, s>>>(T2, W3, scale3, shift3, nullptr, out, W1f, s1, scale1, shift1, T1n, M, N3, m_tiles, stat3, stat1, ds);
     return true;
 }
 
@@ -1358,8 +1365,8 @@ bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, c
     if (N3 % 64 || N3 > 512) return false;
     if (c2 && K != 64 && K != 128) return false;
 #define SYN_C3F(KS3, NT1, MT, TC) launch_c3f_t<KS3, NT1, MT, TC>(T2, W3, scale3, shift3, identity, out, W1f, s1, scale1, shift1, T1n, M, N3, s, stat3, stat1, res_pair, c2)
-    if (K == 64 && N1 == 64) SYN_C3F(2, 4, 2, 4);              // layer 1
-    else if (K == 64 && N1 == 128) SYN_C3F(2, 8, 2, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)
+    if (K == 64 && N1 == 64) SYN_C3F(2, 4, SYN_C3F_L1_MT, SYN_C3F_L1_TC);      // layer 1
+    else if (K == 64 && N1 == 128) SYN_C3F(2, 8, SYN_C3F_L1_MT, 2);        // layer 1 -> layer 2 (32-channel chunks: 48 KB of LDS, < 256 registers)
     else if (K == 128 && N1 == 128) SYN_C3F(4, 8, SYN_C3F_L2_MT, 2);       // layer 2
     else return false;
 #undef SYN_C3F
