@@ -573,7 +573,7 @@ def main():
         # tools/make_profiles.py -> profiles/traffic_rN.json).  They are NOT measured by this run: counters_source says which file,
         # which commit and which box they are from, so a reader can tell a stale bundle from a fresh one.
         traffic = pipe_busy = counters_source = traffic_fwd = None
-        for name in ('traffic_r5.json', 'traffic_r4.json', 'traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
+        for name in ('traffic_r6.json', 'traffic_r5.json', 'traffic_r4.json', 'traffic_r3.json', 'traffic_r2.json', 'traffic_r1.json'):
             tfp = os.path.join(ROOT, 'profiles', name)
             if os.path.isfile(tfp) and B == 1024:
                 try:
