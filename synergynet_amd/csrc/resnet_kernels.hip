@@ -758,12 +758,21 @@ void conv_lt_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
 // lane-linear), fragment entry (pixel r, k-group g, piece p) at 16-byte slot 64 (r >> 3) + 8 (r & 7) + ((4 p + g) ^ (r & 6)): conflict-free
 // in the read lane groups.  Same K order and product order as conv_lt_kernel / conv_h2s_kernel: the same bits.
 // =====================================================================================
-template <int MTW, bool FRAG>
+// DUAL (round 6): a SECOND K segment behind the first -- a 1x1 convolution of another tensor (its own resolution, stride and width) onto the same
+// output grid, accumulated into the same registers: out = act(W [a ; x] + shift).  With the BatchNorm scales folded into the weights that is a
+// bottleneck's conv3 AND its stride-2 downsample branch in one GEMM (resnet_backbone.py:122-134, :127-128): the branch's fp32 tensor (134 MB written
+// and read back in layer3.0) never exists and its launch is gone.  W3 then holds steps + steps2 k32 steps per channel tile.
+struct DualSeg {
+    const float *in2 = nullptr;     // second input [B, Hin2, Hin2, Cin2], pair format
+    int Hin2 = 0, stride2 = 1, Cin2 = 0;
+    unsigned in2_bytes = 0;
+};
+template <int MTW, bool FRAG, bool DUAL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W3, const float *__restrict__ scale,
                     const float *__restrict__ shift, const float *__restrict__ residual, float *__restrict__ out, int M, int Hin,
                     int Hout, int Cin, int N, int KH, int KW, int stride, int pad, int act, int n_tiles, int m_tiles,
-                    float *__restrict__ stat, unsigned in_bytes, int fmt) {
+                    float *__restrict__ stat, unsigned in_bytes, int fmt, DualSeg d2 = DualSeg{}) {
 #if __HIP_DEVICE_COMPILE__      // (the HOST pass silently drops the kernel's launch stub when it has to instantiate this body -- the generic lambdas over device builtins; it only needs the signature)
     constexpr int PT = 4 * MTW, U = MTW / 2, NS = 3;
     static_assert(MTW == 2 || MTW == 4, "128 | 256 pixels per workgroup");
@@ -780,11 +789,11 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = mt_idx * (PT * 16);
     const int n0 = nt_idx * 128;
-    const int KCH = Cin >> 5, steps = KH * KW * KCH;
+    const int KCH = Cin >> 5, steps1 = KH * KW * KCH, steps = steps1 + (DUAL ? d2.Cin2 >> 5 : 0);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int sp = lane >> 3, sc = lane & 7;
     int py[U][2], px[U][2];                                       // [u][h]; FRAG: h = 0 only
-    unsigned pbase[U][2];
+    unsigned pbase[U][2], pbase2[DUAL ? U : 1][2];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -798,11 +807,14 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
             px[u][h] = (r % Hout) * stride - pad;
             const int chunk = FRAG ? g : (sc ^ (sp & 6));
             pbase[u][h] = (unsigned)(((pbi * Hin + py[u][h]) * Hin + px[u][h]) * Cin + 4 * chunk) * 4u;     // (wraps for padding rows: only used when the tap is inside)
+            if constexpr (DUAL)                                  // the second segment's pixel: (oy stride2, ox stride2) of its own image, no padding
+                pbase2[u][h] = (unsigned)(((pbi * d2.Hin2 + (r / Hout) * d2.stride2) * d2.Hin2 + (r % Hout) * d2.stride2) * d2.Cin2 + 4 * chunk) * 4u;
         }
     int roff[2];                                                  // dword offset inside a tile of this lane's fragment entry of piece p
 #pragma unroll
     for (int p = 0; p < 2; ++p) roff[p] = FRAG ? p * 256 + lane * 4 : (r16 >> 3) * 256 + ((r16 & 7) * 8 + ((4 * p + g) ^ (r16 & 6))) * 4;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(DUAL ? d2.in2 : in), 0, (int)(DUAL ? d2.in2_bytes : in_bytes), 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(W3), 0, 0x7fffffff, 0x00027000);
     const float inv_s = __builtin_bit_cast(float, W3[(size_t)(N / 16) * steps * 512 + 1]);
     f32x4 acc[MTW][4];
@@ -812,6 +824,7 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         for (int i = 0; i < 4; ++i) acc[j][i] = z4;
     const unsigned wbase = (unsigned)((n0 / 16 + wave) * steps) * 2048u;        // this wave's channel tile: both pieces of a step (bytes)
     const unsigned l16 = lane * 16;
+    bool seg2 = false;                                            // DUAL: the step the fetch pointer is at lies in the second segment (uniform)
     // the fetch pointer walks the steps in order: (tap row, tap column, k32 chunk) as running scalars; past the last step it stays there
     // (the last loads re-fetch it into stages nobody reads).  A tap outside the image: an offset past the end of the tensor = zeros.
     int f_s = 0, f_kc = 0, f_kx = 0, f_ky = 0, w_s = 0;
@@ -819,6 +832,8 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
     unsigned gw = 0;
     auto prepare = [&]() {                                       // the addresses of the fetch pointer's step; the pointer moves on
         const unsigned dlt = (unsigned)((f_ky * Hin + f_kx) * Cin + f_kc * 32) * 4u;
+        if constexpr (DUAL) seg2 = f_s >= steps1;
+        const unsigned dlt2 = DUAL ? (unsigned)(f_s - steps1) * 128u : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -826,10 +841,12 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
                 const int iy = py[u][h] + f_ky, ix = px[u][h] + f_kx;
                 const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Hin;
                 goff[u][h] = ok ? pbase[u][h] + dlt : 0x80000000u;
+                if constexpr (DUAL) goff[u][h] = seg2 ? pbase2[u][h] + dlt2 : goff[u][h];
             }
         const int adv = f_s + 1 < steps ? 1 : 0;
         f_s += adv;
-        f_kc += adv;
+        const int adv1 = DUAL ? (f_s < steps1 ? adv : 0) : adv;   // (the tap walk belongs to the first segment)
+        f_kc += adv1;
         const int c1 = f_kc == KCH ? 1 : 0;
         f_kc = c1 ? 0 : f_kc;
         f_kx += c1;
@@ -843,8 +860,9 @@ void conv_lp_kernel(const float *__restrict__ in, const unsigned *__restrict__ W
         constexpr int K = decltype(k_c)::value;
         if constexpr (K < 2 * U) {
             constexpr int u = K / 2, e = K % 2;                  // e: FRAG piece | row-shaped: pixel half
-            if (FRAG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][0], 64 * e, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][e], 0, 0, 0);
+            const __amdgpu_buffer_rsrc_t rs = DUAL && seg2 ? rs_in2 : rs_in;      // (a scalar select of the descriptor: no branch around a load)
+            if (FRAG) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][0], 64 * e, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sm + so + ((wave * U + u) * 2 + e) * 256), 16, goff[u][e], 0, 0, 0);
         } else {
             constexpr int pz = K - 2 * U;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sm + so + BF_DW + (wave * 2 + pz) * 256), 16, l16, gw + pz * 1024, 0, 0);
@@ -934,6 +952,23 @@ static void launch_conv_lt_t(const float *in, const unsigned *W3, const float *s
     else { if (frag) SYN_LT_LAUNCH(conv_lt_kernel, true); else SYN_LT_LAUNCH(conv_lt_kernel, false); }
 #undef SYN_LT_LAUNCH
 }
+
+// conv3 + stride-2 downsample branch of a bottleneck as ONE GEMM (conv_lp_kernel DUAL): a = T2 [B, H, H, C1] (1x1), x = the block input [B, Hin2, Hin2, Cin2] at
+// stride2; W3d = the folded weights' fragments, [N/16][C1/32 + Cin2/32][2][64][4], {S, 1/S}; ones / shift: [N].  false: shape not served (the caller launches the two).
+bool launch_conv_dual(const float *a, const float *x, const unsigned *W3d, const float *ones, const float *shift, float *out, int B, int H, int C1,
+                      int Hin2, int stride2, int Cin2, int N, int act, hipStream_t s, float *stat, int fmt) {
+    const int M = B * H * H, steps = (C1 + Cin2) / 32;
+    if (C1 % 32 || Cin2 % 32 || N % 128 || steps % 2 || (long)((M + 255) / 256) * (N / 128) < 256) return false;
+    if ((size_t)B * H * H * C1 * 4 >= (1ull << 31) || (size_t)B * Hin2 * Hin2 * Cin2 * 4 >= (1ull << 31) || (size_t)N * (C1 + Cin2) * 4 >= (1ull << 31)) return false;
+    const int n_tiles = N / 128, m_tiles = (M + 255) / 256, grid = ((m_tiles + 7) / 8) * n_tiles * 8;
+    DualSeg d2;
+    d2.in2 = x; d2.Hin2 = Hin2; d2.stride2 = stride2; d2.Cin2 = Cin2; d2.in2_bytes = (unsigned)((size_t)B * Hin2 * Hin2 * Cin2 * 4);
+    conv_lp_kernel<4, false, true><<<grid, 512, 0, s>>>(a, W3d, ones, shift, nullptr, out, M, H, H, C1, N, 1, 1, 1, 0, act, n_tiles, m_tiles, stat,
+                                                        (unsigned)((size_t)B * H * H * C1 * 4), fmt, d2);
+    return true;
+}
+// the (K, N1) combinations conv_c3f_kernel is instantiated for (launch_conv_c3f)
+bool conv_c3f_supported(int K, int N3, int N1) { return !(N3 % 64 || N3 > 512) && ((K == 64 && (N1 == 64 || N1 == 128)) || (K == 128 && N1 == 128)); }
 
 template <int MT, int NT>
 static void launch_conv_f16x2_t(const float *in, const unsigned *W3, const float *scale, const float *shift, const float *residual,

@@ -217,6 +217,10 @@ bool launch_conv_c3f(const float *T2, const unsigned *W3, const float *scale3, c
 bool launch_conv_c3f_ds(const float *T2, const unsigned *W3, const float *scale3, const float *shift3, const float *X, const unsigned *Wd,
                         const float *scale_d, const float *shift_d, float *out, const unsigned *W1f, const float *s1, const float *scale1,
                         const float *shift1, float *T1n, int M, int K, int Kd, int N3, int N1, hipStream_t s, float *stat3, float *stat1, const C2Args *c2 = nullptr);
+// conv3 + the stride-2 downsample branch of a bottleneck as one GEMM over [T2 ; x] with the BatchNorm scales folded into the weights (resnet_kernels.hip DUAL)
+bool launch_conv_dual(const float *a, const float *x, const unsigned *W3d, const float *ones, const float *shift, float *out, int B, int H, int C1,
+                      int Hin2, int stride2, int Cin2, int N, int act, hipStream_t s, float *stat, int fmt);
+bool conv_c3f_supported(int K, int N3, int N1);
 void launch_resnet_stem(const float *img_nchw, const uint8_t *img_hwc_u8, const float *w147x64, const float *scale,
                         const float *shift, float *out /*[B,60,60,64]*/, int B, hipStream_t s);
 // 7x7 stem on the fp16 matrix instructions (uint8 crops): As3 [group 2][k16 step 10][piece 2][lane 64][4 dwords], lane (i = channel 32G + i,

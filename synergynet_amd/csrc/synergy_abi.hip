@@ -194,7 +194,11 @@ struct RConv {
     size_t dst_wrm = 0;                                   // stem only: fragments + folded shift of resnet_stem_mfma_kernel
     size_t dst_w1f = 0;                                   // conv1 of a block that follows another block: its fragments step-major for conv_c3f_kernel (dwords), or 0
 };
-struct RBlock { int c1, c2, c3, ds; };
+struct RBlock {
+    int c1, c2, c3, ds;
+    size_t dst_w3d = 0, dst_ones = 0, dst_shiftd = 0;   // stride-2 downsample blocks: conv3 and the branch as ONE GEMM (folded weights' fragments, ones, summed shifts), or 0
+    int dual_idx = -1;                                   // bit of the third range word: the folded weights fail the fp16 weight criterion
+};
 struct ResNet50 {
     std::vector<RConv> convs;      // convs[0] = stem
     std::vector<RBlock> blocks;
@@ -243,6 +247,17 @@ struct ResNet50 {
             const size_t osz = (size_t)c.cout * c.hout * c.hout;
             buf_big = osz > buf_big ? osz : buf_big;
         }
+        {
+            int nd = 0;
+            for (auto &b : blocks)
+                if (b.ds >= 0 && convs[b.ds].stride == 2) {
+                    const RConv &c3 = convs[b.c3], &cd = convs[b.ds];
+                    b.dst_w3d = dst; dst += (size_t)c3.cout * (c3.cin + cd.cin) + 4;
+                    b.dst_ones = dst; dst += c3.cout;
+                    b.dst_shiftd = dst; dst += c3.cout;
+                    b.dual_idx = nd++;
+                }
+        }
         buf_mid = 128 * 30 * 30;                      // largest conv1 / conv2 output (layer2.0.conv1: 128 x 30 x 30)
         src_fc = src; src += (size_t)102 * 2048 + 102;
         flat_count = src;
@@ -266,7 +281,7 @@ struct ConstHeader {   // first 256 bytes of an exported constants buffer
 };
 static_assert(sizeof(ConstHeader) == 256, "header must be 256 bytes");
 constexpr uint64_t kMagic = 0x53594e4833353558ull;   // "SYNH355X"
-constexpr uint32_t kConstVersion = 5;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring; 4: clamp-form constants of the register-resident blocks; 5: ResNet-50 fragments with the output channels in pair order)
+constexpr uint32_t kConstVersion = 6;                // bumped whenever the packed encoding changes (2: per-column basis scales, range verdict; 3: stem fragments for the (R, G, B, -) row ring; 4: clamp-form constants of the register-resident blocks; 5: ResNet-50 fragments with the output channels in pair order; 6: + folded conv3 | downsample fragments)
 
 // verdict of the load-time range analysis of the fp16 x2 schedule (analyze_mbv2_ranges below); 64 dwords at Net::dst_range
 struct RangeInfo {
@@ -304,9 +319,9 @@ struct syn_handle {
                                    // uint8 stem + features.1 (stem_rm.hip)
                                    // (fused_block_rm.hip) instead of the tiled one (fused_block_early.hip, kept as a cross-check)
     float *d_range = nullptr;      // resnet50 run-time range guard: per-tensor max |x| of the last forward (kRangeSub sub-slots each) | its initial values
-    uint32_t resnet_w_unsafe[2] = {0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import)
+    uint32_t resnet_w_unsafe[3] = {0, 0, 0};   // bit i: convs[i] must run the fp32-MFMA kernel (weight criterion, set at load / import); word 2: bit j = the folded conv3 + downsample weights of dual block j fail it
     int resnet_gemm = 1;           // SYNERGY_HIP_RESNET_GEMM=0: every convolution on conv_h2s_kernel (cross-check of conv_lt_kernel; 2: its 128-pixel tiles only)
-    int resnet_fuse = 3;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel); 1: conv3 + conv1 fused; 2: ... and layer 1's conv2 in front of them; 3: layer 2's too (three blocks: 270 / 243 / 245 -> 256 / 234 / 235 us)
+    int resnet_fuse = 4;           // SYNERGY_HIP_RESNET_FUSE=0: conv3 and the next conv1 as two launches (cross-check of conv_c3f_kernel); 1: conv3 + conv1 fused; 2: ... and layer 1's conv2 in front of them; 3: layer 2's too (three blocks: 270 / 243 / 245 -> 256 / 234 / 235 us); 4: conv3 + the stride-2 downsample branch of layer3.0 / 4.0 as one GEMM
     int resnet_fp32 = 0;           // sticky: the guard found a tensor outside the fp16 window -> exact fp32-MFMA convolutions from now on
     unsigned *guard_word = nullptr;    // page-locked host word the head kernel of a poisoned forward writes (mapped: guard_word_dev is its device
     unsigned *guard_word_dev = nullptr; // alias); read WITHOUT synchronisation at the entry of the next forward -> automatic switch to fp32-MFMA
@@ -794,7 +809,8 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         bool ds_done = b.ds < 0;
         bool c2_done = false;
         const bool c3f_ok = f16 && h->resnet_fuse && !last && n.convs[b.c3].dst_w3 && n.convs[n.blocks[last ? bi : bi + 1].c1].dst_w1f &&
-                            n.convs[n.blocks[last ? bi : bi + 1].c1].hin == n.convs[b.c3].hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[last ? bi : bi + 1].c1);
+                            n.convs[n.blocks[last ? bi : bi + 1].c1].hin == n.convs[b.c3].hout && !unsafe_w(b.c3) && !unsafe_w(n.blocks[last ? bi : bi + 1].c1) &&
+                            syn::conv_c3f_supported(n.convs[b.c3].cin, n.convs[b.c3].cout, n.convs[n.blocks[last ? bi : bi + 1].c1].cout);
         // conv2 in front of the fused launch (64-channel bottlenecks, SYNERGY_HIP_RESNET_FUSE >= 2 = default): T2 never exists
         syn::C2Args c2a;
         const RConv &c2c = n.convs[b.c2];
@@ -836,8 +852,18 @@ int run_resnet50(syn_handle *h, const float *img, const uint8_t *img8, int B, fl
         }
         if (have_t1 && c2f) { float *t = T1; T1 = T2; T2 = t; }       // the next block's conv1 output sits in the other buffer
         if (c2_done && !have_t1) { conv(b.c2, T1, nullptr, T2, 1, 1, 0); c2_done = false; }      // (the fused launch did not take this shape after all)
+        // conv3 and a stride-2 downsample branch as ONE GEMM (SYNERGY_HIP_RESNET_FUSE >= 4 = default; the pipelined GEMM only): layer3.0, layer4.0
+        bool c3_done = false;
+        if (!have_t1 && !ds_done && f16 && h->resnet_fuse >= 4 && b.dst_w3d && !((h->resnet_w_unsafe[2] >> b.dual_idx) & 1u && h->range_guard) &&
+            !unsafe_w(b.c3) && !unsafe_w(b.ds) && syn::test_knob("lt_glds", 1) >= 1 && h->resnet_gemm == 1) {
+            const RConv &c3 = n.convs[b.c3], &cd = n.convs[b.ds];
+            c3_done = syn::launch_conv_dual(T2, X, reinterpret_cast<const unsigned *>(P + b.dst_w3d), P + b.dst_ones, P + b.dst_shiftd, Y, B, c3.hout, c3.cin,
+                                            cd.hin, cd.stride, cd.cin, c3.cout, 1, s, stat && resnet_stat_used(1 + b.c3) ? range_slot(stat, 1 + b.c3) : nullptr,
+                                            last ? 0 : syn::kFmtOutPair);
+            if (c3_done) ds_done = true;
+        }
         if (!ds_done) { conv(b.ds, X, nullptr, D, 0, 0, 0); identity = D; id_pair = 0; }
-        if (!have_t1) conv(b.c3, T2, identity, Y, 1, last ? 0 : 1, id_pair);      // out = relu(bn3(conv3) + identity)
+        if (!have_t1 && !c3_done) conv(b.c3, T2, identity, Y, 1, last ? 0 : 1, id_pair);      // out = relu(bn3(conv3) + identity)
         float *t = X; X = Y; Y = t;
     }
     // avgpool + heads; rows are packed (ori, shape, exp, tex) = the cat order (:242-246); the SynergyNet wrapper takes [:, :62]
@@ -1672,6 +1698,51 @@ static void pack_backbone_resnet50(const float *flat, std::vector<float> &pk) {
             pk[c.dst_shift + ch] = beta[ch] - mean[ch] * a;
         }
     }
+    // conv3 + stride-2 downsample branch as ONE GEMM (resnet_kernels.hip DUAL): out = relu(a3 (W3 t) + sh3 + ad (Wd x) + shd) = relu([a3 W3 | ad Wd] [t ; x] + (sh3 + shd)):
+    // the BatchNorm scales folded into the rows, one power of two S for the combined matrix, rows in pair order, K = conv3's channels then the branch's
+    for (const RBlock &b : n.blocks) {
+        if (!b.dst_w3d) continue;
+        const RConv &c3 = n.convs[b.c3], &cd = n.convs[b.ds];
+        const int N = c3.cout, K1 = c3.cin, K2 = cd.cin, K = K1 + K2, steps = K / 32;
+        std::vector<float> wf((size_t)N * K);
+        float mx = 0.f;
+        for (int nn = 0; nn < N; ++nn) {
+            const float a3 = pk[c3.dst_scale + nn], ad = pk[cd.dst_scale + nn];
+            for (int k = 0; k < K1; ++k) wf[(size_t)nn * K + k] = pk[c3.dst_w + (size_t)nn * K1 + k] * a3;
+            for (int k = 0; k < K2; ++k) wf[(size_t)nn * K + K1 + k] = pk[cd.dst_w + (size_t)nn * K2 + k] * ad;
+            pk[b.dst_ones + nn] = 1.0f;
+            pk[b.dst_shiftd + nn] = pk[c3.dst_shift + nn] + pk[cd.dst_shift + nn];
+        }
+        for (float v : wf) mx = fmaxf(mx, fabsf(v));
+        const float S = pow2_scale(mx);
+        unsigned *dp = reinterpret_cast<unsigned *>(pk.data() + b.dst_w3d);
+        float *tail = pk.data() + b.dst_w3d + (size_t)(N / 16) * steps * 512;
+        tail[0] = S; tail[1] = 1.0f / S;
+        bool bad = !std::isfinite(mx);
+        for (int nn = 0; nn < N && !bad; ++nn) {
+            double err = 0, mag = 0;
+            for (int k = 0; k < K; ++k) {
+                const float x = wf[(size_t)nn * K + k] * S;
+                const unsigned a = f16_rtz(x), bb = f16_rtz(x - f16_value(a));
+                err += fabs((double)x - (double)f16_value(a) - (double)f16_value(bb));
+                mag += fabs((double)x);
+            }
+            bad = err > mag * 7.62939453125e-6;
+        }
+        if (bad) reinterpret_cast<uint32_t *>(pk.data() + n.dst_range)[2] |= 1u << b.dual_idx;
+        for (int nt = 0; nt < N / 16; ++nt)
+            for (int st = 0; st < steps; ++st)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int rho = lane & 15, nn = 32 * (nt >> 1) + 8 * (rho >> 2) + 4 * (nt & 1) + (rho & 3);
+                        const int k0 = st * 32 + 8 * (lane >> 4) + 2 * d;
+                        const float x0 = wf[(size_t)nn * K + k0] * S, x1 = wf[(size_t)nn * K + k0 + 1] * S;
+                        const unsigned a0 = f16_rtz(x0), a1 = f16_rtz(x1);
+                        const unsigned b0 = f16_rtz(x0 - f16_value(a0)), b1 = f16_rtz(x1 - f16_value(a1));
+                        dp[((((size_t)nt * steps + st) * 2 + 0) * 64 + lane) * 4 + d] = a0 | (a1 << 16);
+                        dp[((((size_t)nt * steps + st) * 2 + 1) * 64 + lane) * 4 + d] = b0 | (b1 << 16);
+                    }
+    }
     {   // heads: flat order fc_tex, fc_ori, fc_shape, fc_exp (module order, resnet_backbone.py:185-188);
         // packed rows in the cat order ori | shape | exp | tex (:246)
         const float *src = flat + n.src_fc;
@@ -1993,7 +2064,7 @@ int syn_import_constants(syn_handle *h, const void *dev_src, size_t bytes, void 
         HIP_TRY(hipMemcpyAsync(h->d_backbone, d, hd.backbone_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
         h->ri = RangeInfo{};
         h->resnet_fp32 = 0; h->range_events = 0; h->guard_armed = 0; if (h->guard_word) { (void)hipDeviceSynchronize(); *(volatile unsigned *)h->guard_word = 0; }
-        h->resnet_w_unsafe[0] = h->resnet_w_unsafe[1] = 0;
+        h->resnet_w_unsafe[0] = h->resnet_w_unsafe[1] = h->resnet_w_unsafe[2] = 0;
         if (h->arch == 0) {          // the sender's verdict on its weights rides in the blob
             HIP_TRY(hipMemcpyAsync(&h->ri, d + net().dst_range * sizeof(float), sizeof h->ri, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));

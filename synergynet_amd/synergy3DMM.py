@@ -43,7 +43,7 @@ def parse_param_62(param):
 
 
 _HDR_MAGIC = 0x53594e4833353558          # "SYNH355X" (csrc/synergy_abi.hip ConstHeader)
-_HDR_VERSION = 5                         # kConstVersion: bumped whenever the packed encoding changes
+_HDR_VERSION = 6                         # kConstVersion: bumped whenever the packed encoding changes
 
 
 def parse_constants_header(raw: bytes) -> dict:

@@ -719,12 +719,14 @@ def test_resnet50_lds_tiled_gemm_is_bit_identical_to_the_wave_tiled_one(pack, B,
     sd = synth.make_resnet50_state(1357)
     cd = torch.from_numpy(synth.make_crops(B, seed=77 + B)).cuda()
     os.environ['SYNERGY_HIP_RESNET_GEMM'] = mode
+    os.environ['SYNERGY_HIP_RESNET_FUSE'] = '3'          # (4 folds conv3 + downsample of layer3.0 / 4.0 into one GEMM: other weights, other bits -- its own test below)
     try:
         tiled = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
         os.environ['SYNERGY_HIP_RESNET_GEMM'] = '0'
         plain = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
     finally:
         os.environ.pop('SYNERGY_HIP_RESNET_GEMM', None)
+        os.environ.pop('SYNERGY_HIP_RESNET_FUSE', None)
     pt, poolt = tiled.forward_crops_u8(cd, return_pool=True)
     pp, poolp = plain.forward_crops_u8(cd, return_pool=True)
     assert torch.equal(pt, pp) and torch.equal(poolt, poolp)
@@ -745,8 +747,9 @@ np.savez(sys.argv[2], **out)
 '''
 
 
-@pytest.mark.parametrize('env', [{'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=0'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=2'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=0'},
-                                 {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=1'}, {'SYNERGY_HIP_RESNET_FUSE': '1'}, {'SYNERGY_HIP_RESNET_FUSE': '2'}],
+@pytest.mark.parametrize('env', [{'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=0', 'SYNERGY_HIP_RESNET_FUSE': '3'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_glds=2', 'SYNERGY_HIP_RESNET_FUSE': '3'},
+                                 {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=0', 'SYNERGY_HIP_RESNET_FUSE': '3'}, {'SYNERGY_HIP_TEST_KNOBS': 'lt_stage=1', 'SYNERGY_HIP_RESNET_FUSE': '3'},
+                                 {'SYNERGY_HIP_RESNET_FUSE': '1'}, {'SYNERGY_HIP_RESNET_FUSE': '2'}],
                          ids=lambda e: ','.join(f'{a}={b}' for a, b in e.items()))
 def test_resnet50_round6_schedules_change_no_bit(pack, tmp_path, env):
     """Round 6 (csrc/resnet_kernels.hip): the pipelined LDS-tiled GEMM (conv_lp_kernel: LDS-direct loads, three stages, two fragment sets) against the
@@ -766,13 +769,48 @@ def test_resnet50_round6_schedules_change_no_bit(pack, tmp_path, env):
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     want = np.load(out)
-    m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_resnet50_state(1357), arch='resnet50')
+    os.environ['SYNERGY_HIP_RESNET_FUSE'] = '3'          # the comparison partner: everything of round 6 but the folded conv3 + downsample GEMM (other weights: its own test)
+    try:
+        m = SynergyNet(device='cuda:0', pack=synth.make_3dmm(n_vert=640), backbone_state=synth.make_resnet50_state(1357), arch='resnet50')
+    finally:
+        os.environ.pop('SYNERGY_HIP_RESNET_FUSE', None)
     for B in sizes:
         p, pool = m.forward_crops_u8(torch.from_numpy(synth.make_crops(B, seed=900 + B)).cuda(), return_pool=True)
         assert np.isfinite(p.cpu().numpy()).all()
         assert np.array_equal(want['p%d' % B], p.cpu().numpy()), f'param B={B}'
         assert np.array_equal(want['q%d' % B], pool.cpu().numpy()), f'pool B={B}'
     assert m.range_status()[0] == 0
+
+
+@pytest.mark.parametrize('B', [9, 136, 512])
+def test_resnet50_conv3_and_downsample_as_one_gemm(pack, B):
+    """Round 6, SYNERGY_HIP_RESNET_FUSE=4 (default): conv3 and the stride-2 downsample branch of layer3.0 / layer4.0 run as ONE GEMM over [T2 ; x] with both
+    BatchNorm scales folded into the weight rows (conv_lp_kernel DUAL; reference resnet_backbone.py:122-134, 127-128) -- the branch's fp32 tensor never exists.
+    Another rounding of the weights than the two launches: equal to fp32 rounding (1e-5) to FUSE=3, both within the tolerance of the oracle; ragged tiles (B = 9)."""
+    import torch
+    from oracle import resnet_torch
+    from synergynet_amd import synth
+    from synergynet_amd.synergy3DMM import SynergyNet
+    sd = synth.make_resnet50_state(2468)
+    crops = synth.make_crops(B, seed=1640 + B)
+    cd = torch.from_numpy(crops).cuda()
+    dual = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    os.environ['SYNERGY_HIP_RESNET_FUSE'] = '3'
+    try:
+        plain = SynergyNet(device='cuda:0', pack=pack, backbone_state=sd, arch='resnet50')
+    finally:
+        os.environ.pop('SYNERGY_HIP_RESNET_FUSE', None)
+    pd_, poold = dual.forward_crops_u8(cd, return_pool=True)
+    pp, poolp = plain.forward_crops_u8(cd, return_pool=True)
+    g, w = pd_.cpu().numpy().astype(np.float64), pp.cpu().numpy().astype(np.float64)
+    per_face = np.abs(g - w).max(axis=1) / np.abs(w).max(axis=1)
+    assert per_face.max() < 1e-5, f'face {per_face.argmax()}: {per_face.max():.3e}'
+    assert rel_max(poold.cpu().numpy(), poolp.cpu().numpy()) < 1e-5
+    pick = np.unique(np.r_[0, B // 2, B - 1])
+    want = resnet_torch.resnet50_forward(sd, synth.normalize_crops(crops[pick]))[0].numpy()[:, :62]
+    assert rel_max(pd_[torch.from_numpy(pick).cuda()].cpu().numpy(), want) < TOL
+    assert torch.equal(dual.forward_crops_u8(cd), pd_)                 # deterministic
+    assert dual.range_status()[0] == 0
 
 
 def test_replica_ring_returns_the_bits_of_a_lone_replica(pack, backbone_sd):
