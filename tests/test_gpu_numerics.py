@@ -91,6 +91,30 @@ def test_adversarial_checkpoint_matches_oracle(pack, base_sd, case, B):
     assert err.max() < TOL, f'{case} B={B}: face {err.argmax()} rel err {err.max():.3e}'
 
 
+@pytest.mark.parametrize('B', [8, 1024])
+def test_checkpoint_no_block_of_which_passes_the_range_proof(pack, B):
+    """bench.py's `extra.all_blocks_fallback` workload (synth.make_unprovable_backbone_state: the expand rows of EVERY block spread over eight decades, BatchNorm
+    shift zeroed): the load-time analysis sends all 16 blocks to their exact fp32-MFMA kernels, and what that schedule computes is the oracle's answer --
+    the floor a user of an unseen checkpoint gets is a correct one (reference synergy3DMM.py:109-113, 156-164: any checkpoint loads and answers)."""
+    import torch
+    import warnings
+    from oracle import backbone_torch
+    from synergynet_amd import synth
+    sd = synth.make_unprovable_backbone_state()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = make_model(pack, sd)
+    n_fb, report = model.numerics_report()
+    assert n_fb == 16, report
+    crops = adv.extreme_crops(B)
+    got = model.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
+    assert np.isfinite(got).all()
+    pick = np.unique(np.r_[0, 1, B // 2, B - 1])
+    want, _ = backbone_torch.mobilenet_v2_forward(sd, synth.normalize_crops(crops[pick]))
+    err = per_face_err(got[pick], want.numpy())
+    assert err.max() < TOL, f'B={B}: face {err.argmax()} rel err {err.max():.3e}'
+
+
 @pytest.mark.parametrize('B', [8, 776])
 def test_the_adversarial_cases_do_break_the_unguarded_schedule(pack, base_sd, B):
     """SYNERGY_HIP_RANGE_GUARD=0 ignores the load-time verdict: the same checkpoints then run the fp16x2 kernels out of range and
