@@ -1,7 +1,16 @@
-// gfx950 kernels for the ResNet-50 backbone variant (BASELINE config 5; reference
-// backbone_nets/resnet_backbone.py:90-136 Bottleneck, :139-254 ResNet): 7x7/2 stem + BN + ReLU, 3x3/2 max-pool,
-// and one implicit-GEMM convolution kernel (any kh x kw / stride / pad, NHWC fp32) on v_mfma_f32_16x16x4_f32
-// with a fused BN (+ residual) + ReLU epilogue that serves every 1x1 and 3x3 convolution of the bottlenecks.
+// gfx950 kernels for the ResNet-50 backbone variant (BASELINE config 5; reference backbone_nets/resnet_backbone.py:90-136 Bottleneck, :139-254 ResNet).
+// What is in this file, in the order of a forward (round 6):
+//   resnet_stem_mfma_kernel   7x7/2 stem + BN + ReLU on v_mfma_f32_32x32x16_f16 from raw uint8 crops, the 3x3/2 max-pool in its epilogue
+//                             (fp32 crops / small batches: resnet_stem_kernel + maxpool3x3s2_kernel)
+//   conv_h2s_kernel           implicit GEMM, 128 pixels x 64 channels, weights through LDS chunks: layer1.0's conv1
+//   conv_c3f_kernel           a bottleneck's conv2 (C2F) + conv3 + identity (or in-kernel downsample, DS) + ReLU + the NEXT bottleneck's conv1: layers 1 / 2
+//   conv_lp_kernel            the LDS-tiled implicit GEMM as a pipeline (LDS-direct loads, three stages, two fragment sets): long-K convolutions of
+//                             layers 2-4; DUAL: conv3 + stride-2 downsample branch as one GEMM (layer3.0 / 4.0)
+//   conv_lt_kernel            the same tile with a register ring, two workgroups per CU: the short-K 1x1 convolutions (conv3, downsample)
+//   conv_f16x2_kernel         64-bit addressing fallback (tensors of 2 GiB and more);  conv_kernel: exact fp32 MFMA (fp32 handles, weight-unsafe convolutions)
+//   pool_fc_generic_kernel    average pool + the four heads + the verdict of the run-time range guard
+// Every fp16 x2 kernel takes its operands as two fp16 pieces (fp32-class results: fused_block_f16.hip); activations travel between the kernels
+// in the PAIR format below; one epilogue function (conv_epilogue) serves them all.
 #include <cstdlib>
 #include <type_traits>
 
@@ -15,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Implicit-GEMM convolution.   out[m][n] = act( sum_{tap,k} in[pix(m,tap)][k] * W[n][tap*Cin + k] * scale[n] + shift[n] (+ res[m][n]) )
 // Same operand convention as pointwise_kernel (backbone_kernels.hip): MFMA "A" rows = 16 output channels (weights,
 // [Npad][KH*KW*Cin] row-major), MFMA "B" cols = 16 output pixels; a lane owns 4 consecutive channels of one pixel.
-// The K axis is walked tap by tap, 16 input channels at a time; a lane's operand fetch for tap (ky,kx) is one float4
+// (exact fp32-MFMA kernel, conv_kernel)  The K axis is walked tap by tap, 16 input channels at a time; a lane's operand fetch for tap (ky,kx) is one float4
 // of the input pixel (oy*s-p+ky, ox*s-p+kx), or zeros outside the image (zero padding).  Operands go straight from
 // L1/L2 to registers (no LDS): fp32 MFMA is slow enough that 8 x 1 KiB of operand traffic per 64 MFMAs is noise.
 // Requires Cin % 16 == 0 and Cout % 4 == 0 (true for every ResNet-50 convolution after the stem).
@@ -500,13 +509,12 @@ static void launch_conv_h2s_t(const float *in, const unsigned *W3, const float *
 // The deep layers (3 / 4: 55 % of the forward) on a workgroup tile of 64 MTW pixels x 128 output channels, BOTH operands through LDS.
 // conv_h2s_kernel's tile is 64 (MT = 1) or 128 pixels x 64 channels: per k32 step a CU moves 128 B x (pixels + channels) through its
 // vector cache (64 B/cycle) for 12 (pixels / 16)(channels / 16) matrix-pipe cycles -- 256 against 192 cycles for 64 x 64, more bytes than the
-// cache delivers in the time the MFMAs take, and every fp32 activation is split by the one wave that owns its pixel while three of
-// four SIMDs wait for theirs.  Here eight waves (4 along pixels x 2 along channels, 16 MTW pixels x 64 channels of accumulators each)
-// share a step's operands: each wave fetches 1/8 of the step's activations (fp32, implicit-GEMM addressing as above) and 1/8 of its
-// weight fragments into registers steps AHEAD, splits the activations once and parks both as ready-made MFMA fragments in the
+// cache delivers in the time the MFMAs take.  Here eight waves (4 along pixels x 2 along channels, 16 MTW pixels x 64 channels of accumulators each)
+// share a step's operands: each wave fetches 1/8 of the step's activations (pair format, implicit-GEMM addressing as above) and 1/8 of its
+// weight fragments into registers steps AHEAD and parks both as ready-made MFMA fragments in the
 // other half of a double buffer ([pixel tile][piece][slot 64][4] / [channel tile][piece][lane][4]: a fragment read is a lane's own
 // 16 bytes); one barrier per step.  Per step and CU (MTW = 4): 48 KB through the vector cache = 768 cycles against
-// 1536 matrix-pipe cycles per SIMD; an activation is split once per 128 output channels instead of once per 64.
+// 1536 matrix-pipe cycles per SIMD.
 // What made it fast (91 -> 55 us for layer 3's conv1; the tile alone: 91 vs conv_h2s_kernel's 92) is that NOTHING consumes a loaded
 // register before the step that parks it: buffer loads whose out-of-range offsets return the padding zeros (a select behind the load
 // made the compiler wait for it at once), a branch-free loop body (its vmcnt bookkeeping gives up at joins), a raw barrier, loads two
