@@ -676,6 +676,29 @@ def test_resnet50_matches_reference_golden_and_oracle(resnet_model):
     assert tuple(mesh.shape) == (33, 3, 53215) and torch.isfinite(mesh).all()
 
 
+def test_resnet50_batch_sizes_across_every_kernel_threshold(resnet_model):
+    """The ResNet-50 launchers pick kernels by shape (csrc/resnet_kernels.hip launch_conv_f16x2 / launch_conv_dual: M >= 4096 for the LDS-tiled GEMMs, 256 workgroup tiles for
+    the 256-pixel tile and for the one-GEMM conv3 + downsample, K >= 1024 for the pipelined 128-pixel tile; synergy_abi.hip: B >= 128 for the matrix-pipe stem): batches on
+    both sides of each threshold, every face of the small ones and a sample of the large ones against the oracle; a face's result does not depend on the batch it rides in
+    beyond fp32 rounding."""
+    import torch
+    from oracle import resnet_torch
+    from synergynet_amd import synth
+    sd = synth.make_resnet50_state(2468)
+    ref = {}
+    for B in (2, 4, 5, 17, 63, 64, 65, 127, 128, 129, 255, 257, 300, 511, 513):
+        crops = synth.make_crops(B, seed=5000)                  # (a prefix of one fixed sequence of faces: face i is the same image in every batch)
+        got = resnet_model.forward_crops_u8(torch.from_numpy(crops).cuda()).cpu().numpy()
+        assert np.isfinite(got).all(), B
+        pick = [i for i in (0, 1, B // 2, B - 1) if i not in ref]
+        if pick:
+            want = resnet_torch.resnet50_forward(sd, synth.normalize_crops(crops[pick]))[0].numpy()[:, :62]
+            ref.update({i: w for i, w in zip(pick, want)})
+        for i in sorted(set((0, 1, B // 2, B - 1))):
+            assert rel_max(got[i:i + 1], ref[i][None]) < TOL, f'B={B} face {i}'
+    assert resnet_model.range_status()[0] == 0
+
+
 @pytest.mark.parametrize('B', [7, 136, 512])
 def test_resnet50_fused_conv3_conv1_equals_separate_launches(pack, B):
     """conv_c3f_kernel (conv3 + BN + identity + ReLU of a bottleneck and the next bottleneck's conv1 + BN + ReLU in one launch, layers 1
